@@ -1,0 +1,141 @@
+"""ctypes binding of libasp_hip.so (the C ABI declared in include/asp.h).
+
+There is no CPU fallback anywhere in this package: if the shared object is
+missing and cannot be built, or no GPU is visible when a compute entry point is
+called, an :class:`AspError` is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import build as _build
+
+c_void_p = ctypes.c_void_p
+c_u64 = ctypes.c_uint64
+c_u32 = ctypes.c_uint32
+c_i32 = ctypes.c_int32
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_double = ctypes.c_double
+
+
+class AspError(RuntimeError):
+    """A libasp_hip call failed; ``code`` is the asp_status."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__("libasp_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+class SaInfo(ctypes.Structure):
+    """Mirror of ``asp_sa_info`` (include/asp.h)."""
+
+    _fields_ = [
+        ("num_spins", c_u64),
+        ("nnz_offdiag", c_u64),
+        ("ell_entries", c_u64),
+        ("num_colors", c_u32),
+        ("num_blocks", c_u32),
+        ("max_degree", c_u32),
+        ("energy_scale_exp", c_i32),
+        ("diag_sum", c_double),
+        ("beta0_auto", c_double),
+        ("beta1_auto", c_double),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/asp.h declares
+SIGNATURES = {
+    "asp_last_error": (ctypes.c_char_p, []),
+    "asp_last_error_code": (c_int, []),
+    "asp_clear_error": (None, []),
+    "asp_device_count": (c_int, []),
+    "asp_set_device": (c_int, [c_int]),
+    "asp_version": (ctypes.c_char_p, []),
+    "build_matrix": (c_u64, [c_u64] + [c_void_p] * 11),
+    "extract_signs": (None, [c_u64, c_void_p, c_void_p]),
+    "asp_build_create": (c_void_p, [c_u64, c_u64]),
+    "asp_build_upload": (c_int, [c_void_p] * 8),
+    "asp_build_run": (c_int, [c_void_p, ctypes.POINTER(c_u64)]),
+    "asp_build_last_ms": (c_float, [c_void_p]),
+    "asp_build_download": (c_int, [c_void_p] * 5),
+    "asp_build_destroy": (None, [c_void_p]),
+    "asp_ising_elements": (c_int, [c_u64, c_void_p, c_void_p, c_u64] + [c_void_p] * 7),
+    "asp_sa_plan_create": (c_void_p, [c_u64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "asp_sa_plan_destroy": (None, [c_void_p]),
+    "asp_sa_plan_info": (c_int, [c_void_p, ctypes.POINTER(SaInfo)]),
+    "asp_sa_layout_host": (c_int, [c_u64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   ctypes.POINTER(SaInfo), c_void_p, c_void_p]),
+    "asp_sa_set_launch": (c_int, [c_void_p, c_int, c_int]),
+    "asp_sa_anneal": (c_int, [c_void_p, c_u64, c_void_p, c_u32, c_u32, c_u32, c_void_p, c_void_p,
+                              c_void_p]),
+    "asp_sa_last_sweep_ms": (c_float, [c_void_p]),
+    "asp_sa_last_total_ms": (c_float, [c_void_p]),
+    "asp_sa_last_stats": (c_int, [c_void_p, c_u32, c_void_p, c_void_p]),
+    "asp_sa_last_launch": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                                   ctypes.POINTER(c_int)]),
+    "asp_sa_energy": (c_int, [c_void_p, c_u32, c_void_p, c_void_p]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def library_path() -> str:
+    return _build.LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load (building first if the sources changed and hipcc is present)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    try:
+        path = _build.build()
+    except Exception as exc:  # no hipcc / read-only tree: use the shipped .so if any
+        if not os.path.exists(path):
+            raise AspError(-2, "libasp_hip.so is missing and could not be built: %s" % exc)
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI mismatch, fail loudly
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().asp_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise AspError(rc, last_error())
+
+
+def check_recorded() -> None:
+    """For the reference-signature symbols, which cannot return a status."""
+    lib = load()
+    code = lib.asp_last_error_code()
+    if code != 0:
+        raise AspError(code, last_error())
+
+
+def device_count() -> int:
+    n = load().asp_device_count()
+    if n < 0:
+        raise AspError(n, last_error())
+    return n
+
+
+def require_gpu() -> None:
+    if device_count() <= 0:
+        raise AspError(-1, "no HIP device visible; this package has no CPU fallback")
+
+
+def ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(c_void_p)

@@ -1,0 +1,237 @@
+"""The ``ising_glass_annealer`` surface the reference uses (``import
+ising_glass_annealer as sa``; annealing_sign_problem/common.py:8), served by the
+gfx950 sweep kernel through the C ABI:
+
+    sa.Hamiltonian(exchange, field)      common.py:204,681
+    sa.anneal(h, seed=, number_sweeps=, repetitions=, only_best=)
+                                         common.py:242-248,
+                                         experiments/full_hilbert_space.py:212-218
+    sa.anneal(h, x0, seed=, number_sweeps=, beta0=, beta1=)   (legacy keywords)
+                                         annealing_sign_problem/train.py:238-245,297
+    sa.signs_to_bits / sa.bits_to_signs  common.py:205,224-225,258-260
+    sa.greedy_solve(h)                   common.py:250
+
+Conventions pinned by the reference: the solver MINIMISES
+``E(s) = sum_ij J_ij s_i s_j + sum_i h_i s_i`` (full double sum, diagonal
+included, no 1/2: common.py:757-760, experiments/full_hilbert_space.py:142-145);
+bit ``i`` of word ``i // 64`` is set iff ``s_i = +1`` (cbits/build_matrix.c:72-74).
+The annealing schedule, RNG and sweep order are this package's own
+specification: the reference's annealer is a third-party library
+whose internals are not available.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+import scipy.sparse
+
+from . import _lib
+
+__all__ = [
+    "Hamiltonian",
+    "anneal",
+    "greedy_solve",
+    "signs_to_bits",
+    "bits_to_signs",
+    "make_schedule",
+]
+
+
+def signs_to_bits(signs) -> np.ndarray:
+    """Pack a ±1 array: bit i of word i // 64 is set iff ``signs[i] > 0``."""
+    signs = np.asarray(signs)
+    n = signs.shape[0]
+    positive = (signs > 0).astype(np.uint8)
+    padded = np.zeros(((n + 63) // 64) * 64, dtype=np.uint8)
+    padded[:n] = positive
+    return np.packbits(padded.reshape(-1, 64), axis=1, bitorder="little").view("<u8").reshape(-1)
+
+
+def bits_to_signs(bits, count: int) -> np.ndarray:
+    """Unpack ``count`` spins to a float64 array of ±1."""
+    bits = np.ascontiguousarray(bits, dtype="<u8").reshape(-1)
+    count = int(count)
+    if count > bits.shape[0] * 64:
+        raise ValueError("'bits' holds fewer than {} spins".format(count))
+    unpacked = np.unpackbits(bits.view(np.uint8), bitorder="little")[:count]
+    return 2.0 * unpacked.astype(np.float64) - 1.0
+
+
+def make_schedule(beta0: float, beta1: float, number_sweeps: int) -> np.ndarray:
+    """Geometric inverse-temperature ladder beta0 -> beta1, one value per sweep."""
+    number_sweeps = int(number_sweeps)
+    if number_sweeps <= 0:
+        return np.zeros(0, dtype=np.float64)
+    if not (beta0 > 0 and beta1 > 0 and np.isfinite(beta0) and np.isfinite(beta1)):
+        raise ValueError("beta0 and beta1 must be positive and finite")
+    if number_sweeps == 1:
+        return np.array([beta1], dtype=np.float64)
+    return np.geomspace(beta0, beta1, number_sweeps).astype(np.float64)
+
+
+class Hamiltonian:
+    """Classical Ising Hamiltonian ``E(s) = s^T J s + h^T s`` resident on the GPU.
+
+    ``exchange`` may be any scipy sparse matrix (the reference hands over COO,
+    common.py:196,204); it is stored as canonical CSR so that the reference's
+    later ``.tocoo()``, ``.tocsr()`` and ``[mask][:, mask]`` uses work
+    (common.py:444,654,674).
+    """
+
+    def __init__(self, exchange, field):
+        matrix = scipy.sparse.csr_matrix(exchange, dtype=np.float64)
+        if matrix.shape[0] != matrix.shape[1]:
+            raise ValueError("'exchange' must be square, got {}".format(matrix.shape))
+        matrix.sum_duplicates()
+        matrix.sort_indices()
+        field = np.ascontiguousarray(field, dtype=np.float64)
+        if field.shape != (matrix.shape[0],):
+            raise ValueError("'field' must have shape ({},)".format(matrix.shape[0]))
+        self.exchange = matrix
+        self.field = field
+        self._plan = None
+        self._plan_key = None
+
+    @property
+    def shape(self) -> Tuple[int, int]:
+        return self.exchange.shape
+
+    @property
+    def size(self) -> int:
+        return self.exchange.shape[0]
+
+    # -- device plan -----------------------------------------------------------
+    def _arrays(self):
+        m = self.exchange
+        return (
+            np.ascontiguousarray(m.indptr, dtype=np.int64),
+            np.ascontiguousarray(m.indices, dtype=np.int32),
+            np.ascontiguousarray(m.data, dtype=np.float64),
+            np.ascontiguousarray(self.field, dtype=np.float64),
+        )
+
+    def plan(self):
+        """The (cached) device-resident sweep plan handle."""
+        key = (id(self.exchange), id(self.field), self.exchange.nnz)
+        if self._plan is not None and self._plan_key == key:
+            return self._plan
+        self.release()
+        lib = _lib.load()
+        _lib.require_gpu()
+        indptr, indices, data, field = self._arrays()
+        handle = lib.asp_sa_plan_create(ctypes.c_uint64(self.size), _lib.ptr(indptr),
+                                        _lib.ptr(indices), _lib.ptr(data), _lib.ptr(field))
+        if not handle:
+            raise _lib.AspError(lib.asp_last_error_code(), _lib.last_error())
+        self._plan = ctypes.c_void_p(handle)
+        self._plan_key = key
+        return self._plan
+
+    def info(self) -> _lib.SaInfo:
+        info = _lib.SaInfo()
+        _lib.check(_lib.load().asp_sa_plan_info(self.plan(), ctypes.byref(info)))
+        return info
+
+    def release(self) -> None:
+        if self._plan is not None:
+            try:
+                _lib.load().asp_sa_plan_destroy(self._plan)
+            finally:
+                self._plan = None
+                self._plan_key = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    # -- energy ----------------------------------------------------------------
+    def energy(self, x) -> float:
+        """E(x) of one packed configuration (experiments/full_hilbert_space.py:144)."""
+        return float(self.energies(np.asarray(x).reshape(1, -1))[0])
+
+    def energies(self, xs) -> np.ndarray:
+        words = (self.size + 63) // 64
+        xs = np.ascontiguousarray(xs, dtype=np.uint64).reshape(-1, max(words, 1))
+        if xs.shape[1] != max(words, 1):
+            raise ValueError("configurations must have {} words".format(words))
+        out = np.zeros(xs.shape[0], dtype=np.float64)
+        _lib.check(_lib.load().asp_sa_energy(self.plan(), ctypes.c_uint32(xs.shape[0]),
+                                             _lib.ptr(xs), _lib.ptr(out)))
+        return out
+
+
+def _resolve_seed(seed) -> int:
+    if seed is None:
+        return int.from_bytes(os.urandom(8), "little")
+    return int(seed) & (2**64 - 1)
+
+
+def anneal_raw(hamiltonian: Hamiltonian, seed: int, betas: np.ndarray, repetitions: int,
+               replica_offset: int = 0, x0=None):
+    """All chains, no reduction: (xs[R, words] uint64, es[R] float64)."""
+    lib = _lib.load()
+    plan = hamiltonian.plan()
+    words = (hamiltonian.size + 63) // 64
+    betas = np.ascontiguousarray(betas, dtype=np.float64)
+    xs = np.zeros((repetitions, max(words, 1)), dtype=np.uint64)
+    es = np.zeros(repetitions, dtype=np.float64)
+    if x0 is not None:
+        x0 = np.ascontiguousarray(x0, dtype=np.uint64).reshape(-1)
+        if x0.shape[0] != words:
+            raise ValueError("'x0' must have {} words".format(words))
+    _lib.check(lib.asp_sa_anneal(plan, ctypes.c_uint64(seed), _lib.ptr(betas),
+                                 ctypes.c_uint32(betas.shape[0]), ctypes.c_uint32(repetitions),
+                                 ctypes.c_uint32(replica_offset), _lib.ptr(x0), _lib.ptr(xs),
+                                 _lib.ptr(es)))
+    return xs[:, :words], es
+
+
+def anneal(hamiltonian: Hamiltonian, x0=None, seed=None, number_sweeps: int = 5120,
+           beta0: Optional[float] = None, beta1: Optional[float] = None, repetitions: int = 1,
+           only_best: bool = True, distributed: bool = True):
+    """Simulated annealing of ``hamiltonian``.
+
+    Returns ``(x, e)``: with ``only_best=True`` the best packed configuration
+    (``uint64[ceil(K/64)]``) over all repetitions and its energy; with
+    ``only_best=False`` the per-repetition arrays ``(xs[R, words], es[R])``
+    (zip-able, experiments/full_hilbert_space.py:176).
+
+    When ``torch.distributed`` is initialised with more than one rank (and
+    ``distributed`` is true) the repetitions are sharded over the ranks and
+    gathered at the end (see :mod:`.distributed`); every rank returns the full
+    result, identical to a single-GPU run with the same seed.
+    """
+    if not isinstance(hamiltonian, Hamiltonian):
+        raise TypeError("'hamiltonian' must be a Hamiltonian")
+    repetitions = int(repetitions)
+    if repetitions < 1:
+        raise ValueError("'repetitions' must be positive")
+    seed = _resolve_seed(seed)
+    if beta0 is None or beta1 is None:
+        info = hamiltonian.info()
+        beta0 = info.beta0_auto if beta0 is None else beta0
+        beta1 = info.beta1_auto if beta1 is None else beta1
+    betas = make_schedule(float(beta0), float(beta1), number_sweeps)
+
+    from . import distributed as _dist  # late import: torch is optional plumbing
+
+    if distributed and _dist.world_size() > 1:
+        xs, es = _dist.anneal_sharded(hamiltonian, seed, betas, repetitions, x0)
+    else:
+        xs, es = anneal_raw(hamiltonian, seed, betas, repetitions, 0, x0)
+    if only_best:
+        best = int(np.argmin(es))  # first minimum: deterministic tie-break
+        return xs[best].copy(), float(es[best])
+    return xs, es
+
+
+def greedy_solve(hamiltonian: Hamiltonian):
+    """Strongest-coupling-first greedy sign assignment (common.py:250)."""
+    from .greedy import greedy_solve as _greedy
+
+    return _greedy(hamiltonian)

@@ -1,0 +1,91 @@
+"""In-tree build of libasp_hip.so (hipcc, gfx950 only).
+
+``python -m annealing_sign_problem_amd.build`` or ``__graft_entry__.build()``.
+The shared object lands next to this file so that it travels with the tree to
+the GPU box; nothing is installed into site-packages.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+LIB_NAME = "libasp_hip.so"
+LIB_PATH = os.path.join(HERE, LIB_NAME)
+STAMP_PATH = os.path.join(HERE, ".libasp_hip.stamp")
+
+SOURCES = [
+    "asp_common.hip",
+    "build_matrix.hip",
+    "ising_elements.hip",
+    "sa_plan.cpp",
+    "sa_sweep.hip",
+]
+
+# -ffp-contract=off: the parity contract needs every multiply/add rounded on its
+# own unless the source says fma().
+HIPCC_FLAGS = [
+    "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+    "-ffp-contract=off", "-fno-fast-math",
+    "-Wall", "-Wextra", "-Wno-unused-parameter",
+]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found; libasp_hip.so cannot be built")
+
+
+def _fingerprint(sources: list[str]) -> str:
+    h = hashlib.sha256()
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    deps = list(sources)
+    for d in (CSRC, INCLUDE):
+        for name in sorted(os.listdir(d)):
+            if name.endswith((".h", ".hpp")):
+                deps.append(os.path.join(d, name))
+    for path in deps:
+        h.update(path.encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    sources = [os.path.join(CSRC, s) for s in SOURCES]
+    missing = [s for s in sources if not os.path.exists(s)]
+    if missing:
+        raise RuntimeError("missing sources: " + ", ".join(missing))
+    fp = _fingerprint(sources)
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(STAMP_PATH):
+        with open(STAMP_PATH) as f:
+            if f.read().strip() == fp:
+                return LIB_PATH
+    if not os.access(HERE, os.W_OK):
+        if os.path.exists(LIB_PATH):
+            return LIB_PATH
+        raise RuntimeError("cannot build: %s is not writable" % HERE)
+    cmd = [hipcc(), *HIPCC_FLAGS, "-I", INCLUDE, "-I", CSRC, "-x", "hip", *sources, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        sys.stderr.write(proc.stdout + proc.stderr)
+        raise RuntimeError("hipcc failed building " + LIB_NAME)
+    if verbose and proc.stderr:
+        sys.stderr.write(proc.stderr)
+    with open(STAMP_PATH, "w") as f:
+        f.write(fp)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

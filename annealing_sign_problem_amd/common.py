@@ -1,0 +1,319 @@
+"""Entry points of ``annealing_sign_problem.common`` on the MI355X path.
+
+Same names, arguments and return values as the reference functions cited in
+each docstring, so a caller of the reference (``process_cluster`` in
+experiments/sampled_connected_components.py:726-751, the CLIs at
+annealing_sign_problem/common.py:838-1002) can switch the import.  The two
+numba kernels of the coupling build and the annealer run on the GPU through
+libasp_hip.so; orchestration stays numpy/scipy exactly where the reference's is.
+"""
+from __future__ import annotations
+
+import ctypes
+import warnings
+from dataclasses import dataclass
+from typing import Any, Callable, Optional, Tuple
+
+import numpy as np
+import scipy.sparse
+from scipy.sparse.csgraph import connected_components
+
+from . import _lib
+from . import annealer as sa
+
+__all__ = [
+    "IsingModel",
+    "make_ising_model",
+    "solve_ising_model",
+    "compute_accuracy_and_overlap",
+    "make_hamiltonian_extension",
+    "sparsify_using_global_cutoff",
+    "get_strongest_off_diag",
+    "binary_search",
+    "monte_carlo_sampling",
+    "add_noise_to_amplitudes",
+    "ground_state_to_log_coeff_fn",
+    "SamplingResult",
+]
+
+APPLY_CHUNK = 10000  # rows per batched_apply call (common.py:85)
+
+
+@dataclass
+class IsingModel:
+    """common.py:46-55."""
+
+    spins: np.ndarray
+    quantum_hamiltonian: Any
+    ising_hamiltonian: sa.Hamiltonian
+    initial_signs: np.ndarray
+
+    @property
+    def size(self) -> int:
+        return self.spins.shape[0]
+
+
+def _normalize_spins(spins) -> np.ndarray:
+    """1-D keys -> C-contiguous (n, 8) zero-padded uint64 (common.py:58-68)."""
+    from ._build_matrix import as_bits512
+
+    return as_bits512(spins)
+
+
+def _batched_apply(hamiltonian, spins, chunk_size: int = APPLY_CHUNK):
+    """Chunked ``hamiltonian.batched_apply`` returning flat
+    ``(other_spins u64[N], other_coeffs f64[N], other_counts i64[K])`` (common.py:85-106)."""
+    if hamiltonian.basis.number_spins > 64:
+        raise AssertionError("TODO: only works with up to 64 bits")
+    keys, coeffs, counts = [], [], []
+    total = spins.shape[0]
+    for start in range(0, total, chunk_size):
+        block = _normalize_spins(spins[start:start + chunk_size])
+        other, c, n = hamiltonian.batched_apply(block)
+        c = np.asarray(c)
+        if not np.allclose(c.imag, 0, atol=1e-6):
+            raise ValueError("expected all Hamiltonian matrix elements to be real")
+        keys.append(np.ascontiguousarray(np.asarray(other)[:, 0], dtype=np.uint64))
+        coeffs.append(np.ascontiguousarray(c.real, dtype=np.float64))
+        counts.append(np.asarray(n, dtype=np.int64))
+    if not keys:
+        return (np.zeros(0, np.uint64), np.zeros(0, np.float64), np.zeros(0, np.int64))
+    return np.hstack(keys), np.hstack(coeffs), np.hstack(counts)
+
+
+def ising_elements(keys, psi, other_keys, other_coeffs, other_counts):
+    """GPU pass over the connections: ``(other_indices i64[N], member bool[N],
+    elements f64[N], offsets i64[K+1])`` — the fused equivalent of
+    ``_clipped_search_sorted`` (common.py:116-128), the membership test (:173)
+    and ``_make_ising_model_compute_elements`` (:71-82)."""
+    lib = _lib.load()
+    _lib.require_gpu()
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    psi = np.ascontiguousarray(psi, dtype=np.float64)
+    other_keys = np.ascontiguousarray(other_keys, dtype=np.uint64)
+    other_coeffs = np.ascontiguousarray(other_coeffs, dtype=np.float64)
+    other_counts = np.ascontiguousarray(other_counts, dtype=np.int64)
+    k, n = keys.shape[0], other_keys.shape[0]
+    indices = np.zeros(max(n, 1), dtype=np.int64)
+    member = np.zeros(max(n, 1), dtype=np.uint8)
+    elements = np.zeros(max(n, 1), dtype=np.float64)
+    offsets = np.zeros(k + 1, dtype=np.int64)
+    _lib.check(lib.asp_ising_elements(
+        ctypes.c_uint64(k), _lib.ptr(keys), _lib.ptr(psi), ctypes.c_uint64(n), _lib.ptr(other_keys),
+        _lib.ptr(other_coeffs), _lib.ptr(other_counts), _lib.ptr(indices), _lib.ptr(member),
+        _lib.ptr(elements), _lib.ptr(offsets)))
+    return indices[:n], member[:n].astype(bool), elements[:n], offsets
+
+
+def make_ising_model(
+    spins,
+    quantum_hamiltonian,
+    log_psi: Optional[np.ndarray] = None,
+    log_psi_fn: Optional[Callable[[np.ndarray], np.ndarray]] = None,
+    external_field: bool = False,
+    debug: bool = False,
+) -> IsingModel:
+    """Auxiliary Ising model of a set of basis states (common.py:131-208).
+
+    ``J = (M + M^T) / 2`` with ``M_ij = H_ij |psi_i| |psi_j|`` over the states of
+    the cluster (psi L2-normalised over the cluster), zero field, and the signs of
+    psi as the initial configuration.  One deliberate difference: for NON-unique
+    input the reference indexes the already-deduplicated array with first-occurrence
+    positions of the original (common.py:149), which is an indexing slip; here the
+    sorted unique states are kept and ``log_psi`` is taken at first occurrences.
+    """
+    if log_psi is None and log_psi_fn is None:
+        raise ValueError("at least one of log_psi or log_psi_fn should be specified")
+    if external_field and log_psi_fn is None:
+        raise ValueError("log_psi_fn should be specified when external_field=True")
+    if external_field:
+        # the reference's branch is `assert False` (common.py:199-202)
+        raise NotImplementedError("external_field=True is not implemented by the reference")
+
+    spins = np.asarray(spins, dtype=np.uint64)
+    spins, first, multiplicity = np.unique(spins, return_index=True, return_counts=True, axis=0)
+    if np.any(multiplicity != 1):
+        warnings.warn("'spins' were not unique, are you sure this is what you want?")
+        if log_psi is not None:
+            log_psi = np.asarray(log_psi)[first]
+    if log_psi is None:
+        log_psi = log_psi_fn(spins)
+    if spins.ndim > 1:
+        spins = np.ascontiguousarray(spins[:, 0])
+    n = spins.shape[0]
+
+    other_spins, other_coeffs, other_counts = _batched_apply(quantum_hamiltonian, spins)
+
+    psi = np.exp(log_psi, dtype=np.complex128)
+    if not np.allclose(psi.imag, 0, atol=1e-6):
+        raise ValueError("expected all wavefunction coefficients to be real")
+    psi = np.ascontiguousarray(psi.real)
+    psi /= np.linalg.norm(psi)
+
+    other_indices, _member, elements, offsets = ising_elements(
+        spins, psi, other_spins, other_coeffs, other_counts)
+
+    matrix = scipy.sparse.csr_matrix((elements, other_indices, offsets), shape=(n, n))
+    matrix = 0.5 * (matrix + matrix.T)
+    matrix.sort_indices()
+    matrix = matrix.tocoo()
+
+    field = np.zeros(n, dtype=np.float64)
+    ising_hamiltonian = sa.Hamiltonian(matrix, field)
+    x0 = sa.signs_to_bits(np.sign(psi))
+    return IsingModel(spins, quantum_hamiltonian, ising_hamiltonian, x0)
+
+
+def compute_accuracy_and_overlap(
+    predicted: np.ndarray,
+    exact: np.ndarray,
+    weights: Optional[np.ndarray] = None,
+    number_spins: Optional[int] = None,
+) -> Tuple[float, float]:
+    """Sign accuracy and weighted overlap, both invariant under a global flip
+    (common.py:211-229)."""
+    if weights is None and number_spins is None:
+        raise ValueError("'weights' and 'number_spins' cannot be both None")
+    if number_spins is None:
+        number_spins = len(weights)
+    if weights is None:
+        weights = np.ones(number_spins, dtype=np.float64)
+    guess = sa.bits_to_signs(predicted, number_spins)
+    truth = sa.bits_to_signs(exact, number_spins)
+    accuracy = np.mean(truth == guess)
+    accuracy = max(accuracy, 1 - accuracy)
+    overlap = abs(np.dot(truth * guess, weights / np.sum(weights)))
+    return accuracy, overlap
+
+
+def binary_search(haystack, needles) -> np.ndarray:
+    """Positions of ``needles`` in sorted ``haystack``; all must be present
+    (common.py:544-548)."""
+    haystack = np.asarray(haystack)
+    needles = np.asarray(needles)
+    assert np.all(np.sort(haystack) == haystack)
+    indices = np.searchsorted(haystack, needles)
+    assert np.all(haystack[np.minimum(indices, haystack.shape[0] - 1)] == needles)
+    return indices
+
+
+def solve_ising_model(
+    model: IsingModel,
+    mode: str = "sa",
+    frozen_spins: Optional[np.ndarray] = None,
+    seed: int = 12345,
+    number_sweeps: int = 5120,
+    repetitions: int = 64,
+    only_best: bool = True,
+) -> np.ndarray:
+    """Optimise the signs of ``model`` and project them onto ``frozen_spins``
+    (common.py:232-261)."""
+    if mode == "sa":
+        x, _ = sa.anneal(model.ising_hamiltonian, seed=seed, number_sweeps=number_sweeps,
+                         repetitions=repetitions, only_best=only_best)
+    elif mode == "greedy":
+        x, _ = sa.greedy_solve(model.ising_hamiltonian)
+    else:
+        raise ValueError(
+            "invalid mode specified: '{}'; expected either 'sa' or 'greedy'".format(mode))
+    if frozen_spins is not None:
+        where = binary_search(model.spins, frozen_spins)
+        signs = sa.bits_to_signs(x, count=model.spins.size)
+        x = sa.signs_to_bits(signs[where])
+    return x
+
+
+def make_hamiltonian_extension(model: IsingModel, log_psi_fn) -> IsingModel:
+    """One-hop extension of a cluster: every state connected to it (common.py:516-522)."""
+    spins, _, _ = _batched_apply(model.quantum_hamiltonian, model.spins)
+    spins = np.unique(spins, axis=0)
+    return make_ising_model(spins, model.quantum_hamiltonian, log_psi_fn=log_psi_fn)
+
+
+def get_strongest_off_diag(matrix) -> np.ndarray:
+    """Per row, the largest |J_ij| with j != i (common.py:525-541)."""
+    m = scipy.sparse.csr_matrix(matrix)
+    rows = np.repeat(np.arange(m.shape[0]), np.diff(m.indptr))
+    magnitude = np.where(rows != m.indices, np.abs(m.data), 0.0)
+    out = np.zeros(m.shape[0], dtype=m.data.dtype)
+    np.maximum.at(out, rows, magnitude)
+    return out
+
+
+def sparsify_using_global_cutoff(model: IsingModel, reltol: float, frozen_spins) -> IsingModel:
+    """Drop couplings below ``reltol * max|J|`` (unless both ends are frozen) and keep
+    the connected component that holds the frozen spins (common.py:634-692)."""
+    frozen = binary_search(model.spins, frozen_spins)
+    is_frozen = np.zeros(model.spins.shape[0], dtype=bool)
+    is_frozen[frozen] = True
+
+    full = model.ising_hamiltonian.exchange.tocsr()
+    rows = np.repeat(np.arange(full.shape[0]), np.diff(full.indptr))
+    data = full.data.copy()
+    if data.size:
+        threshold = reltol * np.max(np.abs(data))
+        weak = (np.abs(data) < threshold) & ~(is_frozen[rows] & is_frozen[full.indices])
+        data[weak] = 0
+    pruned = scipy.sparse.csr_matrix((data, full.indices, full.indptr), shape=full.shape)
+    pruned = 0.5 * (pruned + pruned.transpose())
+    pruned.eliminate_zeros()
+
+    _, component = connected_components(pruned, directed=False)
+    wanted = component[frozen[0]]
+    assert np.all(component[frozen] == wanted)
+    keep = component == wanted
+
+    spins = model.spins[keep]
+    signs = sa.bits_to_signs(model.initial_signs, model.size)[keep]
+    # NB: like the reference (common.py:674) the kept block comes from the
+    # UN-pruned matrix: the cutoff only decides which spins survive.
+    exchange = model.ising_hamiltonian.exchange[keep][:, keep]
+    field = model.ising_hamiltonian.field[keep]
+    return IsingModel(spins, model.quantum_hamiltonian, sa.Hamiltonian(exchange, field),
+                      sa.signs_to_bits(signs))
+
+
+@dataclass
+class SamplingResult:
+    """common.py:264-267."""
+
+    spins: np.ndarray
+    weights: Optional[np.ndarray]
+
+
+def monte_carlo_sampling(states, ground_state, number_samples: int,
+                         sampled_power: float = 2) -> SamplingResult:
+    """Seed states drawn with probability ~ |psi|^p from numpy's global legacy stream
+    (common.py:270-279)."""
+    p = np.abs(ground_state) ** sampled_power
+    p /= np.sum(p)
+    picks = np.random.choice(len(states), size=number_samples, replace=True, p=p)
+    return SamplingResult(spins=np.asarray(states)[picks], weights=None)
+
+
+def add_noise_to_amplitudes(ground_state, eps: float) -> np.ndarray:
+    """psi -> sign(psi) |psi| exp(eps U(-1, 1)), renormalised (common.py:825-835)."""
+    ground_state = np.asarray(ground_state, dtype=np.float64, order="C")
+    assert ground_state.ndim == 1
+    log_amplitude = np.log(np.abs(ground_state))
+    noise = eps * 2 * (np.random.rand(log_amplitude.size) - 0.5)
+    noisy = np.sign(ground_state) * np.exp(log_amplitude + noise)
+    return noisy / np.linalg.norm(noisy)
+
+
+def ground_state_to_log_coeff_fn(ground_state, basis):
+    """Closure ``spins -> log|psi| + i pi [psi < 0]`` (common.py:806-822)."""
+    ground_state = np.asarray(ground_state, dtype=np.float64, order="C")
+    assert ground_state.ndim == 1
+    with np.errstate(divide="ignore"):
+        log_amplitude = np.log(np.abs(ground_state))
+    phase = np.where(ground_state >= 0, 0, np.pi)
+
+    def log_coeff_fn(spins: np.ndarray) -> np.ndarray:
+        spins = np.asarray(spins, dtype=np.uint64, order="C")
+        if spins.ndim > 1:
+            spins = spins[:, 0]
+        where = np.asarray(basis.batched_index(spins), dtype=np.int64)
+        return log_amplitude[where] + 1j * phase[where]
+
+    return log_coeff_fn

@@ -1,0 +1,95 @@
+// Shared host-side plumbing for libasp_hip.so: error recording, HIP call
+// checking, device buffers, device-wide exclusive scan.  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <new>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "asp.h"
+
+namespace asp {
+
+// ---- error state (thread-local, read through asp_last_error) -------------
+struct ErrorState {
+  int code = ASP_OK;
+  char message[512] = {0};
+};
+ErrorState &error_state();
+int set_error(int code, const char *fmt, ...);
+
+#define ASP_HIP_TRY(expr)                                                              \
+  do {                                                                                 \
+    hipError_t asp_hip_err_ = (expr);                                                  \
+    if (asp_hip_err_ != hipSuccess) {                                                  \
+      return ::asp::set_error(asp_hip_err_ == hipErrorNoDevice ? ASP_ERR_NO_DEVICE     \
+                                                               : ASP_ERR_HIP,          \
+                              "%s failed: %s (%s:%d)", #expr,                          \
+                              hipGetErrorString(asp_hip_err_), __FILE__, __LINE__);    \
+    }                                                                                  \
+  } while (0)
+
+#define ASP_TRY(expr)                    \
+  do {                                   \
+    int asp_rc_ = (expr);                \
+    if (asp_rc_ != ASP_OK) return asp_rc_; \
+  } while (0)
+
+// Fails (recording ASP_ERR_NO_DEVICE) unless a gfx950-class device is usable.
+int require_device();
+
+// ---- owning device buffer --------------------------------------------------
+template <typename T>
+struct DeviceBuffer {
+  T *ptr = nullptr;
+  size_t count = 0;
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer &) = delete;
+  DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+  ~DeviceBuffer() { release(); }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    count = 0;
+  }
+  // (Re)allocate for n elements (at least one, so pointers are never null).
+  int alloc(size_t n) {
+    release();
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&ptr), bytes);
+    if (e != hipSuccess) {
+      ptr = nullptr;
+      return set_error(ASP_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", bytes,
+                       hipGetErrorString(e));
+    }
+    count = n;
+    return ASP_OK;
+  }
+  int upload(const T *host, size_t n, hipStream_t stream) {
+    if (n == 0) return ASP_OK;
+    ASP_HIP_TRY(hipMemcpyAsync(ptr, host, n * sizeof(T), hipMemcpyHostToDevice, stream));
+    return ASP_OK;
+  }
+  int download(T *host, size_t n, hipStream_t stream) const {
+    if (n == 0) return ASP_OK;
+    ASP_HIP_TRY(hipMemcpyAsync(host, ptr, n * sizeof(T), hipMemcpyDeviceToHost, stream));
+    return ASP_OK;
+  }
+};
+
+// ---- device-wide exclusive scan -------------------------------------------
+// out[i] = sum_{j<i} in[j] for i in [0, n]; out has n + 1 elements (out[n] is
+// the total).  `scratch` must hold scan_scratch_elems(n) int64.  Integer adds
+// only, so the result is independent of the launch geometry.
+size_t scan_scratch_elems(size_t n);
+int exclusive_scan_i64(const int64_t *in, size_t n, int64_t *out, int64_t *scratch,
+                       hipStream_t stream);
+int exclusive_scan_u32(const uint32_t *in, size_t n, int64_t *out, int64_t *scratch,
+                       hipStream_t stream);
+
+}  // namespace asp

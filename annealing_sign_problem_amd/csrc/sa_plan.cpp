@@ -1,0 +1,263 @@
+// Host preprocessing for the annealing sweep (see sa_plan.hpp).
+// Replaces what ising_glass_annealer.Hamiltonian does on construction
+// (call sites annealing_sign_problem/common.py:204,681).
+#include "sa_plan.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <numeric>
+
+#include "asp_common.hpp"
+
+namespace asp {
+
+namespace {
+
+struct Entry {
+  int32_t col;
+  double val;
+};
+
+}  // namespace
+
+int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *indices,
+                    const double *data, const double *field, SaHostLayout *out) {
+  const uint64_t n = num_spins;
+  if (n >= (1ull << 31)) {
+    return set_error(ASP_ERR_TOO_LARGE, "%llu spins exceed the 2^31 limit", (unsigned long long)n);
+  }
+  if (n > 0 && (!indptr || !field)) return set_error(ASP_ERR_INVALID, "null indptr/field");
+  SaHostLayout &L = *out;
+  L = SaHostLayout();
+  L.num_spins = n;
+  if (n == 0) {
+    L.a_ptr.assign(1, 0);
+    L.color_block_start.assign(1, 0);
+    L.ell_off.assign(1, 0);
+    L.beta0_auto = L.beta1_auto = 1.0;
+    return ASP_OK;
+  }
+  if (indptr[0] != 0) return set_error(ASP_ERR_INVALID, "indptr[0] must be 0");
+  const int64_t nnz = indptr[n];
+  if (nnz > 0 && (!indices || !data)) return set_error(ASP_ERR_INVALID, "null indices/data");
+  for (uint64_t i = 0; i < n; ++i) {
+    if (indptr[i + 1] < indptr[i]) return set_error(ASP_ERR_INVALID, "indptr is not monotone");
+    for (int64_t k = indptr[i]; k < indptr[i + 1]; ++k) {
+      if (indices[k] < 0 || static_cast<uint64_t>(indices[k]) >= n) {
+        return set_error(ASP_ERR_INVALID, "column index %d out of range in row %llu", indices[k],
+                         (unsigned long long)i);
+      }
+      if (k > indptr[i] && indices[k - 1] >= indices[k]) {
+        return set_error(ASP_ERR_INVALID,
+                         "row %llu is not in canonical CSR form (sorted, duplicate-free columns)",
+                         (unsigned long long)i);
+      }
+      if (!std::isfinite(data[k])) {
+        return set_error(ASP_ERR_INVALID, "non-finite coupling in row %llu", (unsigned long long)i);
+      }
+    }
+    if (!std::isfinite(field[i])) {
+      return set_error(ASP_ERR_INVALID, "non-finite field at %llu", (unsigned long long)i);
+    }
+  }
+
+  // ---- J^T by rows (bucket the entries by column; rows are visited in order so
+  //      every bucket ends up sorted by original row) --------------------------
+  std::vector<std::vector<Entry>> transposed(n);
+  {
+    std::vector<uint32_t> per_col(n, 0);
+    for (int64_t k = 0; k < nnz; ++k) per_col[indices[k]]++;
+    for (uint64_t j = 0; j < n; ++j) transposed[j].reserve(per_col[j]);
+    for (uint64_t i = 0; i < n; ++i) {
+      for (int64_t k = indptr[i]; k < indptr[i + 1]; ++k) {
+        transposed[indices[k]].push_back(Entry{static_cast<int32_t>(i), data[k]});
+      }
+    }
+  }
+
+  // ---- A = offdiag(J + J^T), D = sum_i J_ii ----------------------------------
+  L.a_ptr.assign(n + 1, 0);
+  L.a_col.reserve(static_cast<size_t>(2 * nnz));
+  L.a_val.reserve(static_cast<size_t>(2 * nnz));
+  double diag = 0.0;
+  for (uint64_t i = 0; i < n; ++i) {
+    const Entry *t = transposed[i].data();
+    const Entry *t_end = t + transposed[i].size();
+    int64_t k = indptr[i];
+    const int64_t k_end = indptr[i + 1];
+    while (k < k_end || t < t_end) {
+      const bool take_j = k < k_end && (t == t_end || indices[k] <= t->col);
+      const bool take_t = t < t_end && (k == k_end || t->col <= indices[k]);
+      const int32_t col = take_j ? indices[k] : t->col;
+      const double x = take_j ? data[k] : 0.0;  // J_ij or +0
+      const double y = take_t ? t->val : 0.0;   // J_ji or +0
+      if (take_j) ++k;
+      if (take_t) ++t;
+      if (static_cast<uint64_t>(col) == i) {
+        if (take_j) diag = diag + x;
+        continue;
+      }
+      const double v = x + y;
+      if (v != 0.0) {
+        L.a_col.push_back(col);
+        L.a_val.push_back(v);
+      }
+    }
+    L.a_ptr[i + 1] = static_cast<int64_t>(L.a_col.size());
+  }
+  L.diag_sum = diag;
+  transposed.clear();
+  transposed.shrink_to_fit();
+
+  // ---- greedy first-fit colouring, natural order ------------------------------
+  L.color.assign(n, -1);
+  {
+    std::vector<int64_t> last_user;  // last_user[c] = latest spin that saw colour c on a neighbour
+    uint32_t ncol = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+      for (int64_t k = L.a_ptr[i]; k < L.a_ptr[i + 1]; ++k) {
+        const int32_t c = L.color[L.a_col[k]];
+        if (c >= 0) last_user[c] = static_cast<int64_t>(i);
+      }
+      uint32_t c = 0;
+      while (c < ncol && last_user[c] == static_cast<int64_t>(i)) ++c;
+      if (c == ncol) {
+        last_user.push_back(-1);
+        ++ncol;
+      }
+      L.color[i] = static_cast<int32_t>(c);
+    }
+    L.num_colors = ncol;
+  }
+
+  // ---- permutation: (colour asc, degree desc, index asc) ----------------------
+  std::vector<uint32_t> order(n);
+  std::iota(order.begin(), order.end(), 0u);
+  auto degree = [&](uint32_t i) { return L.a_ptr[i + 1] - L.a_ptr[i]; };
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    if (L.color[a] != L.color[b]) return L.color[a] < L.color[b];
+    return degree(a) > degree(b);
+  });
+  for (uint64_t i = 0; i < n; ++i) {
+    L.max_degree = std::max<uint32_t>(L.max_degree, static_cast<uint32_t>(degree(i)));
+  }
+
+  // ---- blocks ------------------------------------------------------------------
+  L.color_block_start.assign(L.num_colors + 1, 0);
+  L.pos_of_spin.assign(n, 0);
+  {
+    size_t q = 0;
+    uint32_t block = 0;
+    for (uint32_t c = 0; c < L.num_colors; ++c) {
+      L.color_block_start[c] = block;
+      size_t q_end = q;
+      while (q_end < n && static_cast<uint32_t>(L.color[order[q_end]]) == c) ++q_end;
+      for (size_t q0 = q; q0 < q_end; q0 += 64) {
+        uint32_t width = 0;
+        for (size_t l = 0; l < 64; ++l) {
+          const size_t qq = q0 + l;
+          if (qq < q_end) {
+            const uint32_t spin = order[qq];
+            L.spin_of_pos.push_back(spin);
+            L.pos_of_spin[spin] = block * 64u + static_cast<uint32_t>(l);
+            L.field_pos.push_back(field[spin]);
+            width = std::max<uint32_t>(width, static_cast<uint32_t>(degree(spin)));
+          } else {
+            L.spin_of_pos.push_back(kDummySpin);
+            L.field_pos.push_back(0.0);
+          }
+        }
+        width = (width + kWidthAlign - 1) / kWidthAlign * kWidthAlign;
+        L.block_width.push_back(width);
+        ++block;
+      }
+      q = q_end;
+    }
+    L.color_block_start[L.num_colors] = block;
+    L.num_blocks = block;
+  }
+
+  // ---- sliced ELL ----------------------------------------------------------------
+  L.ell_off.assign(L.num_blocks + 1, 0);
+  for (uint32_t b = 0; b < L.num_blocks; ++b) L.ell_off[b + 1] = L.ell_off[b] + L.block_width[b];
+  const uint64_t slabs = L.ell_off[L.num_blocks];
+  L.ell_col.assign(slabs * 64, 0);
+  L.ell_val.assign(slabs * 64, 0.0);
+  for (uint32_t b = 0; b < L.num_blocks; ++b) {
+    for (uint32_t l = 0; l < 64; ++l) {
+      const uint32_t pos = b * 64u + l;
+      const uint32_t spin = L.spin_of_pos[pos];
+      const int64_t begin = spin == kDummySpin ? 0 : L.a_ptr[spin];
+      const int64_t deg = spin == kDummySpin ? 0 : degree(spin);
+      for (uint32_t k = 0; k < L.block_width[b]; ++k) {
+        const uint64_t at = (L.ell_off[b] + k) * 64 + l;
+        if (static_cast<int64_t>(k) < deg) {
+          L.ell_col[at] = L.pos_of_spin[L.a_col[begin + k]];
+          L.ell_val[at] = L.a_val[begin + k];
+        } else {
+          L.ell_col[at] = pos;  // padding: own position, +0.0
+          L.ell_val[at] = 0.0;
+        }
+      }
+    }
+  }
+
+  // ---- energy scale and automatic beta range ----------------------------------------
+  double bound = 0.0;      // B = 1/2 sum|A| + sum|h|  (E - D ranges within +-B)
+  double max_delta = 0.0;  // max_i 2 (sum_j |A_ij| + |h_i|)
+  double min_delta = std::numeric_limits<double>::infinity();
+  for (uint64_t i = 0; i < n; ++i) {
+    double row = 0.0;
+    for (int64_t k = L.a_ptr[i]; k < L.a_ptr[i + 1]; ++k) {
+      const double a = std::fabs(L.a_val[k]);
+      row += a;
+      if (a > 0.0) min_delta = std::min(min_delta, 2.0 * a);
+    }
+    const double h = std::fabs(field[i]);
+    if (h > 0.0) min_delta = std::min(min_delta, 2.0 * h);
+    bound += 0.5 * row + h;
+    max_delta = std::max(max_delta, 2.0 * (row + h));
+  }
+  if (!std::isfinite(bound)) return set_error(ASP_ERR_INVALID, "couplings overflow double range");
+  if (bound > 0.0) {
+    int e = 0;
+    (void)std::frexp(2.0 * bound, &e);  // 2B < 2^e
+    L.energy_scale_exp = std::clamp(60 - e, -1000, 1000);
+  }
+  if (max_delta > 0.0 && std::isfinite(min_delta)) {
+    L.beta0_auto = std::log(2.0) / max_delta;
+    L.beta1_auto = std::log(100.0) / min_delta;
+  } else {
+    L.beta0_auto = L.beta1_auto = 1.0;
+  }
+  return ASP_OK;
+}
+
+}  // namespace asp
+
+static void fill_info(const asp::SaHostLayout &L, asp_sa_info *info) {
+  info->num_spins = L.num_spins;
+  info->nnz_offdiag = L.a_col.size();
+  info->ell_entries = L.ell_col.size();
+  info->num_colors = L.num_colors;
+  info->num_blocks = L.num_blocks;
+  info->max_degree = L.max_degree;
+  info->energy_scale_exp = L.energy_scale_exp;
+  info->diag_sum = L.diag_sum;
+  info->beta0_auto = L.beta0_auto;
+  info->beta1_auto = L.beta1_auto;
+}
+
+extern "C" int asp_sa_layout_host(uint64_t num_spins, int64_t const *indptr,
+                                  int32_t const *indices, double const *data,
+                                  double const *field, asp_sa_info *info, int32_t *colors,
+                                  uint32_t *position) {
+  asp_clear_error();
+  asp::SaHostLayout L;
+  ASP_TRY(asp::build_sa_layout(num_spins, indptr, indices, data, field, &L));
+  if (info) fill_info(L, info);
+  if (colors) std::copy(L.color.begin(), L.color.end(), colors);
+  if (position) std::copy(L.pos_of_spin.begin(), L.pos_of_spin.end(), position);
+  return ASP_OK;
+}

@@ -1,0 +1,52 @@
+// Sweep plan: the host-side preprocessing of an Ising Hamiltonian into the
+// layout the gfx950 sweep kernel streams.
+//
+//   A = offdiag(J + J^T) (exact zeros dropped)          -> dE_i = -2 s_i (sum_j A_ij s_j + h_i)
+//   greedy first-fit colouring of A's graph, index order -> same-colour spins are independent
+//   permutation by (colour, degree desc, index)          -> a colour class is a run of 64-row blocks
+//   sliced ELL: block b has width w_b (multiple of 4); entry (k, lane) of block b lives at
+//   (ell_off[b] + k) * 64 + lane, so a wavefront reads 256 B of columns and 512 B of values
+//   per k, fully coalesced.  Columns are padded POSITIONS (block * 64 + lane), i.e. direct
+//   indices into the LDS spin array.  Padding entries point at the lane's own position with
+//   value +0.0 (adding +-0 never changes a sum).
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "asp.h"
+
+namespace asp {
+
+constexpr uint32_t kDummySpin = 0xFFFFFFFFu;  // spin_of_pos of a padding lane
+constexpr int kWidthAlign = 4;                // block widths are rounded up to this
+
+struct SaHostLayout {
+  uint64_t num_spins = 0;
+  // A in CSR over ORIGINAL indices (sorted columns)
+  std::vector<int64_t> a_ptr;
+  std::vector<int32_t> a_col;
+  std::vector<double> a_val;
+  double diag_sum = 0.0;
+  std::vector<int32_t> color;
+  uint32_t num_colors = 0;
+  uint32_t max_degree = 0;
+  // permuted / padded structure
+  uint32_t num_blocks = 0;
+  std::vector<uint32_t> color_block_start;  // num_colors + 1
+  std::vector<uint32_t> block_width;        // num_blocks
+  std::vector<uint64_t> ell_off;            // num_blocks + 1, in 64-entry slabs
+  std::vector<uint32_t> spin_of_pos;        // num_blocks * 64, kDummySpin for padding lanes
+  std::vector<uint32_t> pos_of_spin;        // num_spins
+  std::vector<double> field_pos;            // num_blocks * 64
+  std::vector<uint32_t> ell_col;            // ell_off.back() * 64
+  std::vector<double> ell_val;
+  int32_t energy_scale_exp = 0;
+  double beta0_auto = 0.0, beta1_auto = 0.0;
+};
+
+// Returns ASP_OK or records an error (non-canonical CSR, index out of range ...).
+int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *indices,
+                    const double *data, const double *field, SaHostLayout *out);
+
+}  // namespace asp

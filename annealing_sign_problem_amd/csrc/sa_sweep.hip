@@ -1,0 +1,768 @@
+// Metropolis single-spin-flip annealing sweep on gfx950 (specification ASP-SA-1,
+// DESIGN.md §4): replaces ising_glass_annealer.anneal at the reference's call
+// sites annealing_sign_problem/common.py:242-248 and
+// experiments/full_hilbert_space.py:212-218.
+//
+// Mapping to the machine
+//   * one workgroup = one GROUP of M replicas (M in {1,2,4,8}); the whole anneal
+//     (all sweeps) is ONE launch, the spins never leave LDS;
+//   * LDS: one byte per (padded) spin position, bit m = sign bit of replica m
+//     (1 means s = -1), so one ds_read_u8 serves all M replicas of a neighbour;
+//   * a wavefront owns a 64-row block of one colour class: lane = spin.  Same
+//     colour means no couplings inside the block, so the 64 x M proposals of a
+//     block are independent and are decided at once;
+//   * couplings stream from the sliced-ELL slabs: per k one coalesced 256-B
+//     column read and one 512-B value read per wavefront, shared by M replicas;
+//   * dE is an f64 sum in fixed row order (bit-exact against the oracle), the
+//     acceptance uses a counter-based Philox4x32-10 word per (spin, sweep,
+//     replica) and a fixed-sequence exp, accepted flips are XOR-ed into LDS;
+//   * the running energy of each replica is tracked exactly in 2^-S fixed point
+//     (integer adds commute, so the parallel reduction is deterministic); the
+//     best configuration is snapshotted to HBM at sweep granularity.
+// Memory/latency-bound integer+f64 work: no MFMA.
+#include <algorithm>
+#include <cmath>
+#include <initializer_list>
+#include <vector>
+
+#include "asp_common.hpp"
+#include "sa_plan.hpp"
+
+namespace {
+
+using asp::DeviceBuffer;
+using asp::kDummySpin;
+
+// ---------------------------------------------------------------------------
+// Device arithmetic shared by the kernels
+// ---------------------------------------------------------------------------
+
+struct Philox4 {
+  uint32_t w[4];
+};
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
+                                                 uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c0;
+    const uint64_t p1 = static_cast<uint64_t>(0xCD9E8D57u) * c2;
+    const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = static_cast<uint32_t>(p1);
+    const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = static_cast<uint32_t>(p0);
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return Philox4{{c0, c1, c2, c3}};
+}
+
+__device__ __forceinline__ uint32_t pick_word(const Philox4 &p, uint32_t which) {
+  const uint32_t lo = (which & 1u) ? p.w[1] : p.w[0];
+  const uint32_t hi = (which & 1u) ? p.w[3] : p.w[2];
+  return (which & 2u) ? hi : lo;
+}
+
+// exp(-x), x >= 0: a fixed sequence of IEEE operations (v_rndne_f64, v_fma_f64,
+// v_mul_f64) so that the result is bit-identical to the CPU restatement.
+__device__ __forceinline__ double expneg(double x) {
+  if (!(x < 23.0)) return 0.0;
+  const double y = -x;
+  const double kf = __builtin_rint(__dmul_rn(y, 0x1.71547652b82fep+0));
+  double r = __builtin_fma(kf, -0x1.62e42fee00000p-1, y);
+  r = __builtin_fma(kf, -0x1.a39ef35793c76p-33, r);
+  double p = 0x1.6124613a86d09p-33;
+  p = __builtin_fma(p, r, 0x1.1eed8eff8d898p-29);
+  p = __builtin_fma(p, r, 0x1.ae64567f544e4p-26);
+  p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);
+  p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);
+  p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);
+  p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);
+  p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);
+  p = __builtin_fma(p, r, 0x1.1111111111111p-7);
+  p = __builtin_fma(p, r, 0x1.5555555555555p-5);
+  p = __builtin_fma(p, r, 0x1.5555555555555p-3);
+  p = __builtin_fma(p, r, 0x1.0000000000000p-1);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  const long long k = static_cast<long long>(kf);
+  const double scale = __longlong_as_double((1023ll + k) << 52);
+  return __dmul_rn(p, scale);
+}
+
+// v with its sign flipped when bit `m` of the neighbour's spin byte is set.
+__device__ __forceinline__ double signed_coupling(double v, uint32_t spin_byte, int m) {
+  const unsigned long long flip = static_cast<unsigned long long>((spin_byte >> m) & 1u) << 63;
+  return __longlong_as_double(__double_as_longlong(v) ^ static_cast<long long>(flip));
+}
+
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+  for (int step = 1; step < 64; step <<= 1) v += __shfl_xor(v, step, 64);
+  return v;
+}
+
+// Butterfly sum over the 64 lanes; every lane ends with the balanced-tree total
+// ((v0+v1)+(v2+v3))+... (f64 addition commutes, so all lanes agree bitwise).
+__device__ __forceinline__ double wave_tree_sum_f64(double v) {
+#pragma unroll
+  for (int step = 1; step < 64; step <<= 1) v = __dadd_rn(v, __shfl_xor(v, step, 64));
+  return v;
+}
+
+// Collect bit m of each of the four bytes of d into a nibble (byte 0 -> bit 0).
+__device__ __forceinline__ uint32_t gather_bit4(uint32_t d, int m) {
+  const uint32_t t = (d >> m) & 0x01010101u;
+  return ((t * 0x00204081u) >> 21) & 0xFu;
+}
+
+// ---------------------------------------------------------------------------
+// Sweep kernel
+// ---------------------------------------------------------------------------
+
+struct SweepArgs {
+  const uint32_t *color_block_start;  // num_colors + 1
+  const uint32_t *block_width;        // num_blocks
+  const uint64_t *ell_off;            // num_blocks + 1 (slabs)
+  const uint32_t *ell_col;
+  const double *ell_val;
+  const uint32_t *spin_of_pos;  // num_blocks * 64
+  const double *field_pos;      // num_blocks * 64
+  const double *betas;          // num_sweeps
+  const uint64_t *x0_perm;      // num_blocks sign-bit words or nullptr
+  uint64_t *best_perm;          // [groups * M][num_blocks] sign-bit words
+  long long *tracked;           // [groups * M] best tracked energy (fixed point)
+  unsigned long long *accepted;  // [groups * M] accepted flips
+  uint64_t seed;
+  double scale;  // 2^S
+  uint32_t num_colors, num_blocks, num_sweeps, replica_first;
+};
+
+template <int M>
+__device__ __forceinline__ void snapshot(const uint8_t *spins, const SweepArgs &a, uint32_t group,
+                                         uint32_t mask) {
+  for (uint32_t w = threadIdx.x; w < a.num_blocks; w += blockDim.x) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(spins + 64u * w);
+    uint4 q[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = src[j];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      if (!((mask >> m) & 1u)) continue;
+      uint64_t word = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t nib = gather_bit4(q[j].x, m) | (gather_bit4(q[j].y, m) << 4) |
+                             (gather_bit4(q[j].z, m) << 8) | (gather_bit4(q[j].w, m) << 12);
+        word |= static_cast<uint64_t>(nib) << (16 * j);
+      }
+      a.best_perm[(static_cast<uint64_t>(group) * M + m) * a.num_blocks + w] = word;
+    }
+  }
+}
+
+template <int M>
+__global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  uint8_t *spins = lds;
+  const uint32_t P = a.num_blocks * 64u;
+  long long *delta = reinterpret_cast<long long *>(lds + P);  // P is a multiple of 64
+
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = tid >> 6;
+  const uint32_t waves = blockDim.x >> 6;
+  const uint32_t group = blockIdx.x;
+  const uint32_t r0 = a.replica_first + group * M;
+  const uint32_t key0 = static_cast<uint32_t>(a.seed);
+  const uint32_t key1 = static_cast<uint32_t>(a.seed >> 32);
+
+  // ---- initial configuration ----
+  for (uint32_t p = tid; p < P; p += blockDim.x) {
+    const uint32_t spin = a.spin_of_pos[p];
+    uint32_t byte = 0;
+    if (spin != kDummySpin) {
+      if (a.x0_perm != nullptr) {
+        byte = ((a.x0_perm[p >> 6] >> (p & 63u)) & 1ull) ? ((1u << M) - 1u) : 0u;
+      } else {
+        Philox4 rnd{};
+        uint32_t have = 0xFFFFFFFFu;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          const uint32_t r = r0 + m;
+          if (m == 0 || (r >> 2) != have) {
+            have = r >> 2;
+            rnd = philox4x32_10(spin, 0xFFFFFFFFu, have, 0u, key0, key1);
+          }
+          const uint32_t up = pick_word(rnd, r & 3u) & 1u;  // 1 -> s = +1 -> sign bit 0
+          byte |= (up ^ 1u) << m;
+        }
+      }
+    }
+    spins[p] = static_cast<uint8_t>(byte);
+  }
+  if (tid < 8) delta[tid] = 0;
+  __syncthreads();
+  snapshot<M>(spins, a, group, (1u << M) - 1u);
+  __syncthreads();
+
+  long long e_cur[M], e_best[M];
+  unsigned long long n_acc[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    e_cur[m] = 0;
+    e_best[m] = 0;
+    n_acc[m] = 0;
+  }
+
+  for (uint32_t t = 0; t < a.num_sweeps; ++t) {
+    const double beta = a.betas[t];
+    long long q_acc[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) q_acc[m] = 0;
+
+    for (uint32_t c = 0; c < a.num_colors; ++c) {
+      const uint32_t b_end = a.color_block_start[c + 1];
+      for (uint32_t b = a.color_block_start[c] + wave; b < b_end; b += waves) {
+        const uint32_t p = b * 64u + lane;
+        const uint32_t width = a.block_width[b];
+        const uint64_t base = a.ell_off[b] * 64u + lane;
+        const uint32_t *cptr = a.ell_col + base;
+        const double *vptr = a.ell_val + base;
+        double acc[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[m] = 0.0;
+        for (uint32_t k = 0; k < width; k += 4) {
+          const uint32_t c0 = cptr[(k + 0) * 64u], c1 = cptr[(k + 1) * 64u];
+          const uint32_t c2 = cptr[(k + 2) * 64u], c3 = cptr[(k + 3) * 64u];
+          const double v0 = vptr[(k + 0) * 64u], v1 = vptr[(k + 1) * 64u];
+          const double v2 = vptr[(k + 2) * 64u], v3 = vptr[(k + 3) * 64u];
+          const uint32_t s0 = spins[c0], s1 = spins[c1], s2 = spins[c2], s3 = spins[c3];
+#pragma unroll
+          for (int m = 0; m < M; ++m) {
+            double x = acc[m];
+            x = __dadd_rn(x, signed_coupling(v0, s0, m));
+            x = __dadd_rn(x, signed_coupling(v1, s1, m));
+            x = __dadd_rn(x, signed_coupling(v2, s2, m));
+            x = __dadd_rn(x, signed_coupling(v3, s3, m));
+            acc[m] = x;
+          }
+        }
+        const uint32_t spin = a.spin_of_pos[p];
+        const double h = a.field_pos[p];
+        const bool valid = spin != kDummySpin;
+        const uint32_t own = spins[p];
+        uint32_t flip = 0;
+        Philox4 rnd{};
+        uint32_t have = 0xFFFFFFFFu;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          const uint32_t r = r0 + m;
+          if (m == 0 || (r >> 2) != have) {
+            have = r >> 2;
+            rnd = philox4x32_10(spin, t, have, 0u, key0, key1);
+          }
+          const uint32_t word = pick_word(rnd, r & 3u);
+          const double g = __dadd_rn(acc[m], h);
+          const bool negative = (own >> m) & 1u;  // s = -1
+          const double de = __dmul_rn(negative ? 2.0 : -2.0, g);
+          const double u = __dmul_rn(__dadd_rn(static_cast<double>(word), 0.5), 0x1p-32);
+          const bool accept = valid && (de <= 0.0 || u < expneg(__dmul_rn(beta, de)));
+          if (accept) {
+            flip |= 1u << m;
+            q_acc[m] += static_cast<long long>(__builtin_rint(__dmul_rn(de, a.scale)));
+            n_acc[m] += 1;
+          }
+        }
+        if (flip) spins[p] = static_cast<uint8_t>(own ^ flip);
+      }
+      __syncthreads();
+    }
+
+    // ---- exact (integer) reduction of the sweep's energy change ----
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const long long v = wave_sum_i64(q_acc[m]);
+      if (lane == 0 && v != 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&delta[m]),
+                  static_cast<unsigned long long>(v));
+      }
+    }
+    __syncthreads();
+    uint32_t improved = 0;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      e_cur[m] += delta[m];
+      if (e_cur[m] < e_best[m]) {
+        e_best[m] = e_cur[m];
+        improved |= 1u << m;
+      }
+    }
+    if (improved) snapshot<M>(spins, a, group, improved);
+    __syncthreads();
+    if (tid < M) delta[tid] = 0;  // next atomics are at least one barrier away
+  }
+
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const unsigned long long total = static_cast<unsigned long long>(
+        wave_sum_i64(static_cast<long long>(n_acc[m])));
+    if (lane == 0 && total != 0) atomicAdd(&a.accepted[static_cast<uint64_t>(group) * M + m], total);
+  }
+  if (tid < M) a.tracked[static_cast<uint64_t>(group) * M + tid] = e_best[tid];
+}
+
+// ---------------------------------------------------------------------------
+// Energy of packed configurations: E = D + T, T = radix-64
+// pairwise tree over the blocks of t_p = s_p (A_p . s / 2 + h_p).
+// ---------------------------------------------------------------------------
+
+struct EnergyArgs {
+  const uint32_t *block_width;
+  const uint64_t *ell_off;
+  const uint32_t *ell_col;
+  const double *ell_val;
+  const double *field_pos;
+  const uint64_t *perm_words;  // [count][num_blocks] sign bits
+  double *partial;             // [count][num_blocks]
+  uint32_t num_blocks;
+};
+
+__global__ __launch_bounds__(512) void k_sa_energy_blocks(EnergyArgs a) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  uint64_t *bits = reinterpret_cast<uint64_t *>(lds);
+  const uint32_t r = blockIdx.x;
+  const uint64_t *mine = a.perm_words + static_cast<uint64_t>(r) * a.num_blocks;
+  for (uint32_t w = threadIdx.x; w < a.num_blocks; w += blockDim.x) bits[w] = mine[w];
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t waves = blockDim.x >> 6;
+  for (uint32_t b = threadIdx.x >> 6; b < a.num_blocks; b += waves) {
+    const uint32_t width = a.block_width[b];
+    const uint64_t base = a.ell_off[b] * 64u + lane;
+    double acc = 0.0;
+    for (uint32_t k = 0; k < width; ++k) {
+      const uint32_t c = a.ell_col[base + static_cast<uint64_t>(k) * 64u];
+      const double v = a.ell_val[base + static_cast<uint64_t>(k) * 64u];
+      const uint32_t neg = static_cast<uint32_t>((bits[c >> 6] >> (c & 63u)) & 1ull);
+      acc = __dadd_rn(acc, signed_coupling(v, neg, 0));
+    }
+    const double g = __dadd_rn(__dmul_rn(0.5, acc), a.field_pos[b * 64u + lane]);
+    const bool negative = (bits[b] >> lane) & 1ull;
+    const double total = wave_tree_sum_f64(negative ? -g : g);
+    if (lane == 0) a.partial[static_cast<uint64_t>(r) * a.num_blocks + b] = total;
+  }
+}
+
+// One wavefront per configuration folds its block sums 64 at a time, in place.
+__global__ __launch_bounds__(64) void k_sa_energy_fold(double *partial, uint32_t num_blocks,
+                                                      double diag_sum, double *out_e) {
+  const uint32_t r = blockIdx.x;
+  const uint32_t lane = threadIdx.x;
+  double *level = partial + static_cast<uint64_t>(r) * num_blocks;
+  uint32_t n = num_blocks;
+  while (n > 1) {
+    const uint32_t groups = (n + 63u) / 64u;
+    for (uint32_t g = 0; g < groups; ++g) {
+      const uint32_t i = g * 64u + lane;
+      const double v = i < n ? level[i] : 0.0;
+      const double s = wave_tree_sum_f64(v);
+      if (lane == 0) level[g] = s;
+    }
+    n = groups;
+  }
+  if (lane == 0) out_e[r] = __dadd_rn(diag_sum, num_blocks ? level[0] : 0.0);
+}
+
+// Packed original-order configurations (bit = +1) -> permuted sign-bit words.
+__global__ __launch_bounds__(256) void k_permute_bits(const uint64_t *__restrict__ x,
+                                                     uint32_t words,
+                                                     const uint32_t *__restrict__ spin_of_pos,
+                                                     uint32_t num_blocks, uint32_t count,
+                                                     uint64_t *__restrict__ perm_words) {
+  const uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= static_cast<uint64_t>(count) * num_blocks) return;
+  const uint32_t r = static_cast<uint32_t>(idx / num_blocks);
+  const uint32_t b = static_cast<uint32_t>(idx % num_blocks);
+  uint64_t word = 0;
+  for (uint32_t l = 0; l < 64; ++l) {
+    const uint32_t spin = spin_of_pos[b * 64u + l];
+    if (spin == kDummySpin) continue;
+    const uint64_t up = (x[static_cast<uint64_t>(r) * words + (spin >> 6)] >> (spin & 63u)) & 1ull;
+    word |= (up ^ 1ull) << l;
+  }
+  perm_words[idx] = word;
+}
+
+// Permuted sign-bit words -> packed original-order configurations (bit = +1).
+__global__ __launch_bounds__(256) void k_unpermute_bits(const uint64_t *__restrict__ perm_words,
+                                                       uint32_t num_blocks,
+                                                       const uint32_t *__restrict__ pos_of_spin,
+                                                       uint64_t num_spins, uint32_t words,
+                                                       uint32_t count, uint64_t *__restrict__ x) {
+  const uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= static_cast<uint64_t>(count) * words) return;
+  const uint32_t r = static_cast<uint32_t>(idx / words);
+  const uint32_t w = static_cast<uint32_t>(idx % words);
+  uint64_t word = 0;
+  for (uint32_t j = 0; j < 64; ++j) {
+    const uint64_t spin = static_cast<uint64_t>(w) * 64u + j;
+    if (spin >= num_spins) break;
+    const uint32_t pos = pos_of_spin[spin];
+    const uint64_t neg =
+        (perm_words[static_cast<uint64_t>(r) * num_blocks + (pos >> 6)] >> (pos & 63u)) & 1ull;
+    word |= (neg ^ 1ull) << j;
+  }
+  x[idx] = word;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// Plan object and C ABI
+// ---------------------------------------------------------------------------
+
+struct asp_sa_plan {
+  asp::SaHostLayout host;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  float last_sweep_ms = 0.0f, last_total_ms = 0.0f;
+  int force_m = 0, force_threads = 0;
+  int last_m = 0, last_threads = 0, last_groups = 0;
+  std::vector<int64_t> last_tracked;
+  std::vector<uint64_t> last_accepted;
+  int num_cus = 256;
+  size_t max_lds = 160 * 1024;
+  DeviceBuffer<uint32_t> color_block_start, block_width, ell_col, spin_of_pos, pos_of_spin;
+  DeviceBuffer<uint64_t> ell_off;
+  DeviceBuffer<double> ell_val, field_pos;
+};
+
+namespace {
+
+template <typename T>
+int upload_vector(DeviceBuffer<T> &dst, const std::vector<T> &src, hipStream_t stream) {
+  ASP_TRY(dst.alloc(src.size()));
+  return dst.upload(src.data(), src.size(), stream);
+}
+
+using SweepKernel = void (*)(SweepArgs);
+
+SweepKernel sweep_kernel_for(int m) {
+  switch (m) {
+    case 1: return k_sa_sweep<1>;
+    case 2: return k_sa_sweep<2>;
+    case 4: return k_sa_sweep<4>;
+    case 8: return k_sa_sweep<8>;
+    default: return nullptr;
+  }
+}
+
+size_t sweep_lds_bytes(const asp::SaHostLayout &L) {
+  return static_cast<size_t>(L.num_blocks) * 64 + 8 * sizeof(long long);
+}
+
+// Launch geometry: as many replicas per group as still leaves one group per CU,
+// as many wavefronts as a colour class has blocks.
+void choose_launch(const asp_sa_plan *p, uint32_t repetitions, int *m_out, int *threads_out) {
+  int m = 1;
+  if (p->force_m) {
+    m = p->force_m;
+  } else {
+    for (int cand : {8, 4, 2}) {
+      if ((repetitions + cand - 1) / cand >= static_cast<uint32_t>(p->num_cus)) {
+        m = cand;
+        break;
+      }
+    }
+  }
+  int threads = p->force_threads;
+  if (!threads) {
+    const uint32_t colors = p->host.num_colors ? p->host.num_colors : 1;
+    uint32_t per_color = (p->host.num_blocks + colors - 1) / colors;
+    per_color = std::min<uint32_t>(std::max<uint32_t>(per_color, 1), 16);
+    threads = static_cast<int>(per_color) * 64;
+  }
+  *m_out = m;
+  *threads_out = threads;
+}
+
+int energies_of_perm(asp_sa_plan *p, const uint64_t *perm_words, uint32_t count, double *partial,
+                     double *out_e) {
+  const asp::SaHostLayout &L = p->host;
+  if (count == 0) return ASP_OK;
+  EnergyArgs ea{p->block_width.ptr, p->ell_off.ptr, p->ell_col.ptr, p->ell_val.ptr,
+                p->field_pos.ptr,   perm_words,     partial,        L.num_blocks};
+  const size_t lds = static_cast<size_t>(L.num_blocks) * sizeof(uint64_t);
+  if (lds > p->max_lds) {
+    return asp::set_error(ASP_ERR_TOO_LARGE, "%u blocks do not fit the energy kernel's LDS",
+                          L.num_blocks);
+  }
+  if (lds > 64 * 1024) {
+    ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sa_energy_blocks),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(lds)));
+  }
+  hipLaunchKernelGGL(k_sa_energy_blocks, dim3(count), dim3(512), lds, p->stream, ea);
+  hipLaunchKernelGGL(k_sa_energy_fold, dim3(count), dim3(64), 0, p->stream, partial, L.num_blocks,
+                     L.diag_sum, out_e);
+  ASP_HIP_TRY(hipGetLastError());
+  return ASP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+asp_sa_plan *asp_sa_plan_create(uint64_t num_spins, int64_t const *indptr, int32_t const *indices,
+                                double const *data, double const *field) {
+  asp_clear_error();
+  if (asp::require_device() != ASP_OK) return nullptr;
+  asp_sa_plan *p = new (std::nothrow) asp_sa_plan();
+  if (!p) {
+    asp::set_error(ASP_ERR_ALLOC, "out of host memory");
+    return nullptr;
+  }
+  if (asp::build_sa_layout(num_spins, indptr, indices, data, field, &p->host) != ASP_OK) {
+    delete p;
+    return nullptr;
+  }
+  const asp::SaHostLayout &L = p->host;
+  bool ok = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) == hipSuccess;
+  for (auto &e : p->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+  if (!ok) asp::set_error(ASP_ERR_HIP, "could not create HIP stream/events");
+  int device = 0;
+  hipDeviceProp_t prop;
+  if (ok && hipGetDevice(&device) == hipSuccess &&
+      hipGetDeviceProperties(&prop, device) == hipSuccess) {
+    p->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (prop.sharedMemPerBlockOptin > 0) p->max_lds = prop.sharedMemPerBlockOptin;
+    else if (prop.maxSharedMemoryPerMultiProcessor > 0) p->max_lds = prop.maxSharedMemoryPerMultiProcessor;
+  }
+  ok = ok && upload_vector(p->color_block_start, L.color_block_start, p->stream) == ASP_OK &&
+       upload_vector(p->block_width, L.block_width, p->stream) == ASP_OK &&
+       upload_vector(p->ell_off, L.ell_off, p->stream) == ASP_OK &&
+       upload_vector(p->ell_col, L.ell_col, p->stream) == ASP_OK &&
+       upload_vector(p->ell_val, L.ell_val, p->stream) == ASP_OK &&
+       upload_vector(p->spin_of_pos, L.spin_of_pos, p->stream) == ASP_OK &&
+       upload_vector(p->pos_of_spin, L.pos_of_spin, p->stream) == ASP_OK &&
+       upload_vector(p->field_pos, L.field_pos, p->stream) == ASP_OK;
+  if (ok && hipStreamSynchronize(p->stream) != hipSuccess) {
+    asp::set_error(ASP_ERR_HIP, "plan upload failed");
+    ok = false;
+  }
+  if (!ok) {
+    asp_sa_plan_destroy(p);
+    return nullptr;
+  }
+  return p;
+}
+
+void asp_sa_plan_destroy(asp_sa_plan *p) {
+  if (!p) return;
+  for (auto &e : p->ev) {
+    if (e) (void)hipEventDestroy(e);
+  }
+  if (p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+}
+
+int asp_sa_plan_info(asp_sa_plan const *p, asp_sa_info *info) {
+  if (!p || !info) return asp::set_error(ASP_ERR_INVALID, "null argument");
+  const asp::SaHostLayout &L = p->host;
+  info->num_spins = L.num_spins;
+  info->nnz_offdiag = L.a_col.size();
+  info->ell_entries = L.ell_col.size();
+  info->num_colors = L.num_colors;
+  info->num_blocks = L.num_blocks;
+  info->max_degree = L.max_degree;
+  info->energy_scale_exp = L.energy_scale_exp;
+  info->diag_sum = L.diag_sum;
+  info->beta0_auto = L.beta0_auto;
+  info->beta1_auto = L.beta1_auto;
+  return ASP_OK;
+}
+
+int asp_sa_set_launch(asp_sa_plan *p, int replicas_per_group, int threads) {
+  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  if (replicas_per_group != 0 && !sweep_kernel_for(replicas_per_group)) {
+    return asp::set_error(ASP_ERR_INVALID, "replicas_per_group must be 0, 1, 2, 4 or 8");
+  }
+  if (threads != 0 && (threads < 64 || threads > 1024 || threads % 64 != 0)) {
+    return asp::set_error(ASP_ERR_INVALID, "threads must be 0 or a multiple of 64 in [64, 1024]");
+  }
+  p->force_m = replicas_per_group;
+  p->force_threads = threads;
+  return ASP_OK;
+}
+
+int asp_sa_anneal(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_sweeps,
+                  uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0,
+                  uint64_t *out_x, double *out_e) {
+  asp_clear_error();
+  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  if (repetitions == 0) return ASP_OK;
+  if (!out_x || !out_e || (num_sweeps && !betas)) {
+    return asp::set_error(ASP_ERR_INVALID, "null argument");
+  }
+  if (num_sweeps == 0xFFFFFFFFu) {
+    return asp::set_error(ASP_ERR_INVALID, "num_sweeps 2^32-1 is reserved");
+  }
+  if (static_cast<uint64_t>(replica_offset) + repetitions + 8 > 0xFFFFFFFFull) {
+    return asp::set_error(ASP_ERR_INVALID, "replica ids exceed 32 bits");
+  }
+  for (uint32_t t = 0; t < num_sweeps; ++t) {
+    if (!(betas[t] >= 0.0)) return asp::set_error(ASP_ERR_INVALID, "betas[%u] is not >= 0", t);
+  }
+  const asp::SaHostLayout &L = p->host;
+  const uint64_t K = L.num_spins;
+  const uint32_t words = static_cast<uint32_t>((K + 63) / 64);
+  p->last_sweep_ms = p->last_total_ms = 0.0f;
+  if (K == 0) {
+    for (uint32_t r = 0; r < repetitions; ++r) out_e[r] = 0.0;
+    return ASP_OK;
+  }
+  int m = 1, threads = 64;
+  choose_launch(p, repetitions, &m, &threads);
+  const size_t lds = sweep_lds_bytes(L);
+  if (lds > p->max_lds) {
+    return asp::set_error(ASP_ERR_TOO_LARGE,
+                          "%llu spins (%zu B of LDS) exceed the %zu B one workgroup may hold",
+                          (unsigned long long)K, lds, p->max_lds);
+  }
+  const uint32_t groups = (repetitions + m - 1) / m;
+  const uint64_t padded = static_cast<uint64_t>(groups) * m;
+  hipStream_t s = p->stream;
+
+  DeviceBuffer<double> d_betas, d_partial, d_e;
+  DeviceBuffer<uint64_t> d_best, d_x0, d_x0_perm, d_x;
+  DeviceBuffer<long long> d_tracked;
+  DeviceBuffer<unsigned long long> d_accepted;
+  ASP_TRY(d_betas.alloc(num_sweeps));
+  ASP_TRY(d_best.alloc(padded * L.num_blocks));
+  ASP_TRY(d_tracked.alloc(padded));
+  ASP_TRY(d_accepted.alloc(padded));
+  ASP_TRY(d_partial.alloc(static_cast<uint64_t>(repetitions) * L.num_blocks));
+  ASP_TRY(d_e.alloc(repetitions));
+  ASP_TRY(d_x.alloc(static_cast<uint64_t>(repetitions) * words));
+  ASP_TRY(d_betas.upload(betas, num_sweeps, s));
+  ASP_HIP_TRY(hipMemsetAsync(d_accepted.ptr, 0, padded * sizeof(unsigned long long), s));
+  if (x0) {
+    ASP_TRY(d_x0.alloc(words));
+    ASP_TRY(d_x0_perm.alloc(L.num_blocks));
+    ASP_TRY(d_x0.upload(x0, words, s));
+    hipLaunchKernelGGL(k_permute_bits, dim3((L.num_blocks + 255) / 256), dim3(256), 0, s, d_x0.ptr,
+                       words, p->spin_of_pos.ptr, L.num_blocks, 1u, d_x0_perm.ptr);
+  }
+
+  SweepArgs args{};
+  args.color_block_start = p->color_block_start.ptr;
+  args.block_width = p->block_width.ptr;
+  args.ell_off = p->ell_off.ptr;
+  args.ell_col = p->ell_col.ptr;
+  args.ell_val = p->ell_val.ptr;
+  args.spin_of_pos = p->spin_of_pos.ptr;
+  args.field_pos = p->field_pos.ptr;
+  args.betas = d_betas.ptr;
+  args.x0_perm = x0 ? d_x0_perm.ptr : nullptr;
+  args.best_perm = d_best.ptr;
+  args.tracked = d_tracked.ptr;
+  args.accepted = d_accepted.ptr;
+  args.seed = seed;
+  args.scale = std::ldexp(1.0, L.energy_scale_exp);
+  args.num_colors = L.num_colors;
+  args.num_blocks = L.num_blocks;
+  args.num_sweeps = num_sweeps;
+  args.replica_first = replica_offset;
+
+  SweepKernel kernel = sweep_kernel_for(m);
+  if (lds > 64 * 1024) {
+    ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(lds)));
+  }
+  ASP_HIP_TRY(hipEventRecord(p->ev[0], s));
+  ASP_HIP_TRY(hipEventRecord(p->ev[1], s));
+  hipLaunchKernelGGL(kernel, dim3(groups), dim3(threads), lds, s, args);
+  ASP_HIP_TRY(hipGetLastError());
+  ASP_HIP_TRY(hipEventRecord(p->ev[2], s));
+  // the first `repetitions` rows of best_perm are the real replicas
+  ASP_TRY(energies_of_perm(p, d_best.ptr, repetitions, d_partial.ptr, d_e.ptr));
+  {
+    const uint64_t total = static_cast<uint64_t>(repetitions) * words;
+    hipLaunchKernelGGL(k_unpermute_bits, dim3(static_cast<unsigned>((total + 255) / 256)),
+                       dim3(256), 0, s, d_best.ptr, L.num_blocks, p->pos_of_spin.ptr, K, words,
+                       repetitions, d_x.ptr);
+    ASP_HIP_TRY(hipGetLastError());
+  }
+  ASP_HIP_TRY(hipEventRecord(p->ev[3], s));
+  ASP_TRY(d_x.download(out_x, static_cast<uint64_t>(repetitions) * words, s));
+  ASP_TRY(d_e.download(out_e, repetitions, s));
+  p->last_tracked.assign(repetitions, 0);
+  p->last_accepted.assign(repetitions, 0);
+  ASP_HIP_TRY(hipMemcpyAsync(p->last_tracked.data(), d_tracked.ptr, repetitions * sizeof(int64_t),
+                             hipMemcpyDeviceToHost, s));
+  ASP_HIP_TRY(hipMemcpyAsync(p->last_accepted.data(), d_accepted.ptr,
+                             repetitions * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  ASP_HIP_TRY(hipStreamSynchronize(s));
+  p->last_m = m;
+  p->last_threads = threads;
+  p->last_groups = static_cast<int>(groups);
+  ASP_HIP_TRY(hipEventElapsedTime(&p->last_sweep_ms, p->ev[1], p->ev[2]));
+  ASP_HIP_TRY(hipEventElapsedTime(&p->last_total_ms, p->ev[0], p->ev[3]));
+  return ASP_OK;
+}
+
+int asp_sa_last_stats(asp_sa_plan const *p, uint32_t count, int64_t *tracked, uint64_t *accepted) {
+  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  if (count != p->last_tracked.size()) {
+    return asp::set_error(ASP_ERR_INVALID, "count does not match the last anneal call");
+  }
+  if (tracked) std::copy(p->last_tracked.begin(), p->last_tracked.end(), tracked);
+  if (accepted) std::copy(p->last_accepted.begin(), p->last_accepted.end(), accepted);
+  return ASP_OK;
+}
+
+int asp_sa_last_launch(asp_sa_plan const *p, int *replicas_per_group, int *threads, int *groups) {
+  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  if (replicas_per_group) *replicas_per_group = p->last_m;
+  if (threads) *threads = p->last_threads;
+  if (groups) *groups = p->last_groups;
+  return ASP_OK;
+}
+
+float asp_sa_last_sweep_ms(asp_sa_plan const *p) { return p ? p->last_sweep_ms : 0.0f; }
+float asp_sa_last_total_ms(asp_sa_plan const *p) { return p ? p->last_total_ms : 0.0f; }
+
+int asp_sa_energy(asp_sa_plan *p, uint32_t count, uint64_t const *x, double *out_e) {
+  asp_clear_error();
+  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  if (count == 0) return ASP_OK;
+  if (!x || !out_e) return asp::set_error(ASP_ERR_INVALID, "null argument");
+  const asp::SaHostLayout &L = p->host;
+  const uint64_t K = L.num_spins;
+  if (K == 0) {
+    for (uint32_t r = 0; r < count; ++r) out_e[r] = 0.0;
+    return ASP_OK;
+  }
+  const uint32_t words = static_cast<uint32_t>((K + 63) / 64);
+  hipStream_t s = p->stream;
+  DeviceBuffer<uint64_t> d_x, d_perm;
+  DeviceBuffer<double> d_partial, d_e;
+  ASP_TRY(d_x.alloc(static_cast<uint64_t>(count) * words));
+  ASP_TRY(d_perm.alloc(static_cast<uint64_t>(count) * L.num_blocks));
+  ASP_TRY(d_partial.alloc(static_cast<uint64_t>(count) * L.num_blocks));
+  ASP_TRY(d_e.alloc(count));
+  ASP_TRY(d_x.upload(x, static_cast<uint64_t>(count) * words, s));
+  const uint64_t total = static_cast<uint64_t>(count) * L.num_blocks;
+  hipLaunchKernelGGL(k_permute_bits, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+                     s, d_x.ptr, words, p->spin_of_pos.ptr, L.num_blocks, count, d_perm.ptr);
+  ASP_HIP_TRY(hipGetLastError());
+  ASP_TRY(energies_of_perm(p, d_perm.ptr, count, d_partial.ptr, d_e.ptr));
+  ASP_TRY(d_e.download(out_e, count, s));
+  ASP_HIP_TRY(hipStreamSynchronize(s));
+  return ASP_OK;
+}
+
+}  // extern "C"

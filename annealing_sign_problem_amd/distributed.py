@@ -1,0 +1,94 @@
+"""Multi-GPU sharding of annealing chains: one process per GPU, RCCL over xGMI.
+
+The reference has no distributed runtime; its only scale-out is independent
+SLURM jobs keyed by ``JOBID`` (Makefile:11-15, README.md:171-190).  The chains
+of one ``anneal`` call are independent Markov chains over a read-only J, so they
+shard with NO collective on the data path: rank ``k`` runs a contiguous block of
+global replica ids against its own copy of the plan, and a single
+``all_gather`` of (packed spins, energy) at the end gives every rank the full
+result.  The counter RNG is keyed by the GLOBAL replica id, so the gathered
+result is bit-identical for every world size.
+
+``torch`` is plumbing only (process group + the gather); with backend ``nccl``
+(= RCCL on ROCm) the payload is staged through HBM tensors, with ``gloo`` (CPU
+tests) through host tensors.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+    except Exception:  # torch absent: single process
+        return None
+    if not dist.is_available() or not dist.is_initialized():
+        return None
+    return dist
+
+
+def world_size() -> int:
+    d = _dist()
+    return d.get_world_size() if d is not None else 1
+
+
+def rank() -> int:
+    d = _dist()
+    return d.get_rank() if d is not None else 0
+
+
+def shard_range(total: int, world: int, index: int) -> Tuple[int, int]:
+    """Contiguous block of ``total`` items owned by ``index`` of ``world``: (offset, count)."""
+    base, extra = divmod(int(total), int(world))
+    count = base + (1 if index < extra else 0)
+    offset = index * base + min(index, extra)
+    return offset, count
+
+
+def all_gather_rows(local: np.ndarray, counts, group=None) -> np.ndarray:
+    """Concatenate per-rank row blocks (``counts[k]`` rows from rank k) on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    width = local.shape[1]
+    most = max(counts) if len(counts) else 0
+    padded = np.zeros((max(most, 1), width), dtype=np.int64)
+    padded[: local.shape[0]] = local.view(np.int64) if local.dtype != np.int64 else local
+    backend = dist.get_backend(group)
+    device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    mine = torch.from_numpy(padded).to(device)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    rows = [parts[k][: counts[k]].cpu().numpy() for k in range(world)]
+    return np.concatenate(rows, axis=0) if rows else padded[:0]
+
+
+def anneal_sharded(hamiltonian, seed: int, betas: np.ndarray, repetitions: int, x0=None,
+                   group=None):
+    """Run this rank's block of chains, then gather: (xs[R, words], es[R]) on every rank."""
+    from .annealer import anneal_raw
+
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    me = dist.get_rank(group)
+    offset, count = shard_range(repetitions, world, me)
+    words = (hamiltonian.size + 63) // 64
+    if count > 0:
+        xs, es = anneal_raw(hamiltonian, seed, betas, count, offset, x0)
+    else:
+        xs = np.zeros((0, words), dtype=np.uint64)
+        es = np.zeros(0, dtype=np.float64)
+    counts = [shard_range(repetitions, world, k)[1] for k in range(world)]
+    # one payload: [packed spins | energy bits] per chain
+    payload = np.concatenate(
+        [np.ascontiguousarray(xs, dtype=np.uint64).view(np.int64).reshape(count, words),
+         np.ascontiguousarray(es, dtype=np.float64).view(np.int64).reshape(count, 1)], axis=1)
+    full = all_gather_rows(payload, counts, group)
+    xs_all = np.ascontiguousarray(full[:, :words]).view(np.uint64)
+    es_all = np.ascontiguousarray(full[:, words]).view(np.float64)
+    return xs_all, es_all

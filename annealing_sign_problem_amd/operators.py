@@ -1,0 +1,194 @@
+"""Symmetry-free spin-1/2 bases and two-site operators in numpy.
+
+The reference gets these from ``lattice_symmetries`` (annealing_sign_problem/
+common.py:9; ``ls.SpinBasis``, ``ls.Operator``), a third-party C library that is
+not part of the reference tree.  This module restates the subset the coupling
+build consumes — the call surface at common.py:29,38,86,96,283,786-787,817 — for
+bases WITHOUT lattice symmetries (``symmetries: []``, e.g.
+physical_systems/heisenberg_kagome_16.yaml:1-4), so that tests and benchmarks
+can produce real ``batched_apply`` outputs.  Symmetry-adapted bases
+(kagome_36, pyrochlore) are out of scope.
+
+Conventions (unpinned against lattice_symmetries, which is unavailable): bit
+``i`` of a basis state is site ``i``, 1 = up; a two-site matrix acts on
+``|b_i b_j>`` with row/column index ``2*b_i + b_j``.  All shipped matrices are
+``c * sigma.sigma`` (symmetric under both site exchange and spin inversion)
+apart from the (3,3) entry of the J2 term in j1j2_square_4x4.yaml:22-25.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from itertools import combinations
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import scipy.sparse
+
+SIGMA_DOT_SIGMA = np.array(
+    [[1.0, 0.0, 0.0, 0.0], [0.0, -1.0, 2.0, 0.0], [0.0, 2.0, -1.0, 0.0], [0.0, 0.0, 0.0, 1.0]]
+)
+
+
+class SpinBasis:
+    """All bit strings of ``number_spins`` sites, optionally at fixed hamming weight."""
+
+    def __init__(self, number_spins: int, hamming_weight: Optional[int] = None):
+        if not 0 < number_spins <= 64:
+            raise ValueError("number_spins must be in 1..64")
+        self.number_spins = int(number_spins)
+        self.hamming_weight = None if hamming_weight is None else int(hamming_weight)
+        self._states: Optional[np.ndarray] = None
+
+    def build(self, representatives: Optional[np.ndarray] = None) -> None:
+        if representatives is not None:
+            self._states = np.sort(np.asarray(representatives, dtype=np.uint64))
+            return
+        n, w = self.number_spins, self.hamming_weight
+        if w is None:
+            if n > 26:
+                raise ValueError("refusing to enumerate 2^{} states".format(n))
+            self._states = np.arange(1 << n, dtype=np.uint64)
+            return
+        count = 1
+        for k in range(w):
+            count = count * (n - k) // (k + 1)
+        if count > 50_000_000:
+            raise ValueError("refusing to enumerate {} states".format(count))
+        states = np.fromiter(
+            (sum(1 << b for b in bits) for bits in combinations(range(n), w)),
+            dtype=np.uint64, count=count)
+        states.sort()
+        self._states = states
+
+    @property
+    def states(self) -> np.ndarray:
+        if self._states is None:
+            raise RuntimeError("basis has not been built")
+        return self._states
+
+    @property
+    def number_states(self) -> int:
+        return int(self.states.shape[0])
+
+    def batched_index(self, spins) -> np.ndarray:
+        spins = np.asarray(spins, dtype=np.uint64)
+        if spins.ndim > 1:
+            spins = spins[:, 0]
+        idx = np.searchsorted(self.states, spins)
+        clipped = np.minimum(idx, self.number_states - 1)
+        if not np.array_equal(self.states[clipped], spins):
+            raise ValueError("state does not belong to the basis")
+        return idx.astype(np.uint64)
+
+    def index(self, spin) -> int:
+        return int(self.batched_index(np.array([spin], dtype=np.uint64))[0])
+
+
+@dataclass
+class Term:
+    matrix: np.ndarray  # (4, 4)
+    sites: List[Tuple[int, int]]
+
+
+class Operator:
+    """Sum of two-site terms on a :class:`SpinBasis`."""
+
+    def __init__(self, basis: SpinBasis, terms: Sequence[Term]):
+        self.basis = basis
+        self.terms = [Term(np.asarray(t.matrix, dtype=np.complex128).reshape(4, 4),
+                           [(int(a), int(b)) for a, b in t.sites]) for t in terms]
+        for t in self.terms:
+            for a, b in t.sites:
+                if not (0 <= a < basis.number_spins and 0 <= b < basis.number_spins and a != b):
+                    raise ValueError("invalid bond ({}, {})".format(a, b))
+
+    @classmethod
+    def from_config(cls, config: dict) -> "Operator":
+        """``{"basis": {...}, "hamiltonian": {"terms": [{"matrix", "sites"}]}}``: the
+        schema of physical_systems/*.yaml (symmetries must be empty)."""
+        b = config["basis"]
+        if b.get("symmetries"):
+            raise ValueError("symmetry-adapted bases are not supported")
+        if b.get("spin_inversion") not in (None, 0):
+            raise ValueError("spin-inversion sectors are not supported")
+        basis = SpinBasis(b["number_spins"], b.get("hamming_weight"))
+        terms = [Term(np.asarray(t["matrix"]), [tuple(s) for s in t["sites"]])
+                 for t in config["hamiltonian"]["terms"]]
+        return cls(basis, terms)
+
+    # -- action on basis states ------------------------------------------------
+    def batched_apply(self, spins):
+        """``(other_spins (m, 8) u64, coeffs c128[m], counts i64[n])``: per input state one
+        diagonal entry followed by its non-zero off-diagonal connections in term
+        order (what the reference unpacks at common.py:96-103)."""
+        spins = np.asarray(spins, dtype=np.uint64)
+        if spins.ndim > 1:
+            spins = spins[:, 0]
+        n = spins.shape[0]
+        rows = [np.arange(n, dtype=np.int64)]
+        targets = [spins.copy()]
+        diagonal = np.zeros(n, dtype=np.complex128)
+        coeffs: List[np.ndarray] = [diagonal]
+        one = np.uint64(1)
+        for term in self.terms:
+            m = term.matrix
+            for a, b in term.sites:
+                ba = (spins >> np.uint64(a)) & one
+                bb = (spins >> np.uint64(b)) & one
+                k = (2 * ba + bb).astype(np.int64)
+                diagonal += m[k, k]
+                for src in range(4):
+                    for dst in range(4):
+                        if src == dst or m[dst, src] == 0:
+                            continue
+                        sel = np.nonzero(k == src)[0]
+                        if sel.size == 0:
+                            continue
+                        flip = np.uint64((((src ^ dst) >> 1) & 1) << a | ((src ^ dst) & 1) << b)
+                        rows.append(sel)
+                        targets.append(spins[sel] ^ flip)
+                        coeffs.append(np.full(sel.size, m[dst, src], dtype=np.complex128))
+        row = np.concatenate(rows)
+        order = np.argsort(row, kind="stable")
+        out = np.zeros((row.shape[0], 8), dtype=np.uint64)
+        out[:, 0] = np.concatenate(targets)[order]
+        counts = np.bincount(row, minlength=n).astype(np.int64)
+        return out, np.concatenate(coeffs)[order], counts
+
+    def apply(self, spin):
+        other, coeffs, _ = self.batched_apply(np.array([spin], dtype=np.uint64))
+        return other, coeffs
+
+    # -- dense-vector view (exact diagonalisation of 16-site systems) -------------
+    def to_sparse(self) -> scipy.sparse.csr_matrix:
+        """Matrix in the built basis; rows = output states."""
+        states = self.basis.states
+        other, coeffs, counts = self.batched_apply(states)
+        cols = np.repeat(np.arange(states.shape[0]), counts)
+        rows = np.searchsorted(states, other[:, 0])
+        ok = (rows < states.shape[0])
+        ok[ok] &= states[rows[ok]] == other[ok, 0]
+        if not ok.all():
+            raise ValueError("operator leaves the basis")
+        matrix = scipy.sparse.coo_matrix((coeffs, (rows, cols)), shape=(states.shape[0],) * 2)
+        return matrix.tocsr()
+
+    def expectation(self, vector) -> complex:
+        vector = np.asarray(vector)
+        return complex(np.vdot(vector, self.to_sparse() @ vector) / np.vdot(vector, vector))
+
+    def ground_state(self, seed: int = 0) -> Tuple[float, np.ndarray]:
+        """Lowest eigenpair (real symmetric operators), sign-fixed so that the
+        largest-magnitude amplitude is positive."""
+        import scipy.sparse.linalg
+
+        h = self.to_sparse()
+        if abs(h.imag).max() > 1e-12:
+            raise ValueError("ground_state expects a real operator")
+        h = h.real.tocsr()
+        rng = np.random.default_rng(seed)
+        v0 = rng.standard_normal(h.shape[0])
+        values, vectors = scipy.sparse.linalg.eigsh(h, k=1, which="SA", v0=v0, tol=1e-13)
+        psi = vectors[:, 0]
+        psi = psi * np.sign(psi[np.argmax(np.abs(psi))])
+        return float(values[0]), np.ascontiguousarray(psi / np.linalg.norm(psi))

@@ -1,0 +1,205 @@
+/* asp.h — C ABI of libasp_hip.so, the MI355X (gfx950) implementation of the
+ * sign-optimisation hot path of twesterhout/annealing-sign-problem.
+ *
+ * Plain C: pointers and sizes only, no torch / C++ types.  Every entry point
+ * names the reference interface it replaces (paths relative to the reference
+ * checkout).  Unless a function says "device", pointers are HOST pointers and
+ * the callee stages them through HBM itself.
+ *
+ * Error model: the two drop-in symbols keep the reference's signatures (no
+ * error return, cbits/build_matrix.h:7-14); every failure — no GPU, HIP error,
+ * violated precondition that was detected — is recorded and can be read with
+ * asp_last_error().  All other functions return 0 on success and a negative
+ * asp_status otherwise.  Nothing in this library falls back to a CPU path.
+ */
+#ifndef ASP_H
+#define ASP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* Status / errors                                                           */
+/* ------------------------------------------------------------------------- */
+
+typedef enum asp_status {
+  ASP_OK = 0,
+  ASP_ERR_NO_DEVICE = -1,  /* no HIP device visible                          */
+  ASP_ERR_HIP = -2,        /* a HIP runtime call failed                      */
+  ASP_ERR_INVALID = -3,    /* invalid argument / violated precondition       */
+  ASP_ERR_TOO_LARGE = -4,  /* problem does not fit this implementation       */
+  ASP_ERR_ALLOC = -5       /* host or device allocation failed               */
+} asp_status;
+
+/* Last error recorded on the calling thread ("" if none). */
+const char *asp_last_error(void);
+int asp_last_error_code(void);
+void asp_clear_error(void);
+
+/* Number of HIP devices (>= 0) or a negative asp_status. */
+int asp_device_count(void);
+/* Select the device used by subsequently created objects of this thread. */
+int asp_set_device(int device);
+/* Library version, "major.minor.patch". */
+const char *asp_version(void);
+
+/* ------------------------------------------------------------------------- */
+/* (1) Drop-in replacements for cbits/build_matrix.h:3-14                    */
+/*     (cffi cdef duplicate: annealing_sign_problem/build_extension.py:5-20) */
+/* ------------------------------------------------------------------------- */
+
+typedef struct ls_bits512 {
+  uint64_t words[8];
+} ls_bits512;
+
+/* Replaces build_matrix (cbits/build_matrix.c:22-65).
+ *
+ * For every row r and each of its other_counts[r] connections e (flat,
+ * row-major): look other_spins[e] up in the table spins[0..num_spins), which
+ * is sorted ascending under the lexicographic order of words[0..7]
+ * (cbits/build_matrix.c:7-20) and unique.
+ *   hit  -> append (r, position, counts[r]*other_coeffs[e]*|psi[r]|*|other_psi[e]|)
+ *           to (row_indices, col_indices, elements), preserving input order;
+ *   miss -> field[r] += counts[r]*other_coeffs[e]*|psi[r]|*other_psi[e]
+ *           (signed other_psi, left-to-right accumulation in row order).
+ * Products are evaluated left to right without FMA contraction, so results are
+ * bit-identical to the reference compiled without -ffast-math.
+ * Caller allocates all outputs (capacity sum(other_counts) for the COO triple,
+ * num_spins for field).  Returns the number of COO entries written; on failure
+ * returns 0, leaves outputs untouched and records an error.
+ */
+uint64_t build_matrix(uint64_t num_spins, ls_bits512 const spins[],
+                      int64_t const *counts, double const *psi,
+                      ls_bits512 const *other_spins, double const *other_coeffs,
+                      int64_t const *other_counts, double const *other_psi,
+                      uint32_t *row_indices, uint32_t *col_indices,
+                      double *elements, double *field);
+
+/* Replaces extract_signs (cbits/build_matrix.c:67-76): bit i of signs[i/64]
+ * is set iff psi[i] > 0 (zero and NaN clear it); ceil(num_spins/64) words are
+ * fully overwritten. */
+void extract_signs(uint64_t num_spins, double const *psi, uint64_t *signs);
+
+/* ------------------------------------------------------------------------- */
+/* (2) Device-resident form of the same coupling build (what bench.py times) */
+/* ------------------------------------------------------------------------- */
+
+typedef struct asp_build asp_build;
+
+/* Allocate HBM for a build with num_spins rows and num_other = sum(other_counts)
+ * connections.  NULL on failure. */
+asp_build *asp_build_create(uint64_t num_spins, uint64_t num_other);
+/* Host -> HBM copy of the seven input arrays of build_matrix. */
+int asp_build_upload(asp_build *b, ls_bits512 const *spins, int64_t const *counts,
+                     double const *psi, ls_bits512 const *other_spins,
+                     double const *other_coeffs, int64_t const *other_counts,
+                     double const *other_psi);
+/* Run the kernels on resident inputs; *nnz receives the COO length.  The
+ * device time of the launch sequence is measured with HIP events on the
+ * library's stream and returned by asp_build_last_ms(). */
+int asp_build_run(asp_build *b, uint64_t *nnz);
+float asp_build_last_ms(asp_build const *b);
+/* HBM -> host copy of the outputs of the last run (any pointer may be NULL). */
+int asp_build_download(asp_build *b, uint32_t *row_indices, uint32_t *col_indices,
+                       double *elements, double *field);
+void asp_build_destroy(asp_build *b);
+
+/* ------------------------------------------------------------------------- */
+/* (3) Live coupling build: the two numba kernels of common.make_ising_model */
+/* ------------------------------------------------------------------------- */
+
+/* Replaces _clipped_search_sorted (annealing_sign_problem/common.py:116-128)
+ * fused with the membership test (common.py:173) and
+ * _make_ising_model_compute_elements (common.py:71-82), for 64-bit keys
+ * (number_spins <= 64, asserted by the reference at common.py:86).
+ *
+ *   other_indices[e] = clip(searchsorted_left(keys, other_keys[e]), 0, K-1)
+ *   member[e]        = other_keys[e] == keys[other_indices[e]]
+ *   elements[e]      = (other_coeffs[e] * |member ? psi[idx] : 0|) * |psi[row(e)]|
+ *   offsets          = [0, cumsum(other_counts)]
+ * keys must be sorted ascending (np.unique output).  Any output may be NULL.
+ */
+int asp_ising_elements(uint64_t num_spins, uint64_t const *keys, double const *psi,
+                       uint64_t num_other, uint64_t const *other_keys,
+                       double const *other_coeffs, int64_t const *other_counts,
+                       int64_t *other_indices, uint8_t *member, double *elements,
+                       int64_t *offsets);
+
+/* ------------------------------------------------------------------------- */
+/* (4) Annealer: replaces ising_glass_annealer.{Hamiltonian,anneal}          */
+/*     call sites: common.py:204,242-248; full_hilbert_space.py:212-218      */
+/* ------------------------------------------------------------------------- */
+
+typedef struct asp_sa_plan asp_sa_plan;
+
+/* Build the device-resident sweep plan for E(s) = sum_ij J_ij s_i s_j +
+ * sum_i h_i s_i.  J is a square CSR matrix with sorted, duplicate-free column
+ * indices per row (scipy "canonical format"); it may carry a diagonal and need
+ * not be symmetric (the sweep uses J + J^T).  Host preprocessing: symmetrised
+ * off-diagonal part, greedy first-fit colouring, colour-major permutation,
+ * 64-row sliced-ELL slabs; all uploaded once.  NULL on failure. */
+asp_sa_plan *asp_sa_plan_create(uint64_t num_spins, int64_t const *indptr,
+                                int32_t const *indices, double const *data,
+                                double const *field);
+void asp_sa_plan_destroy(asp_sa_plan *p);
+
+typedef struct asp_sa_info {
+  uint64_t num_spins;
+  uint64_t nnz_offdiag;     /* entries of offdiag(J + J^T) after dropping zeros */
+  uint64_t ell_entries;     /* slab entries incl. padding (64 * sum of widths)  */
+  uint32_t num_colors;
+  uint32_t num_blocks;      /* 64-row blocks (colour classes padded)            */
+  uint32_t max_degree;
+  int32_t energy_scale_exp; /* S: tracked energies are in units of 2^-S         */
+  double diag_sum;          /* sum_i J_ii                                       */
+  double beta0_auto;        /* ln 2 / max_i dE_max(i)                           */
+  double beta1_auto;        /* ln 100 / min over non-zero couplings             */
+} asp_sa_info;
+int asp_sa_plan_info(asp_sa_plan const *p, asp_sa_info *info);
+
+/* The same host preprocessing WITHOUT touching a device (inspection, CPU tests):
+ * fills *info and, when non-NULL, colors[K] (greedy colour of every spin) and
+ * position[K] (index of the spin in the padded, colour-major order). */
+int asp_sa_layout_host(uint64_t num_spins, int64_t const *indptr, int32_t const *indices,
+                       double const *data, double const *field, asp_sa_info *info,
+                       int32_t *colors, uint32_t *position);
+
+/* Launch geometry override (0 = choose automatically).
+ * replicas_per_group in {1,2,4,8}; threads multiple of 64, <= 1024. */
+int asp_sa_set_launch(asp_sa_plan *p, int replicas_per_group, int threads);
+
+/* Run `repetitions` independent annealing chains (global replica ids
+ * replica_offset .. replica_offset+repetitions-1) of num_sweeps sweeps, sweep t
+ * at inverse temperature betas[t].  x0 == NULL: random initial spins from the
+ * counter RNG; otherwise every chain starts from the packed configuration x0
+ * (ceil(K/64) words, bit set = +1).  Outputs (host): out_x[repetitions *
+ * ceil(K/64)] best configuration of each chain, out_e[repetitions] its energy.
+ * The result depends only on (J, h, seed, betas, global replica id), not on the
+ * launch geometry or the number of GPUs. */
+int asp_sa_anneal(asp_sa_plan *p, uint64_t seed, double const *betas,
+                  uint32_t num_sweeps, uint32_t repetitions, uint32_t replica_offset,
+                  uint64_t const *x0, uint64_t *out_x, double *out_e);
+/* Device time (ms, HIP events on the launch stream) of the sweep kernel of the
+ * last asp_sa_anneal call, and of everything device-side in that call. */
+float asp_sa_last_sweep_ms(asp_sa_plan const *p);
+float asp_sa_last_total_ms(asp_sa_plan const *p);
+
+/* Diagnostics of the last asp_sa_anneal call: per chain the best tracked energy
+ * (fixed point, units of 2^-S, relative to the chain's start) and the number of
+ * accepted flips.  `count` = that call's repetitions.  Either may be NULL. */
+int asp_sa_last_stats(asp_sa_plan const *p, uint32_t count, int64_t *tracked,
+                      uint64_t *accepted);
+/* Launch geometry used by the last asp_sa_anneal call. */
+int asp_sa_last_launch(asp_sa_plan const *p, int *replicas_per_group, int *threads,
+                       int *groups);
+
+/* E(x) for `count` packed configurations (host in, host out). */
+int asp_sa_energy(asp_sa_plan *p, uint32_t count, uint64_t const *x, double *out_e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASP_H */

@@ -1,0 +1,183 @@
+"""GPU parity: the annealing sweep through the C ABI vs the CPU oracle (bit-exact
+packed spins, energies, tracked fixed-point energies and accepted-flip counts)."""
+import ctypes
+
+import numpy as np
+import pytest
+import scipy.sparse
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _stats(h, count):
+    from annealing_sign_problem_amd import _lib
+
+    tracked = np.zeros(count, np.int64)
+    accepted = np.zeros(count, np.uint64)
+    _lib.check(_lib.load().asp_sa_last_stats(h.plan(), count, _lib.ptr(tracked), _lib.ptr(accepted)))
+    return tracked, accepted
+
+
+def _set_launch(h, m, threads):
+    from annealing_sign_problem_amd import _lib
+
+    _lib.check(_lib.load().asp_sa_set_launch(h.plan(), m, threads))
+
+
+def _compare(J, field, seed, betas, reps, offset=0, x0=None, m=0, threads=0):
+    from annealing_sign_problem_amd import annealer as sa
+
+    h = sa.Hamiltonian(J, field)
+    _set_launch(h, m, threads)
+    xs, es = sa.anneal_raw(h, seed, betas, reps, offset, x0)
+    tracked, accepted = _stats(h, reps)
+    S = h.info().energy_scale_exp
+    oxs, oes, otracked, oaccepted = oracle.sa_anneal(J, field, seed, betas, reps, offset, x0, S,
+                                                    num_threads=8)
+    assert np.array_equal(accepted, oaccepted), "accepted-flip counts differ"
+    assert np.array_equal(tracked, otracked), "tracked energies differ"
+    assert np.array_equal(xs, oxs), "best configurations differ"
+    assert es.tobytes() == oes.tobytes(), "energies differ"
+    return h, xs, es
+
+
+def _planted(n, seed, **kw):
+    from annealing_sign_problem_amd import synthetic
+
+    return synthetic.planted_cluster(n, seed=seed, **kw)
+
+
+@pytest.mark.parametrize("m", [1, 2, 4, 8])
+def test_sweep_bit_exact_every_group_width(m):
+    J, h, _ = _planted(1500, 11)
+    betas = np.geomspace(0.5, 2e4, 40)
+    _compare(J, h, 12345, betas, 16, m=m, threads=256)
+
+
+@pytest.mark.parametrize("threads", [64, 192, 1024])
+def test_sweep_independent_of_workgroup_size(threads):
+    J, h, _ = _planted(3000, 12, mean_degree=9.0, max_degree=20)
+    betas = np.geomspace(1.0, 1e5, 25)
+    _compare(J, h, 99, betas, 8, m=4, threads=threads)
+
+
+def test_sweep_auto_launch_ragged_replicas_and_offset():
+    J, h, _ = _planted(700, 13)
+    betas = np.geomspace(0.3, 3e4, 30)
+    # 13 chains starting at global id 6: groups straddle the Philox 4-replica blocks
+    hh, xs, es = _compare(J, h, 2**63 + 17, betas, 13, offset=6)
+    # the same global ids computed as part of a bigger run give the same chains
+    from annealing_sign_problem_amd import annealer as sa
+    xs_all, es_all = sa.anneal_raw(hh, 2**63 + 17, betas, 32, 0)
+    assert np.array_equal(xs_all[6:19], xs) and es_all[6:19].tobytes() == es.tobytes()
+
+
+def test_sweep_with_field_nonsymmetric_J_and_x0():
+    rng = np.random.default_rng(3)
+    n = 900
+    J = scipy.sparse.random(n, n, density=0.01, random_state=4, format="csr", dtype=np.float64)
+    J.data = rng.normal(size=J.data.shape)          # not symmetric, has a diagonal
+    J = (J + scipy.sparse.diags(rng.normal(size=n))).tocsr()
+    field = rng.normal(size=n) * 0.3
+    x0 = rng.integers(0, 2**63, size=(n + 63) // 64, dtype=np.uint64)
+    _compare(J, field, 7, np.geomspace(0.2, 50.0, 35), 9, x0=x0, m=2, threads=128)
+
+
+def test_sweep_dense_rows_sk_like():
+    from annealing_sign_problem_amd import synthetic
+
+    J, h = synthetic.sk_cluster(600, degree=120, seed=5)
+    _compare(J, h, 5, np.geomspace(1.0, 1e4, 12), 8, m=8, threads=512)
+
+
+def test_sweep_degenerate_shapes():
+    # isolated spins only (no couplings): every proposal has dE = +-2h
+    n = 130
+    J = scipy.sparse.csr_matrix((n, n), dtype=np.float64)
+    _compare(J, np.linspace(-1, 1, n), 3, np.geomspace(0.1, 10, 10), 5)
+    # one spin
+    _compare(scipy.sparse.csr_matrix(np.array([[2.5]])), np.array([0.7]), 3, np.ones(4), 3)
+    # zero sweeps: best = initial configuration
+    J, h, _ = _planted(200, 14)
+    _compare(J, h, 1, np.zeros(0), 4)
+
+
+def test_energy_matches_oracle_and_numpy():
+    from annealing_sign_problem_amd import annealer as sa
+
+    J, h, _ = _planted(5000, 15)
+    h = np.random.default_rng(1).normal(size=5000) * 1e-3
+    ham = sa.Hamiltonian(J, h)
+    rng = np.random.default_rng(2)
+    xs = rng.integers(0, 2**63, size=(7, (5000 + 63) // 64), dtype=np.uint64)
+    xs[:, -1] &= np.uint64((1 << (5000 % 64)) - 1)
+    got = ham.energies(xs)
+    assert got.tobytes() == oracle.sa_energy(J, h, xs).tobytes()
+    for x, e in zip(xs, got):
+        s = sa.bits_to_signs(x, 5000)
+        ref = s @ (J @ s) + h @ s
+        assert abs(e - ref) <= 1e-12 * max(abs(ref), 1e-300)
+
+
+def test_anneal_api_and_quality_on_planted_ferromagnet():
+    """Unfrustrated planted instance: SA must reach the planted ground state."""
+    from annealing_sign_problem_amd import annealer as sa
+
+    J, h, planted = _planted(2000, 16, frustrated_fraction=0.0, diagonal_range=0)
+    ham = sa.Hamiltonian(J, h)
+    x, e = sa.anneal(ham, seed=12345, number_sweeps=400, repetitions=16, only_best=True)
+    assert x.dtype == np.uint64 and x.shape == ((2000 + 63) // 64,)
+    s = sa.bits_to_signs(x, 2000)
+    e_planted = planted @ (J @ planted)
+    assert e <= e_planted + 1e-12 * abs(e_planted)
+    xs, es = sa.anneal(ham, seed=12345, number_sweeps=400, repetitions=16, only_best=False)
+    assert xs.shape == (16, 32) and es.shape == (16,)
+    assert float(es.min()) == e and np.array_equal(xs[int(np.argmin(es))], x)
+    # determinism
+    x2, e2 = sa.anneal(ham, seed=12345, number_sweeps=400, repetitions=16)
+    assert np.array_equal(x, x2) and e == e2
+    assert abs(ham.energy(x) - s @ (J @ s)) <= 1e-12 * abs(e)
+
+
+def test_kagome16_full_space_signs(models):
+    """BASELINE config 'heisenberg_kagome_16: full-space SA': K = 12870, the real
+    coupling structure; chains vs oracle bit for bit, and SA recovers the exact
+    ground-state energy <psi|H|psi> = E(sign psi) within 1e-12."""
+    from annealing_sign_problem_amd import annealer as sa, common, operators
+
+    op = operators.Operator.from_config(models["heisenberg_kagome_16"])
+    op.basis.build()
+    e0, psi = op.ground_state()
+    model = common.make_ising_model(op.basis.states, op, log_psi_fn=common.ground_state_to_log_coeff_fn(psi, op.basis))
+    ham = model.ising_hamiltonian
+    assert abs(ham.energy(model.initial_signs) - e0) <= 1e-12 * abs(e0)  # full_hilbert_space.py:142-145
+    info = ham.info()
+    betas = sa.make_schedule(info.beta0_auto, info.beta1_auto, 60)
+    _compare(ham.exchange, ham.field, 435834, betas, 6, m=2, threads=1024)
+
+
+def test_full_size_properties_kagome36_sized():
+    """K = 1e5 (kagome_36-sized), 64 chains: too big for the oracle in seconds, so
+    check size-independent properties: reported energies equal E(x) recomputed
+    from the returned bits (numpy, 1e-12), different launch geometries agree
+    bit for bit, chains differ from each other, energies decrease with sweeps."""
+    from annealing_sign_problem_amd import annealer as sa
+
+    J, h, planted = _planted(100000, 17)
+    ham = sa.Hamiltonian(J, h)
+    info = ham.info()
+    betas = sa.make_schedule(info.beta0_auto, min(info.beta1_auto, 1e8), 24)
+    _set_launch(ham, 8, 1024)
+    xs, es = sa.anneal_raw(ham, 42, betas, 64)
+    _set_launch(ham, 1, 512)
+    xs1, es1 = sa.anneal_raw(ham, 42, betas, 64)
+    assert np.array_equal(xs, xs1) and es.tobytes() == es1.tobytes()
+    for r in [0, 31, 63]:
+        s = sa.bits_to_signs(xs[r], 100000)
+        ref = s @ (J @ s)
+        assert abs(es[r] - ref) <= 1e-12 * abs(ref)
+    assert len({x.tobytes() for x in xs}) == 64
+    xs_short, es_short = sa.anneal_raw(ham, 42, betas[:2], 64)
+    assert es.mean() < es_short.mean()
