@@ -182,8 +182,13 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
   L.ell_off.assign(L.num_blocks + 1, 0);
   for (uint32_t b = 0; b < L.num_blocks; ++b) L.ell_off[b + 1] = L.ell_off[b] + L.block_width[b];
   const uint64_t slabs = L.ell_off[L.num_blocks];
-  L.ell_col.assign(slabs * 64, 0);
-  L.ell_val.assign(slabs * 64, 0.0);
+  if (slabs >= (1ull << 32)) {
+    return set_error(ASP_ERR_TOO_LARGE, "%llu ELL slabs exceed the 32-bit slab index",
+                     (unsigned long long)slabs);
+  }
+  // + kEllTailSlabs of zeros: the sweep kernel's prefetch may read one quad past the end
+  L.ell_col.assign((slabs + kEllTailSlabs) * 64, 0);
+  L.ell_val.assign((slabs + kEllTailSlabs) * 64, 0.0);
   for (uint32_t b = 0; b < L.num_blocks; ++b) {
     for (uint32_t l = 0; l < 64; ++l) {
       const uint32_t pos = b * 64u + l;
@@ -239,7 +244,7 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
 static void fill_info(const asp::SaHostLayout &L, asp_sa_info *info) {
   info->num_spins = L.num_spins;
   info->nnz_offdiag = L.a_col.size();
-  info->ell_entries = L.ell_col.size();
+  info->ell_entries = L.ell_off.back() * 64;
   info->num_colors = L.num_colors;
   info->num_blocks = L.num_blocks;
   info->max_degree = L.max_degree;

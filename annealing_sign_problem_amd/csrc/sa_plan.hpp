@@ -20,6 +20,7 @@ namespace asp {
 
 constexpr uint32_t kDummySpin = 0xFFFFFFFFu;  // spin_of_pos of a padding lane
 constexpr int kWidthAlign = 4;                // block widths are rounded up to this
+constexpr int kEllTailSlabs = 4;              // zero slabs after the last block (prefetch over-read)
 
 struct SaHostLayout {
   uint64_t num_spins = 0;
@@ -39,7 +40,7 @@ struct SaHostLayout {
   std::vector<uint32_t> spin_of_pos;        // num_blocks * 64, kDummySpin for padding lanes
   std::vector<uint32_t> pos_of_spin;        // num_spins
   std::vector<double> field_pos;            // num_blocks * 64
-  std::vector<uint32_t> ell_col;            // ell_off.back() * 64
+  std::vector<uint32_t> ell_col;            // (ell_off.back() + kEllTailSlabs) * 64
   std::vector<double> ell_val;
   int32_t energy_scale_exp = 0;
   double beta0_auto = 0.0, beta1_auto = 0.0;

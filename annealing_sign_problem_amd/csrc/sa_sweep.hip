@@ -91,9 +91,26 @@ __device__ __forceinline__ double expneg(double x) {
   return __dmul_rn(p, scale);
 }
 
-// v with its sign flipped when bit `m` of the neighbour's spin byte is set.
-__device__ __forceinline__ double signed_coupling(double v, uint32_t spin_byte, int m) {
-  const unsigned long long flip = static_cast<unsigned long long>((spin_byte >> m) & 1u) << 63;
+// +-1.0 with the sign taken from bit `m` of the neighbour's spin byte (1 -> -1.0).
+// acc = fma(v, +-1.0, acc) is bit-identical to acc + (+-v): the product is exact, so
+// the only rounding is the add's.  Three VALU ops per (term, replica) and no
+// register-pair shuffling: the low dword of the multiplier is a constant zero.
+__device__ __forceinline__ double spin_factor(uint32_t spin_byte, int m) {
+  uint32_t hi;
+  if (m == 0) {
+    hi = (spin_byte << 31) | 0x3FF00000u;  // v_lshl_or_b32: nothing but bit 0 survives the shift
+  } else {
+    // bit 31 from the shifted byte, everything else from 1.0's high word: one v_bfi_b32
+    // (hipcc folds the constant mask and emits v_and + v_or instead)
+    const uint32_t shifted = spin_byte << (31 - m);
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hi) : "s"(0x80000000u), "v"(shifted), "v"(0x3FF00000u));
+  }
+  return __hiloint2double(static_cast<int>(hi), 0);
+}
+
+// v with its sign flipped when bit 0 of `neg` is set (energy kernel, not hot).
+__device__ __forceinline__ double signed_coupling(double v, uint32_t neg, int m) {
+  const unsigned long long flip = static_cast<unsigned long long>((neg >> m) & 1u) << 63;
   return __longlong_as_double(__double_as_longlong(v) ^ static_cast<long long>(flip));
 }
 
@@ -120,6 +137,36 @@ __device__ __forceinline__ uint32_t gather_bit4(uint32_t d, int m) {
 // ---------------------------------------------------------------------------
 // Sweep kernel
 // ---------------------------------------------------------------------------
+
+// Four consecutive ELL entries of one lane (one row), k .. k+3.
+struct Quad {
+  uint32_t c[4];
+  double v[4];
+};
+
+__device__ __forceinline__ void load_quad(Quad &q, const uint32_t *__restrict__ cptr,
+                                          const double *__restrict__ vptr, uint32_t k) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    q.c[j] = cptr[(k + j) * 64u];
+    q.v[j] = vptr[(k + j) * 64u];
+  }
+}
+
+template <int M>
+__device__ __forceinline__ void accumulate_quad(const Quad &q, const uint8_t *spins,
+                                                double (&acc)[M]) {
+  uint32_t s[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s[j] = spins[q.c[j]];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    double x = acc[m];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x = __builtin_fma(q.v[j], spin_factor(s[j], m), x);
+    acc[m] = x;
+  }
+}
 
 struct SweepArgs {
   const uint32_t *color_block_start;  // num_colors + 1
@@ -167,7 +214,12 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
   extern __shared__ __align__(16) uint8_t lds[];
   uint8_t *spins = lds;
   const uint32_t P = a.num_blocks * 64u;
-  long long *delta = reinterpret_cast<long long *>(lds + P);  // P is a multiple of 64
+  // P is a multiple of 64.  Per replica m: delta[m] = energy change of the running
+  // sweep, book[m] = current tracked energy, book[8+m] = best, book[16+m] = accepted flips
+  long long *delta = reinterpret_cast<long long *>(lds + P);
+  long long *book = delta + 8;
+  uint32_t *improved_flag = reinterpret_cast<uint32_t *>(book + 24);
+  uint2 *meta = reinterpret_cast<uint2 *>(book + 26);  // per block {first ELL slab, width}
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -202,55 +254,64 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
     }
     spins[p] = static_cast<uint8_t>(byte);
   }
-  if (tid < 8) delta[tid] = 0;
+  for (uint32_t b = tid; b < a.num_blocks; b += blockDim.x) {
+    meta[b] = make_uint2(static_cast<uint32_t>(a.ell_off[b]), a.block_width[b]);
+  }
+  if (tid < 32) delta[tid] = 0;  // delta[8] + book[24]
+  if (tid == 0) *improved_flag = 0;
   __syncthreads();
   snapshot<M>(spins, a, group, (1u << M) - 1u);
   __syncthreads();
 
-  long long e_cur[M], e_best[M];
-  unsigned long long n_acc[M];
-#pragma unroll
-  for (int m = 0; m < M; ++m) {
-    e_cur[m] = 0;
-    e_best[m] = 0;
-    n_acc[m] = 0;
-  }
-
   for (uint32_t t = 0; t < a.num_sweeps; ++t) {
     const double beta = a.betas[t];
     long long q_acc[M];
+    uint32_t n_acc[M];  // accepted flips of this lane in this sweep (< 2^32 blocks per sweep)
 #pragma unroll
-    for (int m = 0; m < M; ++m) q_acc[m] = 0;
+    for (int m = 0; m < M; ++m) {
+      q_acc[m] = 0;
+      n_acc[m] = 0;
+    }
 
     for (uint32_t c = 0; c < a.num_colors; ++c) {
       const uint32_t b_end = a.color_block_start[c + 1];
       for (uint32_t b = a.color_block_start[c] + wave; b < b_end; b += waves) {
         const uint32_t p = b * 64u + lane;
-        const uint32_t width = a.block_width[b];
-        const uint64_t base = a.ell_off[b] * 64u + lane;
+        const uint2 info = meta[b];  // {first slab, width}: one broadcast LDS read
+        // wave-uniform by construction; readfirstlane makes the loop control scalar
+        const uint32_t quads = __builtin_amdgcn_readfirstlane(info.y) >> 2;
+        const uint64_t base =
+            static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(info.x)) * 64u + lane;
         const uint32_t *cptr = a.ell_col + base;
         const double *vptr = a.ell_val + base;
+        // issued now, consumed after the row sum: their latency hides under the k-loop
+        const uint32_t spin = a.spin_of_pos[p];
+        const double h = a.field_pos[p];
         double acc[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[m] = 0.0;
-        for (uint32_t k = 0; k < width; k += 4) {
-          const uint32_t c0 = cptr[(k + 0) * 64u], c1 = cptr[(k + 1) * 64u];
-          const uint32_t c2 = cptr[(k + 2) * 64u], c3 = cptr[(k + 3) * 64u];
-          const double v0 = vptr[(k + 0) * 64u], v1 = vptr[(k + 1) * 64u];
-          const double v2 = vptr[(k + 2) * 64u], v3 = vptr[(k + 3) * 64u];
-          const uint32_t s0 = spins[c0], s1 = spins[c1], s2 = spins[c2], s3 = spins[c3];
-#pragma unroll
-          for (int m = 0; m < M; ++m) {
-            double x = acc[m];
-            x = __dadd_rn(x, signed_coupling(v0, s0, m));
-            x = __dadd_rn(x, signed_coupling(v1, s1, m));
-            x = __dadd_rn(x, signed_coupling(v2, s2, m));
-            x = __dadd_rn(x, signed_coupling(v3, s3, m));
-            acc[m] = x;
-          }
+        // Double-buffered k-loop: the next four (column, value) pairs are in flight while
+        // the current four are gathered from LDS and accumulated, in the order k = 0, 1, ...
+        // of the oracle.  The body has no conditional loads (hipcc would otherwise drain the
+        // queue with vmcnt(0) at the loop header): for an even quad count the last load
+        // reads one quad past the block — the next block's first slabs or the four slabs of
+        // tail padding the plan appends — and is never consumed.
+        Quad qa, qb;
+        load_quad(qa, cptr, vptr, 0);
+        uint32_t i = 0;
+        for (; i + 2 <= quads; i += 2) {
+          // sched_barrier: keep each load group AHEAD of the accumulate it overlaps with
+          // (the machine scheduler otherwise sinks the second group below it)
+          load_quad(qb, cptr, vptr, 4 * (i + 1));
+          __builtin_amdgcn_sched_barrier(0);
+          accumulate_quad<M>(qa, spins, acc);
+          __builtin_amdgcn_sched_barrier(0);
+          load_quad(qa, cptr, vptr, 4 * (i + 2));
+          __builtin_amdgcn_sched_barrier(0);
+          accumulate_quad<M>(qb, spins, acc);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        const uint32_t spin = a.spin_of_pos[p];
-        const double h = a.field_pos[p];
+        if (i < quads) accumulate_quad<M>(qa, spins, acc);
         const bool valid = spin != kDummySpin;
         const uint32_t own = spins[p];
         uint32_t flip = 0;
@@ -284,33 +345,36 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       const long long v = wave_sum_i64(q_acc[m]);
-      if (lane == 0 && v != 0) {
+      const long long n = wave_sum_i64(static_cast<long long>(n_acc[m]));
+      if (lane == 0 && n != 0) {
         atomicAdd(reinterpret_cast<unsigned long long *>(&delta[m]),
                   static_cast<unsigned long long>(v));
+        atomicAdd(reinterpret_cast<unsigned long long *>(&book[16 + m]),
+                  static_cast<unsigned long long>(n));
       }
     }
     __syncthreads();
-    uint32_t improved = 0;
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      e_cur[m] += delta[m];
-      if (e_cur[m] < e_best[m]) {
-        e_best[m] = e_cur[m];
-        improved |= 1u << m;
+    if (tid < M) {
+      const long long e = book[tid] + delta[tid];
+      book[tid] = e;
+      delta[tid] = 0;
+      if (e < book[8 + tid]) {
+        book[8 + tid] = e;
+        atomicOr(improved_flag, 1u << tid);
       }
     }
+    __syncthreads();
+    const uint32_t improved = *improved_flag;
     if (improved) snapshot<M>(spins, a, group, improved);
     __syncthreads();
-    if (tid < M) delta[tid] = 0;  // next atomics are at least one barrier away
+    if (tid == 0) *improved_flag = 0;  // next write to it is two barriers away
   }
 
-#pragma unroll
-  for (int m = 0; m < M; ++m) {
-    const unsigned long long total = static_cast<unsigned long long>(
-        wave_sum_i64(static_cast<long long>(n_acc[m])));
-    if (lane == 0 && total != 0) atomicAdd(&a.accepted[static_cast<uint64_t>(group) * M + m], total);
+  if (tid < M) {
+    a.tracked[static_cast<uint64_t>(group) * M + tid] = book[8 + tid];
+    a.accepted[static_cast<uint64_t>(group) * M + tid] =
+        static_cast<unsigned long long>(book[16 + tid]);
   }
-  if (tid < M) a.tracked[static_cast<uint64_t>(group) * M + tid] = e_best[tid];
 }
 
 // ---------------------------------------------------------------------------
@@ -460,7 +524,9 @@ SweepKernel sweep_kernel_for(int m) {
 }
 
 size_t sweep_lds_bytes(const asp::SaHostLayout &L) {
-  return static_cast<size_t>(L.num_blocks) * 64 + 8 * sizeof(long long);
+  // spins | delta[8] book[24] | flag (16 B) | meta[num_blocks]
+  return static_cast<size_t>(L.num_blocks) * 64 + 34 * sizeof(long long) +
+         static_cast<size_t>(L.num_blocks) * sizeof(uint2);
 }
 
 // Launch geometry: as many replicas per group as still leaves one group per CU,
@@ -573,7 +639,7 @@ int asp_sa_plan_info(asp_sa_plan const *p, asp_sa_info *info) {
   const asp::SaHostLayout &L = p->host;
   info->num_spins = L.num_spins;
   info->nnz_offdiag = L.a_col.size();
-  info->ell_entries = L.ell_col.size();
+  info->ell_entries = L.ell_off.back() * 64;
   info->num_colors = L.num_colors;
   info->num_blocks = L.num_blocks;
   info->max_degree = L.max_degree;

@@ -1,0 +1,320 @@
+"""Headline benchmark: simulated-annealing spin-flips/s on kagome_36-sized clusters.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One STEP = one pass of the hot path over one batch of synthetic input: for each of
+the three kagome_36-sized planted clusters of SURVEY §8d C3 (K = 1e4, 3e4, 1e5;
+mean row degree 24 incl. diagonal) run `--replicas` (default 1024) independent
+annealing chains per GPU for `--sweeps` (default 128) sweeps over the full
+automatic beta ladder, return per-chain best configurations and energies, and
+(N > 1) gather energies and each rank's best configuration over RCCL.  The plans
+(couplings in sliced-ELL form) are resident in HBM before the timed region.
+
+Weak scaling: every rank runs its own 1024 chains (global replica ids
+rank*1024 ...); value = all ranks' flip attempts / max-over-ranks wall time.
+
+The JSON line also carries
+  roofline      for the sweep kernel: algorithmic bytes (B_flip = 12*dbar + 16 per
+                attempt) / kernel time from HIP events on the launch
+                stream, against the 8 TB/s HBM3E peak;
+  cpu_baseline  the oracle's OpenMP port of the same sweep on the host cores,
+                timed on a bounded sample (rank 0, N = 1 only);
+  build         the coupling build (build_matrix) on the K = 1e5 cluster, device
+                resident, next to the reference's own C timed on a sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+CLUSTER_SIZES = (10000, 30000, 100000)
+CLUSTER_SEED = 783494  # experiments/sampled_connected_components.py:621
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--replicas", type=int, default=1024, help="chains per GPU")
+    p.add_argument("--sweeps", type=int, default=128, help="sweeps per step")
+    p.add_argument("--sizes", type=str, default=",".join(str(k) for k in CLUSTER_SIZES))
+    p.add_argument("--group", type=int, default=0, help="replicas per workgroup (0 = auto)")
+    p.add_argument("--threads", type=int, default=0, help="threads per workgroup (0 = auto)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-build", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0)
+    return p.parse_args()
+
+
+def traffic_from_profiles():
+    """Measured HBM bytes per sweep-kernel launch (rocprofv3 PMC passes, corrected as
+    MI355X_MICROARCH.md §HBM prescribes), if a committed summary names this workload."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def usable_cores() -> int:
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return cores
+
+
+def cpu_baseline(J, field, cores, seconds):
+    """Oracle sweep (OpenMP over chains) on the host: flips/s on a bounded sample."""
+    import oracle
+    from annealing_sign_problem_amd import annealer as sa, _lib
+
+    info = _lib.SaInfo()
+    m = J.tocsr()
+    indptr = m.indptr.astype(np.int64)
+    indices = m.indices.astype(np.int32)
+    _lib.check(_lib.load().asp_sa_layout_host(
+        m.shape[0], _lib.ptr(indptr), _lib.ptr(indices), _lib.ptr(m.data), _lib.ptr(field),
+        ctypes.byref(info), None, None))
+    k = m.shape[0]
+
+    def run(reps, sweeps):
+        betas = sa.make_schedule(info.beta0_auto, info.beta1_auto, sweeps)
+        t0 = time.perf_counter()
+        oracle.sa_anneal(m, field, 12345, betas, reps, 0, None, info.energy_scale_exp,
+                         num_threads=cores)
+        return time.perf_counter() - t0
+
+    reps = cores
+    t_probe = run(reps, 4)
+    rate = reps * 4 * k / max(t_probe, 1e-6)
+    sweeps = int(max(8, min(4096, seconds * rate / (reps * k))))
+    t = run(reps, sweeps)
+    return {
+        "value": reps * sweeps * k / t,
+        "unit": "spin-flips/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "oracle/sa_oracle.c (OpenMP over chains), K=%d cluster, %d chains x %d sweeps, %.1f s"
+                  % (k, reps, sweeps, t),
+    }
+
+
+def bench_build(J, cores_unused, seconds=6.0):
+    """Coupling build on the largest cluster: device-resident HIP vs the reference C."""
+    import oracle
+    from annealing_sign_problem_amd import _build_matrix, _lib, synthetic
+
+    lib = _lib.load()
+    keys, counts, psi, other, coeffs, other_counts, other_psi = synthetic.build_inputs_from_matrix(J)
+    spins = _build_matrix.as_bits512(keys)
+    others = _build_matrix.as_bits512(other)
+    n, m = spins.shape[0], others.shape[0]
+    handle = ctypes.c_void_p(lib.asp_build_create(n, m))
+    if not handle:
+        raise RuntimeError(_lib.last_error())
+    _lib.check(lib.asp_build_upload(handle, _lib.ptr(spins), _lib.ptr(counts), _lib.ptr(psi),
+                                    _lib.ptr(others), _lib.ptr(coeffs), _lib.ptr(other_counts),
+                                    _lib.ptr(other_psi)))
+    nnz = ctypes.c_uint64(0)
+    times = []
+    for _ in range(6):
+        _lib.check(lib.asp_build_run(handle, ctypes.byref(nnz)))
+        times.append(lib.asp_build_last_ms(handle))
+    lib.asp_build_destroy(handle)
+    ms = float(np.median(times[1:]))
+    # reference C (serial: cbits/build_matrix.c has no OpenMP) on a prefix of the rows; the
+    # key table must stay whole, so the remaining rows get other_counts = 0
+    rows = max(1, min(n, int(n * 0.2)))
+    cut = int(other_counts[:rows].sum())
+    ref = oracle.ref_lib()
+    cpu = None
+    if ref is not None:
+        row = np.zeros(max(cut, 1), np.uint32)
+        col = np.zeros(max(cut, 1), np.uint32)
+        el = np.zeros(max(cut, 1), np.float64)
+        fld = np.zeros(n, np.float64)
+        oc = other_counts.copy()
+        oc[rows:] = 0
+        t0 = time.perf_counter()
+        ref.build_matrix(ctypes.c_uint64(n), _lib.ptr(spins), _lib.ptr(counts), _lib.ptr(psi),
+                         _lib.ptr(others), _lib.ptr(coeffs), _lib.ptr(oc), _lib.ptr(other_psi),
+                         _lib.ptr(row), _lib.ptr(col), _lib.ptr(el), _lib.ptr(fld))
+        t = time.perf_counter() - t0
+        cpu = {"value": cut / t, "unit": "connections/s", "cores": 1, "kind": "reference",
+               "sample": "oracle/_ref (cbits/build_matrix.c, serial), first %d of %d rows, %.2f s"
+                         % (rows, n, t)}
+    return {
+        "workload": "build_matrix K=%d, %d connections (512-bit keys)" % (n, m),
+        "connections_per_s": m / (ms * 1e-3),
+        "ms": ms,
+        "nnz": int(nnz.value),
+        "algorithmic_GBps": m * 96 / (ms * 1e-3) / 1e9,
+        "cpu_baseline": cpu,
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+
+    from annealing_sign_problem_amd import _lib, synthetic
+    from annealing_sign_problem_amd import annealer as sa
+    from annealing_sign_problem_amd import distributed as asp_dist
+
+    lib = _lib.load()
+    _lib.require_gpu()
+    _lib.check(lib.asp_set_device(local_rank))
+
+    sizes = [int(s) for s in args.sizes.split(",") if s]
+    clusters = []
+    for k in sizes:
+        J, field, _ = synthetic.planted_cluster(k, seed=CLUSTER_SEED)
+        ham = sa.Hamiltonian(J, field)
+        info = ham.info()  # builds the plan: couplings now resident in HBM
+        if args.group or args.threads:
+            _lib.check(lib.asp_sa_set_launch(ham.plan(), args.group, args.threads))
+        betas = sa.make_schedule(info.beta0_auto, info.beta1_auto, args.sweeps)
+        dbar = J.nnz / J.shape[0]
+        clusters.append(dict(J=J, field=field, ham=ham, info=info, betas=betas, dbar=dbar,
+                             b_flip=12.0 * dbar + 16.0))
+
+    replicas = args.replicas
+    offset = rank * replicas
+    sweep_ms = []
+    accepted = []
+
+    def step(record):
+        for c in clusters:
+            xs, es = sa.anneal_raw(c["ham"], 12345, c["betas"], replicas, offset)
+            if record:
+                sweep_ms.append((c, lib.asp_sa_last_sweep_ms(c["ham"].plan())))
+            if world > 1:
+                best = int(np.argmin(es))
+                words = xs.shape[1]
+                payload = np.concatenate([xs[best].view(np.int64).reshape(1, words),
+                                          np.array([[es[best]]]).view(np.int64)], axis=1)
+                asp_dist.all_gather_rows(payload, [1] * world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    flips_per_step = sum(c["J"].shape[0] for c in clusters) * replicas * args.sweeps
+    value = world * flips_per_step * args.steps / elapsed
+
+    if rank == 0:
+        launch = []
+        for c in clusters:
+            m, th, g = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+            lib.asp_sa_last_launch(c["ham"].plan(), ctypes.byref(m), ctypes.byref(th), ctypes.byref(g))
+            launch.append({"K": c["J"].shape[0], "colors": int(c["info"].num_colors),
+                           "replicas_per_group": m.value, "threads": th.value, "groups": g.value,
+                           "ell_padding": float(c["info"].ell_entries) / max(1, c["info"].nnz_offdiag)})
+        alg_bytes = sum(c["J"].shape[0] * replicas * args.sweeps * c["b_flip"] for c, _ in sweep_ms)
+        kernel_s = sum(ms for _, ms in sweep_ms) * 1e-3
+        launches = max(1, len(sweep_ms))
+        achieved = alg_bytes / kernel_s / 1e9
+        traffic = traffic_from_profiles()
+        roofline = {
+            "bound": "hbm",
+            "kernel": "k_sa_sweep",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic.get("hbm_bytes_per_launch") if traffic else None,
+            "algorithmic_bytes_per_launch": alg_bytes / launches,
+            "avg_launch_ms": kernel_s * 1e3 / launches,
+            "kernel_flips_per_s": flips_per_step * args.steps / kernel_s,
+            "note": "couplings are cache-resident and shared by the replicas of a workgroup, so "
+                    "algorithmic bytes/s may exceed the HBM peak; see DESIGN.md §6",
+        }
+        out = {
+            "metric": "SA spin-flips/sec, kagome_36-sized clusters",
+            "value": value,
+            "unit": "spin-flips/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "heisenberg_kagome_36-sized planted clusters K=%s, dbar=24, %d chains/GPU, "
+                            "%d sweeps/step (geometric beta ladder), Metropolis single-spin-flip"
+                            % ("/".join(str(s) for s in sizes), replicas, args.sweeps),
+                "replicas_per_gpu": replicas,
+                "sweeps_per_step": args.sweeps,
+                "launch": launch,
+            },
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cores = usable_cores()
+            out["cpu_baseline"] = cpu_baseline(clusters[0]["J"], clusters[0]["field"], cores,
+                                               args.cpu_seconds)
+        if world == 1 and not args.no_build:
+            out["build"] = bench_build(clusters[-1]["J"], 1)
+        print(json.dumps(out))
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
