@@ -1,0 +1,71 @@
+"""CPU, world_size 2, gloo: the replica-sharding + final-gather layer
+(annealing_sign_problem_amd/distributed.py).  No GPU here, so each rank's local
+block of chains is produced by the oracle standing in for the device call; what
+is under test is that sharding by GLOBAL replica id and gathering reproduces the
+single-process result bit for bit on every rank."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, repetitions, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    import oracle
+    from annealing_sign_problem_amd import annealer, distributed, synthetic
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank,
+                            world_size=world)
+    J, h, _ = synthetic.planted_cluster(300, seed=3, mean_degree=8.0)
+    betas = np.geomspace(0.5, 100.0, 15)
+
+    def fake_anneal_raw(hamiltonian, seed, betas, count, offset=0, x0=None):
+        xs, es, _, _ = oracle.sa_anneal(hamiltonian.exchange, hamiltonian.field, seed, betas, count,
+                                        offset, x0, 40)
+        return xs, es
+
+    annealer.anneal_raw = fake_anneal_raw
+    ham = annealer.Hamiltonian(J, h)
+    assert distributed.world_size() == world and distributed.rank() == rank
+    xs, es = distributed.anneal_sharded(ham, 999, betas, repetitions)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), xs=xs, es=es)
+    # the public entry point picks the sharded path by itself
+    annealer_info = type("I", (), {"beta0_auto": 0.5, "beta1_auto": 100.0})()
+    ham.info = lambda: annealer_info
+    x, e = annealer.anneal(ham, seed=999, number_sweeps=15, repetitions=repetitions)
+    np.savez(os.path.join(out_dir, "best%d.npz" % rank), x=x, e=e)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("repetitions", [7, 2])
+def test_sharded_anneal_equals_single_process(tmp_path, repetitions):
+    import torch.multiprocessing as mp
+
+    import oracle
+    from annealing_sign_problem_amd import synthetic
+
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, repetitions, str(tmp_path)), nprocs=world, join=True)
+    J, h, _ = synthetic.planted_cluster(300, seed=3, mean_degree=8.0)
+    betas = np.geomspace(0.5, 100.0, 15)
+    xs, es, _, _ = oracle.sa_anneal(J, h, 999, betas, repetitions, 0, None, 40)
+    for rank in range(world):
+        got = np.load(tmp_path / ("rank%d.npz" % rank))
+        assert np.array_equal(got["xs"], xs) and got["es"].tobytes() == es.tobytes()
+        best = np.load(tmp_path / ("best%d.npz" % rank))
+        k = int(np.argmin(es))
+        assert np.array_equal(best["x"], xs[k]) and float(best["e"]) == es[k]

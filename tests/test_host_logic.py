@@ -1,0 +1,186 @@
+"""CPU: host-side logic of the package and the C-ABI surface (no device compute)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse
+
+import oracle
+from conftest import ROOT, golden
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from annealing_sign_problem_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "asp.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b([a-z_][a-z0-9_]*)\s*\(", header)) - {"defined"}
+    declared = {d for d in declared if d.startswith("asp_") or d in ("build_matrix", "extract_signs")}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()  # resolves every symbol or raises
+    raw = ctypes.CDLL(_lib.library_path())
+    for name in declared:
+        assert getattr(raw, name) is not None
+    assert lib.asp_version().decode().count(".") == 2
+
+
+def test_fails_loudly_without_gpu():
+    from annealing_sign_problem_amd import _build_matrix, _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.AspError) as err:
+        _build_matrix.build_matrix(np.arange(3, dtype=np.uint64), np.ones(3, np.int64), np.ones(3),
+                                   np.arange(3, dtype=np.uint64), np.ones(3),
+                                   np.ones(3, np.int64), np.ones(3))
+    assert err.value.code == -1
+    ham = sa.Hamiltonian(scipy.sparse.identity(4, format="csr"), np.zeros(4))
+    with pytest.raises(_lib.AspError):
+        sa.anneal(ham, seed=1, number_sweeps=2, repetitions=1)
+    with pytest.raises(_lib.AspError):
+        _build_matrix.extract_signs(np.ones(5))
+
+
+def test_bit_packing_conventions():
+    from annealing_sign_problem_amd import annealer as sa
+
+    rng = np.random.default_rng(0)
+    for n in [1, 63, 64, 65, 1000]:
+        signs = rng.choice([-1.0, 1.0], size=n)
+        bits = sa.signs_to_bits(signs)
+        assert bits.dtype == np.uint64 and bits.shape == ((n + 63) // 64,)
+        assert np.array_equal(bits, oracle.extract_signs(signs))  # cbits/build_matrix.c:72-74
+        back = sa.bits_to_signs(bits, n)
+        assert back.dtype == np.float64 and np.array_equal(back, signs)
+    assert sa.signs_to_bits(np.array([0.0, 1.0, -1.0, 0.0]))[0] == 0b0010  # sign(0) -> bit clear
+    with pytest.raises(ValueError):
+        sa.bits_to_signs(np.zeros(1, np.uint64), 65)
+
+
+def test_schedule():
+    from annealing_sign_problem_amd import annealer as sa
+
+    b = sa.make_schedule(0.5, 50.0, 11)
+    assert b.shape == (11,) and b[0] == 0.5 and b[-1] == 50.0
+    assert np.allclose(b[1:] / b[:-1], (50.0 / 0.5) ** 0.1)
+    assert sa.make_schedule(1.0, 2.0, 0).shape == (0,)
+    assert sa.make_schedule(1.0, 2.0, 1).tolist() == [2.0]
+    with pytest.raises(ValueError):
+        sa.make_schedule(0.0, 1.0, 5)
+
+
+def test_accuracy_and_overlap_match_reference_golden():
+    from annealing_sign_problem_amd import common
+
+    g = golden("accuracy_overlap.npz")
+    n = int(g["number_spins"])
+    for pred, acc, ov in zip(g["predicted"], g["accuracy"], g["overlap"]):
+        a, o = common.compute_accuracy_and_overlap(pred, g["exact"], g["weights"])
+        assert a == acc[0] and o == ov[0]
+        a, o = common.compute_accuracy_and_overlap(pred, g["exact"], number_spins=n)
+        assert a == acc[1] and o == ov[1]
+    with pytest.raises(ValueError):
+        common.compute_accuracy_and_overlap(g["predicted"][0], g["exact"])
+
+
+def test_sparsify_matches_reference_golden():
+    """common.py:634-692 on the reference's own output (host numpy/scipy; the
+    Hamiltonian objects never touch the device here)."""
+    from annealing_sign_problem_amd import common
+    from annealing_sign_problem_amd import annealer as sa
+
+    g = golden("make_ising_kagome16_cluster.npz")
+    n = g["ext_spins"].shape[0]
+    ext = scipy.sparse.coo_matrix((g["ext_data"], (g["ext_row"], g["ext_col"])), shape=(n, n))
+    log_psi = np.log(np.abs(g["ground_state"]) + 0j)
+    idx = np.searchsorted(g["basis_states"], g["ext_spins"])
+    psi = g["ground_state"][idx]
+    model = common.IsingModel(g["ext_spins"], None, sa.Hamiltonian(ext, np.zeros(n)),
+                              sa.signs_to_bits(np.sign(psi)))
+    out = common.sparsify_using_global_cutoff(model, float(g["sp_reltol"]), g["spins"])
+    assert np.array_equal(out.spins, g["sp_spins"])
+    m = scipy.sparse.coo_matrix(out.ising_hamiltonian.exchange)
+    assert np.array_equal(m.row, g["sp_row"]) and np.array_equal(m.col, g["sp_col"])
+    assert m.data.tobytes() == g["sp_data"].tobytes()
+    assert np.array_equal(out.initial_signs, g["sp_x0"])
+
+
+def test_strongest_off_diag_and_binary_search():
+    from annealing_sign_problem_amd import common
+
+    rng = np.random.default_rng(3)
+    m = scipy.sparse.random(200, 200, density=0.05, random_state=3, format="csr")
+    m = (m + scipy.sparse.diags(rng.normal(size=200) * 10)).tocsr()
+    got = common.get_strongest_off_diag(m)
+    dense = np.abs(m.toarray())
+    np.fill_diagonal(dense, 0)
+    assert np.array_equal(got, dense.max(axis=1))
+    hay = np.array([2, 5, 9, 11], dtype=np.uint64)
+    assert common.binary_search(hay, np.array([9, 2], dtype=np.uint64)).tolist() == [2, 0]
+    with pytest.raises(AssertionError):
+        common.binary_search(hay, np.array([3], dtype=np.uint64))
+
+
+def test_plan_layout_matches_oracle_layout():
+    """Host preprocessing of the product (csrc/sa_plan.cpp) vs the oracle's restatement."""
+    from annealing_sign_problem_amd import _lib, synthetic
+
+    lib = _lib.load()
+    for n, seed in [(1, 1), (70, 2), (3000, 3)]:
+        J, h, _ = synthetic.planted_cluster(n, seed=seed, mean_degree=min(23.0, n / 3))
+        indptr = J.indptr.astype(np.int64)
+        indices = J.indices.astype(np.int32)
+        info = _lib.SaInfo()
+        colors = np.zeros(n, np.int32)
+        pos = np.zeros(n, np.uint32)
+        _lib.check(lib.asp_sa_layout_host(n, _lib.ptr(indptr), _lib.ptr(indices), _lib.ptr(J.data),
+                                          _lib.ptr(h), ctypes.byref(info), _lib.ptr(colors),
+                                          _lib.ptr(pos)))
+        ocolors, order, ncol, nnz, diag = oracle.sa_layout(J)
+        assert np.array_equal(colors, ocolors) and info.num_colors == ncol
+        assert info.nnz_offdiag == nnz and info.diag_sum == diag
+        assert np.all(np.diff(pos[order].astype(np.int64)) > 0)   # same visiting order
+        assert len(set(pos.tolist())) == n and pos.max() < info.num_blocks * 64
+        assert info.ell_entries % 256 == 0 and info.ell_entries >= nnz
+        assert info.beta0_auto > 0 and info.beta1_auto >= info.beta0_auto or nnz == 0
+    # rejects non-canonical input loudly
+    bad_indices = np.array([1, 0], np.int32)
+    rc = lib.asp_sa_layout_host(2, _lib.ptr(np.array([0, 2, 2], np.int64)), _lib.ptr(bad_indices),
+                                _lib.ptr(np.ones(2)), _lib.ptr(np.zeros(2)), None, None, None)
+    assert rc == -3 and b"canonical" in lib.asp_last_error()
+
+
+def test_operators_small_systems(models):
+    from annealing_sign_problem_amd import operators
+
+    ring = operators.Operator(operators.SpinBasis(4, 2), [operators.Term(
+        operators.SIGMA_DOT_SIGMA, [(0, 1), (1, 2), (2, 3), (3, 0)])])
+    ring.basis.build()
+    e0, psi = ring.ground_state()
+    assert abs(e0 + 8.0) < 1e-10 and ring.basis.number_states == 6
+    kag = operators.Operator.from_config(models["heisenberg_kagome_16"])
+    kag.basis.build()
+    assert kag.basis.number_states == 12870
+    other, coeffs, counts = kag.batched_apply(kag.basis.states[:500])
+    assert other.shape == (counts.sum(), 8) and coeffs.dtype == np.complex128
+    # 24 bonds: off-diagonal connections = number of antiparallel bonds, plus one diagonal entry
+    s = kag.basis.states[:500]
+    bonds = models["heisenberg_kagome_16"]["hamiltonian"]["terms"][0]["sites"]
+    anti = sum(((s >> np.uint64(a)) ^ (s >> np.uint64(b))) & np.uint64(1) for a, b in bonds)
+    assert np.array_equal(counts, anti.astype(np.int64) + 1)
+    h = kag.to_sparse()
+    assert abs(h - h.T).max() < 1e-14
+
+
+def test_shard_range_covers_everything():
+    from annealing_sign_problem_amd import distributed
+
+    for total in [0, 1, 7, 64, 1000]:
+        for world in [1, 2, 3, 8]:
+            parts = [distributed.shard_range(total, world, k) for k in range(world)]
+            assert sum(c for _, c in parts) == total
+            assert all(parts[k][0] + parts[k][1] == parts[k + 1][0] for k in range(world - 1))
+            assert max(c for _, c in parts) - min(c for _, c in parts) <= 1

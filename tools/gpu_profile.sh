@@ -1,15 +1,20 @@
 #!/bin/bash
-# Runs on the GPU box: kernel-trace stats of bench.py, then PMC passes on the sweep kernel.
+# Runs on the GPU box: kernel-trace stats of bench.py, FETCH_SIZE calibration, then PMC
+# passes (each in its own run, --kernel-trace only) on the sweep kernel.
 set -o pipefail
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_trace.log 2>&1 || exit 1
-ARGS="tools/profile_sweep.py --size 100000 --group 4 --threads 1024 --sweeps 32 --runs 2"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-build > $OUT/bench_trace.log 2>&1 || exit 1
+hipcc --offload-arch=gfx950 -O3 tools/fetch_calibrate.hip -o /tmp/fetch_calibrate > $OUT/calib_build.log 2>&1 || exit 6
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_calib -- /tmp/fetch_calibrate > $OUT/pmc_calib.log 2>&1 || exit 7
+# the SAME command as the bench line (rank 0, N=1), minus the CPU legs
+ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-build"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $ARGS > $OUT/pmc_fetch.log 2>&1 || exit 2
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -- python $ARGS > $OUT/pmc_l2.log 2>&1 || exit 3
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/pmc_sq1 -- python $ARGS > $OUT/pmc_sq1.log 2>&1 || exit 4
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM --output-format csv -d $OUT/pmc_sq2 -- python $ARGS > $OUT/pmc_sq2.log 2>&1 || exit 5
-rocprofv3 -L > $OUT/counters_list.txt 2>&1
-find $OUT -name "*.csv" | head -50
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmc_sq2 -- python $ARGS > $OUT/pmc_sq2.log 2>&1 || exit 5
+python tools/summarise_profile.py $OUT ${1:-r01} > $OUT/summary.log 2>&1
+cp profiles/${1:-r01}_* $OUT/ 2>/dev/null
+tail -5 $OUT/bench_trace.log | cut -c1-600
