@@ -5,21 +5,24 @@
 // Data in HBM (all SoA except the 512-bit keys, which keep the reference's AoS
 // layout because that is what the ABI hands over):
 //   table   ls_bits512[K]   sorted, unique           table0  u64[K] = words[0]
+//   slots   u64[2^s]        open-addressing hash of table0: {fingerprint:32 | index+1:32}
 //   needles ls_bits512[N]   flat, row-major by row
 //   counts i64[K], psi f64[K], coeffs f64[N], other_psi f64[N], other_counts i64[K]
 //   offsets i64[K+1] (scan of other_counts), found i32[N] (table index or -1),
 //   row_hits u32[K], row_start i64[K+1] (scan of row_hits)
 //   out: row u32[N], col u32[N], elements f64[N], field f64[K]
 //
-// Launch sequence of one build (all on one stream, no host round trip except
-// reading back nnz):
-//   k_split_word0      table -> table0 (8 B/key probe array instead of 64 B)
-//   scan               other_counts -> offsets
-//   k_search           one lane per needle: binary search, word 0 first
-//   k_row_hits         one lane per row: number of hits in its needle range
-//   scan               row_hits -> row_start
-//   k_emit             one lane per row: COO triples in input order + the row's
-//                      field as a left-to-right sum (the reference's rounding)
+// Launch sequence of one build (one stream, no host round trip except nnz):
+//   k_split_word0   table -> table0, and a flag "some table key has a non-zero word 1..7"
+//   k_hash_insert   table0 -> slots (load factor <= 1/2, linear probing, atomicCAS)
+//   scan            other_counts -> offsets
+//   k_search_rows   32 lanes per row: each lane resolves one connection through the hash
+//                   (the reference bsearches, cbits/build_matrix.c:37-38; on a unique table
+//                   any exact lookup returns the same element), row hit count by ballot
+//   scan            row_hits -> row_start
+//   k_emit_rows     32 lanes per row: COO triples in input order at ballot-prefix positions
+//                   (coalesced), and the row's field as a LEFT-TO-RIGHT sum over its misses
+//                   (the reference's rounding, cbits/build_matrix.c:49)
 //
 // Arithmetic: __dmul_rn / __dadd_rn keep every product and the field add
 // separately rounded (no FMA contraction), matching the reference binary.
@@ -31,100 +34,171 @@ namespace {
 using asp::DeviceBuffer;
 
 constexpr int kThreads = 256;
+constexpr int kRowLanes = 32;                         // lanes cooperating on one row
+constexpr int kRowsPerBlock = kThreads / kRowLanes;   // 8
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
 
 __global__ __launch_bounds__(kThreads) void k_split_word0(const ls_bits512 *__restrict__ table,
                                                          uint64_t n,
-                                                         uint64_t *__restrict__ table0) {
+                                                         uint64_t *__restrict__ table0,
+                                                         uint32_t *__restrict__ tail_flag) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x;
-  if (i < n) table0[i] = table[i].words[0];
-}
-
-// Three-way compare of words[1..7] (word 0 already known equal); the order of
-// cbits/build_matrix.c:11-18.
-__device__ __forceinline__ int compare_tail(const ls_bits512 *__restrict__ a,
-                                            const ls_bits512 *__restrict__ b) {
+  if (i >= n) return;
+  const ls_bits512 key = table[i];
+  table0[i] = key.words[0];
+  uint64_t tail = 0;
 #pragma unroll
-  for (int w = 1; w < 8; ++w) {
-    const uint64_t x = a->words[w];
-    const uint64_t y = b->words[w];
-    if (x != y) return x < y ? -1 : 1;
-  }
-  return 0;
+  for (int w = 1; w < 8; ++w) tail |= key.words[w];
+  if (tail != 0) atomicOr(tail_flag, 1u);
 }
 
-// Index of *needle in the sorted unique table, or -1.
-__device__ __forceinline__ int32_t find_key(const uint64_t *__restrict__ table0,
-                                            const ls_bits512 *__restrict__ table, uint64_t n,
+__global__ __launch_bounds__(kThreads) void k_hash_insert(const uint64_t *__restrict__ table0,
+                                                         uint64_t n,
+                                                         unsigned long long *__restrict__ slots,
+                                                         uint64_t mask) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t h = mix64(table0[i]);
+  const unsigned long long entry = (h & 0xFFFFFFFF00000000ull) | (i + 1);
+  uint64_t at = h & mask;
+  while (atomicCAS(&slots[at], 0ull, entry) != 0ull) at = (at + 1) & mask;
+}
+
+// Words 1..7 equal?  (word 0 already known equal)
+__device__ __forceinline__ bool tails_equal(const ls_bits512 *__restrict__ a,
+                                            const ls_bits512 *__restrict__ b) {
+  uint64_t diff = 0;
+#pragma unroll
+  for (int w = 1; w < 8; ++w) diff |= a->words[w] ^ b->words[w];
+  return diff == 0;
+}
+
+// Index of *needle in the table, or -1.
+__device__ __forceinline__ int32_t find_key(const unsigned long long *__restrict__ slots,
+                                            uint64_t mask, const uint64_t *__restrict__ table0,
+                                            const ls_bits512 *__restrict__ table,
+                                            bool table_has_tails,
                                             const ls_bits512 *__restrict__ needle) {
   const uint64_t n0 = needle->words[0];
-  uint64_t lo = 0, hi = n;
-  while (lo < hi) {
-    const uint64_t mid = lo + ((hi - lo) >> 1);
-    const uint64_t t0 = table0[mid];
-    int c;
-    if (t0 != n0) {
-      c = t0 < n0 ? -1 : 1;
+  const uint64_t h = mix64(n0);
+  const uint32_t fingerprint = static_cast<uint32_t>(h >> 32);
+  for (uint64_t at = h & mask;; at = (at + 1) & mask) {
+    const unsigned long long slot = slots[at];
+    if (slot == 0) return -1;
+    if (static_cast<uint32_t>(slot >> 32) != fingerprint) continue;
+    const uint32_t idx = static_cast<uint32_t>(slot) - 1u;
+    if (table0[idx] != n0) continue;
+    // word 0 matches: the full 512-bit keys must agree (cbits/build_matrix.c:11-18)
+    bool same;
+    if (table_has_tails) {
+      same = tails_equal(&table[idx], needle);
     } else {
-      c = compare_tail(&table[mid], needle);
-      if (c == 0) return static_cast<int32_t>(mid);
+      uint64_t tail = 0;
+#pragma unroll
+      for (int w = 1; w < 8; ++w) tail |= needle->words[w];
+      same = tail == 0;
     }
-    if (c < 0) {
-      lo = mid + 1;
-    } else {
-      hi = mid;
-    }
+    if (same) return static_cast<int32_t>(idx);
   }
-  return -1;
 }
 
-__global__ __launch_bounds__(kThreads) void k_search(const uint64_t *__restrict__ table0,
-                                                    const ls_bits512 *__restrict__ table,
-                                                    uint64_t num_spins,
-                                                    const ls_bits512 *__restrict__ needles,
-                                                    uint64_t num_other,
-                                                    int32_t *__restrict__ found) {
-  const uint64_t e = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x;
-  if (e < num_other) found[e] = find_key(table0, table, num_spins, &needles[e]);
+// Ballot restricted to this lane's 32-lane half.
+__device__ __forceinline__ uint32_t half_ballot(bool predicate, uint32_t lane) {
+  const uint64_t all = __ballot(predicate);
+  return static_cast<uint32_t>(all >> (lane & 32u));
 }
 
-__global__ __launch_bounds__(kThreads) void k_row_hits(const int64_t *__restrict__ offsets,
-                                                      const int32_t *__restrict__ found,
-                                                      uint64_t num_spins,
-                                                      uint32_t *__restrict__ row_hits) {
-  const uint64_t r = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x;
-  if (r >= num_spins) return;
+__global__ __launch_bounds__(kThreads) void k_search_rows(
+    const unsigned long long *__restrict__ slots, uint64_t mask,
+    const uint64_t *__restrict__ table0, const ls_bits512 *__restrict__ table,
+    const uint32_t *__restrict__ tail_flag, uint64_t num_spins,
+    const ls_bits512 *__restrict__ needles, const int64_t *__restrict__ offsets,
+    int32_t *__restrict__ found, uint32_t *__restrict__ row_hits) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t sub = threadIdx.x & (kRowLanes - 1);
+  const uint64_t r = static_cast<uint64_t>(blockIdx.x) * kRowsPerBlock + threadIdx.x / kRowLanes;
+  const bool row_ok = r < num_spins;
+  const int64_t begin = row_ok ? offsets[r] : 0;
+  const int64_t end = row_ok ? offsets[r + 1] : 0;
+  const bool has_tails = *tail_flag != 0;
   uint32_t hits = 0;
-  for (int64_t e = offsets[r]; e < offsets[r + 1]; ++e) hits += found[e] >= 0 ? 1u : 0u;
-  row_hits[r] = hits;
+  // both halves of the wavefront iterate until the longer row is done, so the ballot is
+  // always executed by all 64 lanes
+  const int64_t other_len = __shfl_xor(end - begin, 32, 64);
+  const int64_t trips = ((end - begin > other_len ? end - begin : other_len) + kRowLanes - 1) / kRowLanes;
+  for (int64_t it = 0; it < trips; ++it) {
+    const int64_t e = begin + it * kRowLanes + sub;
+    const bool active = e < end;
+    int32_t idx = -1;
+    if (active) {
+      idx = find_key(slots, mask, table0, table, has_tails, &needles[e]);
+      found[e] = idx;
+    }
+    hits += __popc(half_ballot(idx >= 0, lane));
+  }
+  if (row_ok && sub == 0) row_hits[r] = hits;
 }
 
-__global__ __launch_bounds__(kThreads) void k_emit(
+__global__ __launch_bounds__(kThreads) void k_emit_rows(
     const int64_t *__restrict__ offsets, const int64_t *__restrict__ row_start,
     const int32_t *__restrict__ found, const int64_t *__restrict__ counts,
     const double *__restrict__ psi, const double *__restrict__ coeffs,
     const double *__restrict__ other_psi, uint64_t num_spins, uint32_t *__restrict__ out_row,
     uint32_t *__restrict__ out_col, double *__restrict__ out_elements,
     double *__restrict__ out_field) {
-  const uint64_t r = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x;
-  if (r >= num_spins) return;
-  const double c = static_cast<double>(counts[r]);  // exact int64 -> f64 conversion as in C
-  const double a = fabs(psi[r]);
-  int64_t w = row_start[r];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t sub = threadIdx.x & (kRowLanes - 1);
+  const uint32_t half_base = lane & 32u;
+  const uint64_t r = static_cast<uint64_t>(blockIdx.x) * kRowsPerBlock + threadIdx.x / kRowLanes;
+  const bool row_ok = r < num_spins;
+  const int64_t begin = row_ok ? offsets[r] : 0;
+  const int64_t end = row_ok ? offsets[r + 1] : 0;
+  const double c = row_ok ? static_cast<double>(counts[r]) : 0.0;  // exact i64 -> f64 as in C
+  const double a = row_ok ? fabs(psi[r]) : 0.0;
+  int64_t w = row_ok ? row_start[r] : 0;
   double f = 0.0;
-  for (int64_t e = offsets[r]; e < offsets[r + 1]; ++e) {
-    const int32_t pos = found[e];
+  const int64_t other_len = __shfl_xor(end - begin, 32, 64);
+  const int64_t trips = ((end - begin > other_len ? end - begin : other_len) + kRowLanes - 1) / kRowLanes;
+  for (int64_t it = 0; it < trips; ++it) {
+    const int64_t e = begin + it * kRowLanes + sub;
+    const bool active = e < end;
+    const int32_t pos = active ? found[e] : -1;
     // ((counts * coeff) * |psi|) * x, each product rounded: build_matrix.c:41-42,49
-    const double head = __dmul_rn(__dmul_rn(c, coeffs[e]), a);
-    if (pos >= 0) {
-      out_row[w] = static_cast<uint32_t>(r);
-      out_col[w] = static_cast<uint32_t>(pos);
-      out_elements[w] = __dmul_rn(head, fabs(other_psi[e]));
-      ++w;
-    } else {
-      f = __dadd_rn(f, __dmul_rn(head, other_psi[e]));
+    const double head = active ? __dmul_rn(__dmul_rn(c, coeffs[e]), a) : 0.0;
+    const double x = active ? other_psi[e] : 0.0;
+    const bool hit = active && pos >= 0;
+    const uint32_t hit_mask = half_ballot(hit, lane);
+    if (hit) {
+      const int64_t at = w + __popc(hit_mask & ((1u << sub) - 1u));
+      out_row[at] = static_cast<uint32_t>(r);
+      out_col[at] = static_cast<uint32_t>(pos);
+      out_elements[at] = __dmul_rn(head, fabs(x));
+    }
+    w += __popc(hit_mask);
+    // misses: every lane of the half replays the row's sequential sum
+    const double t = __dmul_rn(head, x);
+    uint32_t miss_mask = half_ballot(active && pos < 0, lane);
+    const uint32_t other_mask = __shfl_xor(miss_mask, 32, 64);
+    uint32_t rounds = __popc(miss_mask) > __popc(other_mask) ? __popc(miss_mask) : __popc(other_mask);
+    for (; rounds > 0; --rounds) {  // uniform trip count: the shuffle runs with all lanes on
+      const bool take = miss_mask != 0;
+      const uint32_t j = take ? static_cast<uint32_t>(__ffs(miss_mask) - 1) : 0u;
+      const double tj = __shfl(t, static_cast<int>(half_base + j), 64);
+      if (take) {
+        f = __dadd_rn(f, tj);
+        miss_mask &= miss_mask - 1u;
+      }
     }
   }
-  out_field[r] = f;
+  if (row_ok && sub == 0) out_field[r] = f;
 }
 
 // extract_signs: one wavefront builds one 64-bit word with a ballot.
@@ -138,6 +212,9 @@ __global__ __launch_bounds__(kThreads) void k_extract_signs(const double *__rest
 }
 
 inline unsigned blocks_for(uint64_t n) { return static_cast<unsigned>((n + kThreads - 1) / kThreads); }
+inline unsigned row_blocks_for(uint64_t rows) {
+  return static_cast<unsigned>((rows + kRowsPerBlock - 1) / kRowsPerBlock);
+}
 
 }  // namespace
 
@@ -151,6 +228,9 @@ struct asp_build {
   bool uploaded = false;
   DeviceBuffer<ls_bits512> table, needles;
   DeviceBuffer<uint64_t> table0;
+  DeviceBuffer<unsigned long long> slots;
+  DeviceBuffer<uint32_t> tail_flag;
+  uint64_t slot_mask = 0;
   DeviceBuffer<int64_t> counts, other_counts, offsets, row_start, scratch;
   DeviceBuffer<double> psi, coeffs, other_psi, elements, field;
   DeviceBuffer<int32_t> found;
@@ -177,9 +257,13 @@ asp_build *asp_build_create(uint64_t num_spins, uint64_t num_other) {
   bool ok = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&b->ev_start) == hipSuccess && hipEventCreate(&b->ev_stop) == hipSuccess;
   if (!ok) asp::set_error(ASP_ERR_HIP, "could not create HIP stream/events");
+  uint64_t slot_count = 64;
+  while (slot_count < 2 * K) slot_count <<= 1;  // load factor <= 1/2
+  b->slot_mask = slot_count - 1;
   const size_t scratch = asp::scan_scratch_elems(K > N ? K : N);
   ok = ok && b->table.alloc(K) == ASP_OK && b->needles.alloc(N) == ASP_OK &&
-       b->table0.alloc(K) == ASP_OK && b->counts.alloc(K) == ASP_OK &&
+       b->table0.alloc(K) == ASP_OK && b->slots.alloc(b->slot_mask + 1) == ASP_OK &&
+       b->tail_flag.alloc(1) == ASP_OK && b->counts.alloc(K) == ASP_OK &&
        b->other_counts.alloc(K) == ASP_OK && b->offsets.alloc(K + 1) == ASP_OK &&
        b->row_start.alloc(K + 1) == ASP_OK && b->scratch.alloc(scratch) == ASP_OK &&
        b->psi.alloc(K) == ASP_OK && b->coeffs.alloc(N) == ASP_OK &&
@@ -241,25 +325,26 @@ int asp_build_upload(asp_build *b, ls_bits512 const *spins, int64_t const *count
 int asp_build_run(asp_build *b, uint64_t *nnz) {
   if (!b) return asp::set_error(ASP_ERR_INVALID, "null build handle");
   if (!b->uploaded) return asp::set_error(ASP_ERR_INVALID, "asp_build_run before asp_build_upload");
-  const uint64_t K = b->num_spins, N = b->num_other;
+  const uint64_t K = b->num_spins;
   hipStream_t s = b->stream;
   ASP_HIP_TRY(hipEventRecord(b->ev_start, s));
+  ASP_HIP_TRY(hipMemsetAsync(b->slots.ptr, 0, (b->slot_mask + 1) * sizeof(unsigned long long), s));
+  ASP_HIP_TRY(hipMemsetAsync(b->tail_flag.ptr, 0, sizeof(uint32_t), s));
   if (K > 0) {
     hipLaunchKernelGGL(k_split_word0, dim3(blocks_for(K)), dim3(kThreads), 0, s, b->table.ptr, K,
-                       b->table0.ptr);
+                       b->table0.ptr, b->tail_flag.ptr);
+    hipLaunchKernelGGL(k_hash_insert, dim3(blocks_for(K)), dim3(kThreads), 0, s, b->table0.ptr, K,
+                       b->slots.ptr, b->slot_mask);
   }
   ASP_TRY(asp::exclusive_scan_i64(b->other_counts.ptr, K, b->offsets.ptr, b->scratch.ptr, s));
-  if (N > 0) {
-    hipLaunchKernelGGL(k_search, dim3(blocks_for(N)), dim3(kThreads), 0, s, b->table0.ptr,
-                       b->table.ptr, K, b->needles.ptr, N, b->found.ptr);
-  }
   if (K > 0) {
-    hipLaunchKernelGGL(k_row_hits, dim3(blocks_for(K)), dim3(kThreads), 0, s, b->offsets.ptr,
-                       b->found.ptr, K, b->row_hits.ptr);
+    hipLaunchKernelGGL(k_search_rows, dim3(row_blocks_for(K)), dim3(kThreads), 0, s, b->slots.ptr,
+                       b->slot_mask, b->table0.ptr, b->table.ptr, b->tail_flag.ptr, K,
+                       b->needles.ptr, b->offsets.ptr, b->found.ptr, b->row_hits.ptr);
   }
   ASP_TRY(asp::exclusive_scan_u32(b->row_hits.ptr, K, b->row_start.ptr, b->scratch.ptr, s));
   if (K > 0) {
-    hipLaunchKernelGGL(k_emit, dim3(blocks_for(K)), dim3(kThreads), 0, s, b->offsets.ptr,
+    hipLaunchKernelGGL(k_emit_rows, dim3(row_blocks_for(K)), dim3(kThreads), 0, s, b->offsets.ptr,
                        b->row_start.ptr, b->found.ptr, b->counts.ptr, b->psi.ptr, b->coeffs.ptr,
                        b->other_psi.ptr, K, b->out_row.ptr, b->out_col.ptr, b->elements.ptr,
                        b->field.ptr);

@@ -189,10 +189,15 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # Rehearsal knobs for a 1-GPU box (never set by the driver): all ranks on device 0 and a
+    # gloo process group, which exercises everything but RCCL itself.
+    backend = os.environ.get("ASP_BENCH_BACKEND", "nccl")
+    if os.environ.get("ASP_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        dist.init_process_group(backend)
 
     from annealing_sign_problem_amd import _lib, synthetic
     from annealing_sign_problem_amd import annealer as sa
@@ -246,7 +251,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
