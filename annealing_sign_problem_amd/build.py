@@ -16,9 +16,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
-LIB_NAME = "libasp_hip.so"
+# Development aid: ASP_LIB_TAG=x builds/loads libasp_hip_x.so with ASP_EXTRA_FLAGS appended
+# (same-box A/B timing of kernel variants); unset in normal use.
+_TAG = os.environ.get("ASP_LIB_TAG", "")
+EXTRA_FLAGS = os.environ.get("ASP_EXTRA_FLAGS", "").split() if _TAG else []
+LIB_NAME = "libasp_hip%s.so" % ("_" + _TAG if _TAG else "")
 LIB_PATH = os.path.join(HERE, LIB_NAME)
-STAMP_PATH = os.path.join(HERE, ".libasp_hip.stamp")
+STAMP_PATH = os.path.join(HERE, ".libasp_hip%s.stamp" % ("_" + _TAG if _TAG else ""))
 
 SOURCES = [
     "asp_common.hip",
@@ -46,7 +50,7 @@ def hipcc() -> str:
 
 def _fingerprint(sources: list[str]) -> str:
     h = hashlib.sha256()
-    h.update(" ".join(HIPCC_FLAGS).encode())
+    h.update(" ".join(HIPCC_FLAGS + EXTRA_FLAGS).encode())
     deps = list(sources)
     for d in (CSRC, INCLUDE):
         for name in sorted(os.listdir(d)):
@@ -64,6 +68,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     missing = [s for s in sources if not os.path.exists(s)]
     if missing:
         raise RuntimeError("missing sources: " + ", ".join(missing))
+    if _TAG and os.environ.get("ASP_NO_REBUILD") == "1" and os.path.exists(LIB_PATH):
+        return LIB_PATH  # A/B against a variant built from an OLDER source tree
     fp = _fingerprint(sources)
     if not force and os.path.exists(LIB_PATH) and os.path.exists(STAMP_PATH):
         with open(STAMP_PATH) as f:
@@ -73,7 +79,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if os.path.exists(LIB_PATH):
             return LIB_PATH
         raise RuntimeError("cannot build: %s is not writable" % HERE)
-    cmd = [hipcc(), *HIPCC_FLAGS, "-I", INCLUDE, "-I", CSRC, "-x", "hip", *sources, "-o", LIB_PATH]
+    cmd = [hipcc(), *HIPCC_FLAGS, *EXTRA_FLAGS, "-I", INCLUDE, "-I", CSRC, "-x", "hip", *sources, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, capture_output=True, text=True)

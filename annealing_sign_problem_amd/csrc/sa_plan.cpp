@@ -189,6 +189,12 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
   // + kEllTailSlabs of zeros: the sweep kernel's prefetch may read one quad past the end
   L.ell_col.assign((slabs + kEllTailSlabs) * 64, 0);
   L.ell_val.assign((slabs + kEllTailSlabs) * 64, 0.0);
+  // Quad-interleaved storage: entries k = 4Q .. 4Q+3 of a lane are adjacent, so the kernel
+  // fetches them with three 16-byte loads per lane (one uint4 of columns, two double2 of
+  // values), each wavefront instruction covering 1 KiB of contiguous memory.
+  //   ell_col[((Q * 64) + lane) * 4 + j]              column of k = 4Q + j
+  //   ell_val[(((Q * 2 + h) * 64) + lane) * 2 + j]    value  of k = 4Q + 2h + j
+  // with Q = ell_off[b] / 4 + q the global quad index (block widths are multiples of 4).
   for (uint32_t b = 0; b < L.num_blocks; ++b) {
     for (uint32_t l = 0; l < 64; ++l) {
       const uint32_t pos = b * 64u + l;
@@ -196,13 +202,16 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
       const int64_t begin = spin == kDummySpin ? 0 : L.a_ptr[spin];
       const int64_t deg = spin == kDummySpin ? 0 : degree(spin);
       for (uint32_t k = 0; k < L.block_width[b]; ++k) {
-        const uint64_t at = (L.ell_off[b] + k) * 64 + l;
+        const uint64_t quad = (L.ell_off[b] + k) / 4;
+        const uint32_t j = k % 4;
+        const uint64_t at_col = (quad * 64 + l) * 4 + j;
+        const uint64_t at_val = ((quad * 2 + j / 2) * 64 + l) * 2 + (j % 2);
         if (static_cast<int64_t>(k) < deg) {
-          L.ell_col[at] = L.pos_of_spin[L.a_col[begin + k]];
-          L.ell_val[at] = L.a_val[begin + k];
+          L.ell_col[at_col] = L.pos_of_spin[L.a_col[begin + k]];
+          L.ell_val[at_val] = L.a_val[begin + k];
         } else {
-          L.ell_col[at] = pos;  // padding: own position, +0.0
-          L.ell_val[at] = 0.0;
+          L.ell_col[at_col] = pos;  // padding: own position, +0.0
+          L.ell_val[at_val] = 0.0;
         }
       }
     }
@@ -226,9 +235,12 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
   }
   if (!std::isfinite(bound)) return set_error(ASP_ERR_INVALID, "couplings overflow double range");
   if (bound > 0.0) {
-    int e = 0;
-    (void)std::frexp(2.0 * bound, &e);  // 2B < 2^e
-    L.energy_scale_exp = std::clamp(60 - e, -1000, 1000);
+    // S: the whole tracked range 2B stays below 2^60 and a single |dE| <= max_delta stays
+    // below 2^50, so the kernel can round dE * 2^S to int64 with one f64 add (|x| < 2^51)
+    int e = 0, e_single = 0;
+    (void)std::frexp(2.0 * bound, &e);    // 2B < 2^e
+    (void)std::frexp(max_delta, &e_single);  // max_delta < 2^e_single
+    L.energy_scale_exp = std::clamp(std::min(60 - e, 50 - e_single), -1000, 1000);
   }
   if (max_delta > 0.0 && std::isfinite(min_delta)) {
     L.beta0_auto = std::log(2.0) / max_delta;

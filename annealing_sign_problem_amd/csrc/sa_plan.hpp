@@ -4,9 +4,10 @@
 //   A = offdiag(J + J^T) (exact zeros dropped)          -> dE_i = -2 s_i (sum_j A_ij s_j + h_i)
 //   greedy first-fit colouring of A's graph, index order -> same-colour spins are independent
 //   permutation by (colour, degree desc, index)          -> a colour class is a run of 64-row blocks
-//   sliced ELL: block b has width w_b (multiple of 4); entry (k, lane) of block b lives at
-//   (ell_off[b] + k) * 64 + lane, so a wavefront reads 256 B of columns and 512 B of values
-//   per k, fully coalesced.  Columns are padded POSITIONS (block * 64 + lane), i.e. direct
+//   sliced ELL: block b has width w_b (multiple of 4) and starts at slab ell_off[b]; entries
+//   are stored quad-interleaved (four consecutive k of a lane adjacent, see sa_plan.cpp) so a
+//   lane fetches a quad with three 16-byte loads and every wavefront load instruction covers
+//   1 KiB of contiguous memory.  Columns are padded POSITIONS (block * 64 + lane), i.e. direct
 //   indices into the LDS spin array.  Padding entries point at the lane's own position with
 //   value +0.0 (adding +-0 never changes a sum).
 #pragma once

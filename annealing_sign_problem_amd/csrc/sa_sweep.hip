@@ -28,6 +28,27 @@
 #include "asp_common.hpp"
 #include "sa_plan.hpp"
 
+// Experiment switches (tools/ab_sweep.sh builds tagged variants with -D...=0/1).
+#ifndef ASP_SERPENTINE
+#define ASP_SERPENTINE 0
+#endif
+#ifndef ASP_MAGIC_RINT
+#define ASP_MAGIC_RINT 1
+#endif
+// Timing-only ablations (results are WRONG when any is set; never set in the product build).
+#ifndef ASP_ABL_NO_ACCEPT
+#define ASP_ABL_NO_ACCEPT 0
+#endif
+#ifndef ASP_ABL_NO_KLOOP
+#define ASP_ABL_NO_KLOOP 0
+#endif
+#ifndef ASP_ABL_NO_BARRIER
+#define ASP_ABL_NO_BARRIER 0
+#endif
+#ifndef ASP_ABL_NO_LDS
+#define ASP_ABL_NO_LDS 0
+#endif
+
 namespace {
 
 using asp::DeviceBuffer;
@@ -138,32 +159,36 @@ __device__ __forceinline__ uint32_t gather_bit4(uint32_t d, int m) {
 // Sweep kernel
 // ---------------------------------------------------------------------------
 
-// Four consecutive ELL entries of one lane (one row), k .. k+3.
+// Four consecutive ELL entries of one lane (one row), k = 4q .. 4q+3.
 struct Quad {
-  uint32_t c[4];
-  double v[4];
+  uint4 c;
+  double2 v01, v23;
 };
 
-__device__ __forceinline__ void load_quad(Quad &q, const uint32_t *__restrict__ cptr,
-                                          const double *__restrict__ vptr, uint32_t k) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    q.c[j] = cptr[(k + j) * 64u];
-    q.v[j] = vptr[(k + j) * 64u];
-  }
+// Three 16-byte loads per lane; quad index `q` is relative to the block's first quad.
+__device__ __forceinline__ void load_quad(Quad &q, const uint4 *__restrict__ cptr,
+                                          const double2 *__restrict__ vptr, uint32_t quad) {
+  q.c = cptr[quad * 64u];
+  q.v01 = vptr[quad * 128u];
+  q.v23 = vptr[quad * 128u + 64u];
 }
 
 template <int M>
 __device__ __forceinline__ void accumulate_quad(const Quad &q, const uint8_t *spins,
                                                 double (&acc)[M]) {
   uint32_t s[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) s[j] = spins[q.c[j]];
+#if ASP_ABL_NO_LDS
+  s[0] = q.c.x & 15u; s[1] = q.c.y & 15u; s[2] = q.c.z & 15u; s[3] = q.c.w & 15u;
+#else
+  s[0] = spins[q.c.x]; s[1] = spins[q.c.y]; s[2] = spins[q.c.z]; s[3] = spins[q.c.w];
+#endif
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     double x = acc[m];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) x = __builtin_fma(q.v[j], spin_factor(s[j], m), x);
+    x = __builtin_fma(q.v01.x, spin_factor(s[0], m), x);
+    x = __builtin_fma(q.v01.y, spin_factor(s[1], m), x);
+    x = __builtin_fma(q.v23.x, spin_factor(s[2], m), x);
+    x = __builtin_fma(q.v23.y, spin_factor(s[3], m), x);
     acc[m] = x;
   }
 }
@@ -274,16 +299,29 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
     }
 
     for (uint32_t c = 0; c < a.num_colors; ++c) {
+      const uint32_t b_begin = a.color_block_start[c];
       const uint32_t b_end = a.color_block_start[c + 1];
-      for (uint32_t b = a.color_block_start[c] + wave; b < b_end; b += waves) {
+#if ASP_SERPENTINE
+      // Serpentine assignment: blocks of a colour are sorted by descending width, so a plain
+      // round-robin would always hand wave 0 the widest block of every round.  Any assignment
+      // gives the same bits (blocks of one colour are independent).
+      for (uint32_t round = 0;; ++round) {
+        const uint32_t slot = (round & 1u) ? (waves - 1u - wave) : wave;
+        const uint32_t b = b_begin + round * waves + slot;
+        if (round * waves >= b_end - b_begin) break;
+        if (b >= b_end) continue;
+#else
+      for (uint32_t b = b_begin + wave; b < b_end; b += waves) {
+#endif
         const uint32_t p = b * 64u + lane;
         const uint2 info = meta[b];  // {first slab, width}: one broadcast LDS read
         // wave-uniform by construction; readfirstlane makes the loop control scalar
         const uint32_t quads = __builtin_amdgcn_readfirstlane(info.y) >> 2;
-        const uint64_t base =
-            static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(info.x)) * 64u + lane;
-        const uint32_t *cptr = a.ell_col + base;
-        const double *vptr = a.ell_val + base;
+        // info.x = first slab of the block (a multiple of 4): quad index = slab / 4
+        const uint64_t first_quad = __builtin_amdgcn_readfirstlane(info.x) >> 2;
+        const uint4 *cptr = reinterpret_cast<const uint4 *>(a.ell_col) + first_quad * 64u + lane;
+        const double2 *vptr =
+            reinterpret_cast<const double2 *>(a.ell_val) + first_quad * 128u + lane;
         // issued now, consumed after the row sum: their latency hides under the k-loop
         const uint32_t spin = a.spin_of_pos[p];
         const double h = a.field_pos[p];
@@ -297,21 +335,28 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
         // reads one quad past the block — the next block's first slabs or the four slabs of
         // tail padding the plan appends — and is never consumed.
         Quad qa, qb;
+#if ASP_ABL_NO_KLOOP
+        const uint32_t quads_run = 0;
+        (void)quads;
+        qa = Quad{};
+#else
+        const uint32_t quads_run = quads;
         load_quad(qa, cptr, vptr, 0);
+#endif
         uint32_t i = 0;
-        for (; i + 2 <= quads; i += 2) {
+        for (; i + 2 <= quads_run; i += 2) {
           // sched_barrier: keep each load group AHEAD of the accumulate it overlaps with
           // (the machine scheduler otherwise sinks the second group below it)
-          load_quad(qb, cptr, vptr, 4 * (i + 1));
+          load_quad(qb, cptr, vptr, i + 1);
           __builtin_amdgcn_sched_barrier(0);
           accumulate_quad<M>(qa, spins, acc);
           __builtin_amdgcn_sched_barrier(0);
-          load_quad(qa, cptr, vptr, 4 * (i + 2));
+          load_quad(qa, cptr, vptr, i + 2);
           __builtin_amdgcn_sched_barrier(0);
           accumulate_quad<M>(qb, spins, acc);
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (i < quads) accumulate_quad<M>(qa, spins, acc);
+        if (i < quads_run) accumulate_quad<M>(qa, spins, acc);
         const bool valid = spin != kDummySpin;
         const uint32_t own = spins[p];
         uint32_t flip = 0;
@@ -329,16 +374,29 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
           const bool negative = (own >> m) & 1u;  // s = -1
           const double de = __dmul_rn(negative ? 2.0 : -2.0, g);
           const double u = __dmul_rn(__dadd_rn(static_cast<double>(word), 0.5), 0x1p-32);
+#if ASP_ABL_NO_ACCEPT
+          const bool accept = valid && de < -1e300 && u < 0.0;
+#else
           const bool accept = valid && (de <= 0.0 || u < expneg(__dmul_rn(beta, de)));
+#endif
           if (accept) {
             flip |= 1u << m;
+            // rint(dE * 2^S) as int64: |dE * 2^S| < 2^51 by the plan's choice of S, so adding
+            // 1.5 * 2^52 leaves the rounded integer in the mantissa (ties to even, = rint)
+#if ASP_MAGIC_RINT
+            q_acc[m] += __double_as_longlong(__dadd_rn(__dmul_rn(de, a.scale), 0x1.8p52)) -
+                        0x4338000000000000ll;
+#else
             q_acc[m] += static_cast<long long>(__builtin_rint(__dmul_rn(de, a.scale)));
+#endif
             n_acc[m] += 1;
           }
         }
         if (flip) spins[p] = static_cast<uint8_t>(own ^ flip);
       }
+#if !ASP_ABL_NO_BARRIER
       __syncthreads();
+#endif
     }
 
     // ---- exact (integer) reduction of the sweep's energy change ----
@@ -403,14 +461,22 @@ __global__ __launch_bounds__(512) void k_sa_energy_blocks(EnergyArgs a) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t waves = blockDim.x >> 6;
   for (uint32_t b = threadIdx.x >> 6; b < a.num_blocks; b += waves) {
-    const uint32_t width = a.block_width[b];
-    const uint64_t base = a.ell_off[b] * 64u + lane;
+    const uint32_t quads = a.block_width[b] >> 2;
+    const uint64_t first_quad = a.ell_off[b] >> 2;
+    const uint4 *cptr = reinterpret_cast<const uint4 *>(a.ell_col) + first_quad * 64u + lane;
+    const double2 *vptr = reinterpret_cast<const double2 *>(a.ell_val) + first_quad * 128u + lane;
     double acc = 0.0;
-    for (uint32_t k = 0; k < width; ++k) {
-      const uint32_t c = a.ell_col[base + static_cast<uint64_t>(k) * 64u];
-      const double v = a.ell_val[base + static_cast<uint64_t>(k) * 64u];
-      const uint32_t neg = static_cast<uint32_t>((bits[c >> 6] >> (c & 63u)) & 1ull);
-      acc = __dadd_rn(acc, signed_coupling(v, neg, 0));
+    for (uint32_t q = 0; q < quads; ++q) {
+      const uint4 c = cptr[q * 64u];
+      const double2 v01 = vptr[q * 128u];
+      const double2 v23 = vptr[q * 128u + 64u];
+      const uint32_t cs[4] = {c.x, c.y, c.z, c.w};
+      const double vs[4] = {v01.x, v01.y, v23.x, v23.y};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t neg = static_cast<uint32_t>((bits[cs[j] >> 6] >> (cs[j] & 63u)) & 1ull);
+        acc = __dadd_rn(acc, signed_coupling(vs[j], neg, 0));
+      }
     }
     const double g = __dadd_rn(__dmul_rn(0.5, acc), a.field_pos[b * 64u + lane]);
     const bool negative = (bits[b] >> lane) & 1ull;
