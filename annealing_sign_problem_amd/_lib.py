@@ -73,6 +73,8 @@ SIGNATURES = {
     "asp_sa_set_launch": (c_int, [c_void_p, c_int, c_int]),
     "asp_sa_anneal": (c_int, [c_void_p, c_u64, c_void_p, c_u32, c_u32, c_u32, c_void_p, c_void_p,
                               c_void_p]),
+    "asp_sa_greedy": (c_int, [c_void_p, c_u32, c_void_p, c_void_p, ctypes.POINTER(c_u32)]),
+    "asp_sa_greedy_tree_host": (c_int, [c_u64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "asp_sa_last_sweep_ms": (c_float, [c_void_p]),
     "asp_sa_last_total_ms": (c_float, [c_void_p]),
     "asp_sa_last_stats": (c_int, [c_void_p, c_u32, c_void_p, c_void_p]),

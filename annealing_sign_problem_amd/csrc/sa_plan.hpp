@@ -21,7 +21,7 @@ namespace asp {
 
 constexpr uint32_t kDummySpin = 0xFFFFFFFFu;  // spin_of_pos of a padding lane
 constexpr int kWidthAlign = 4;                // block widths are rounded up to this
-constexpr int kEllTailSlabs = 4;              // zero slabs after the last block (prefetch over-read)
+constexpr int kEllTailSlabs = 8;              // zero slabs after the last block (prefetch over-read)
 
 struct SaHostLayout {
   uint64_t num_spins = 0;
@@ -50,5 +50,9 @@ struct SaHostLayout {
 // Returns ASP_OK or records an error (non-canonical CSR, index out of range ...).
 int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *indices,
                     const double *data, const double *field, SaHostLayout *out);
+
+// Greedy sign assignment before relaxation (specification DESIGN.md §4.8): packed
+// configuration (bit = +1), ceil(K/64) words.
+int greedy_tree_signs(const SaHostLayout &layout, uint64_t *x);
 
 }  // namespace asp

@@ -35,6 +35,9 @@
 #ifndef ASP_MAGIC_RINT
 #define ASP_MAGIC_RINT 1
 #endif
+#ifndef ASP_PREFETCH_DEPTH
+#define ASP_PREFETCH_DEPTH 2
+#endif
 // Timing-only ablations (results are WRONG when any is set; never set in the product build).
 #ifndef ASP_ABL_NO_ACCEPT
 #define ASP_ABL_NO_ACCEPT 0
@@ -47,6 +50,12 @@
 #endif
 #ifndef ASP_ABL_NO_LDS
 #define ASP_ABL_NO_LDS 0
+#endif
+#ifndef ASP_ABL_NO_GLOAD
+#define ASP_ABL_NO_GLOAD 0
+#endif
+#ifndef ASP_ABL_NO_FMA
+#define ASP_ABL_NO_FMA 0
 #endif
 
 namespace {
@@ -168,9 +177,16 @@ struct Quad {
 // Three 16-byte loads per lane; quad index `q` is relative to the block's first quad.
 __device__ __forceinline__ void load_quad(Quad &q, const uint4 *__restrict__ cptr,
                                           const double2 *__restrict__ vptr, uint32_t quad) {
+#if ASP_ABL_NO_GLOAD
+  const uint32_t l = (threadIdx.x * 37u + quad * 101u) & 0x3FFFu;
+  q.c = make_uint4(l, l + 1u, l + 2u, l + 3u);
+  q.v01 = make_double2(1.0 + quad, 2.0);
+  q.v23 = make_double2(3.0, 4.0 + quad);
+#else
   q.c = cptr[quad * 64u];
   q.v01 = vptr[quad * 128u];
   q.v23 = vptr[quad * 128u + 64u];
+#endif
 }
 
 template <int M>
@@ -181,6 +197,11 @@ __device__ __forceinline__ void accumulate_quad(const Quad &q, const uint8_t *sp
   s[0] = q.c.x & 15u; s[1] = q.c.y & 15u; s[2] = q.c.z & 15u; s[3] = q.c.w & 15u;
 #else
   s[0] = spins[q.c.x]; s[1] = spins[q.c.y]; s[2] = spins[q.c.z]; s[3] = spins[q.c.w];
+#endif
+#if ASP_ABL_NO_FMA
+  asm volatile("" ::"v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(q.v01.x), "v"(q.v01.y),
+               "v"(q.v23.x), "v"(q.v23.y));
+  return;
 #endif
 #pragma unroll
   for (int m = 0; m < M; ++m) {
@@ -234,7 +255,9 @@ __device__ __forceinline__ void snapshot(const uint8_t *spins, const SweepArgs &
   }
 }
 
-template <int M>
+// DESCENT = true: strict-descent sweeps (accept iff dE < 0, no random numbers), used by the
+// greedy solver's relaxation; the final configuration is snapshotted after every sweep.
+template <int M, bool DESCENT>
 __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
   extern __shared__ __align__(16) uint8_t lds[];
   uint8_t *spins = lds;
@@ -334,29 +357,55 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
         // queue with vmcnt(0) at the loop header): for an even quad count the last load
         // reads one quad past the block — the next block's first slabs or the four slabs of
         // tail padding the plan appends — and is never consumed.
-        Quad qa, qb;
 #if ASP_ABL_NO_KLOOP
         const uint32_t quads_run = 0;
         (void)quads;
-        qa = Quad{};
+        (void)cptr;
+        (void)vptr;
 #else
         const uint32_t quads_run = quads;
-        load_quad(qa, cptr, vptr, 0);
 #endif
-        uint32_t i = 0;
-        for (; i + 2 <= quads_run; i += 2) {
-          // sched_barrier: keep each load group AHEAD of the accumulate it overlaps with
-          // (the machine scheduler otherwise sinks the second group below it)
-          load_quad(qb, cptr, vptr, i + 1);
-          __builtin_amdgcn_sched_barrier(0);
-          accumulate_quad<M>(qa, spins, acc);
-          __builtin_amdgcn_sched_barrier(0);
-          load_quad(qa, cptr, vptr, i + 2);
-          __builtin_amdgcn_sched_barrier(0);
-          accumulate_quad<M>(qb, spins, acc);
-          __builtin_amdgcn_sched_barrier(0);
+        if constexpr (M <= 4 && ASP_PREFETCH_DEPTH == 2) {
+          // Prefetch distance two: three register buffers rotate, so a quad's loads have two
+          // accumulate phases (of this wave, plus whatever the other waves of the SIMD issue)
+          // to land.  Up to two quads past the block are read and never consumed.
+          Quad q0, q1, q2;
+          load_quad(q0, cptr, vptr, 0);
+          load_quad(q1, cptr, vptr, 1);
+          uint32_t i = 0;
+          for (; i + 3 <= quads_run; i += 3) {
+            load_quad(q2, cptr, vptr, i + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate_quad<M>(q0, spins, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            load_quad(q0, cptr, vptr, i + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate_quad<M>(q1, spins, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            load_quad(q1, cptr, vptr, i + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate_quad<M>(q2, spins, acc);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (i < quads_run) accumulate_quad<M>(q0, spins, acc);
+          if (i + 1 < quads_run) accumulate_quad<M>(q1, spins, acc);
+        } else {
+          // M = 8 has no registers to spare: prefetch distance one (two buffers)
+          Quad qa, qb;
+          load_quad(qa, cptr, vptr, 0);
+          uint32_t i = 0;
+          for (; i + 2 <= quads_run; i += 2) {
+            load_quad(qb, cptr, vptr, i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate_quad<M>(qa, spins, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            load_quad(qa, cptr, vptr, i + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate_quad<M>(qb, spins, acc);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (i < quads_run) accumulate_quad<M>(qa, spins, acc);
         }
-        if (i < quads_run) accumulate_quad<M>(qa, spins, acc);
         const bool valid = spin != kDummySpin;
         const uint32_t own = spins[p];
         uint32_t flip = 0;
@@ -364,21 +413,27 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
         uint32_t have = 0xFFFFFFFFu;
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-          const uint32_t r = r0 + m;
-          if (m == 0 || (r >> 2) != have) {
-            have = r >> 2;
-            rnd = philox4x32_10(spin, t, have, 0u, key0, key1);
-          }
-          const uint32_t word = pick_word(rnd, r & 3u);
           const double g = __dadd_rn(acc[m], h);
           const bool negative = (own >> m) & 1u;  // s = -1
           const double de = __dmul_rn(negative ? 2.0 : -2.0, g);
-          const double u = __dmul_rn(__dadd_rn(static_cast<double>(word), 0.5), 0x1p-32);
+          bool accept;
+          if constexpr (DESCENT) {
+            accept = valid && de < 0.0;
+          } else {
+            const uint32_t r = r0 + m;
+            if (m == 0 || (r >> 2) != have) {
+              have = r >> 2;
+              rnd = philox4x32_10(spin, t, have, 0u, key0, key1);
+            }
+            const uint32_t word = pick_word(rnd, r & 3u);
+            const double u = __dmul_rn(__dadd_rn(static_cast<double>(word), 0.5), 0x1p-32);
 #if ASP_ABL_NO_ACCEPT
-          const bool accept = valid && de < -1e300 && u < 0.0;
+            asm volatile("" ::"v"(de), "v"(u));
+            accept = false;
 #else
-          const bool accept = valid && (de <= 0.0 || u < expneg(__dmul_rn(beta, de)));
+            accept = valid && (de <= 0.0 || u < expneg(__dmul_rn(beta, de)));
 #endif
+          }
           if (accept) {
             flip |= 1u << m;
             // rint(dE * 2^S) as int64: |dE * 2^S| < 2^51 by the plan's choice of S, so adding
@@ -422,7 +477,7 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
       }
     }
     __syncthreads();
-    const uint32_t improved = *improved_flag;
+    const uint32_t improved = DESCENT ? ((1u << M) - 1u) : *improved_flag;
     if (improved) snapshot<M>(spins, a, group, improved);
     __syncthreads();
     if (tid == 0) *improved_flag = 0;  // next write to it is two barriers away
@@ -579,12 +634,12 @@ int upload_vector(DeviceBuffer<T> &dst, const std::vector<T> &src, hipStream_t s
 
 using SweepKernel = void (*)(SweepArgs);
 
-SweepKernel sweep_kernel_for(int m) {
+SweepKernel sweep_kernel_for(int m, bool descent = false) {
   switch (m) {
-    case 1: return k_sa_sweep<1>;
-    case 2: return k_sa_sweep<2>;
-    case 4: return k_sa_sweep<4>;
-    case 8: return k_sa_sweep<8>;
+    case 1: return descent ? k_sa_sweep<1, true> : k_sa_sweep<1, false>;
+    case 2: return k_sa_sweep<2, false>;
+    case 4: return k_sa_sweep<4, false>;
+    case 8: return k_sa_sweep<8, false>;
     default: return nullptr;
   }
 }
@@ -729,10 +784,14 @@ int asp_sa_set_launch(asp_sa_plan *p, int replicas_per_group, int threads) {
   return ASP_OK;
 }
 
-int asp_sa_anneal(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_sweeps,
-                  uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0,
-                  uint64_t *out_x, double *out_e) {
-  asp_clear_error();
+}  // extern "C"
+
+namespace {
+
+// All chains of one call; descent = strict-descent sweeps (greedy relaxation).
+int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_sweeps,
+               uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0, bool descent,
+               uint64_t *out_x, double *out_e) {
   if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
   if (repetitions == 0) return ASP_OK;
   if (!out_x || !out_e || (num_sweeps && !betas)) {
@@ -757,6 +816,7 @@ int asp_sa_anneal(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t n
   }
   int m = 1, threads = 64;
   choose_launch(p, repetitions, &m, &threads);
+  if (descent) m = 1;
   const size_t lds = sweep_lds_bytes(L);
   if (lds > p->max_lds) {
     return asp::set_error(ASP_ERR_TOO_LARGE,
@@ -808,7 +868,7 @@ int asp_sa_anneal(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t n
   args.num_sweeps = num_sweeps;
   args.replica_first = replica_offset;
 
-  SweepKernel kernel = sweep_kernel_for(m);
+  SweepKernel kernel = sweep_kernel_for(m, descent);
   if (lds > 64 * 1024) {
     ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -843,6 +903,56 @@ int asp_sa_anneal(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t n
   p->last_groups = static_cast<int>(groups);
   ASP_HIP_TRY(hipEventElapsedTime(&p->last_sweep_ms, p->ev[1], p->ev[2]));
   ASP_HIP_TRY(hipEventElapsedTime(&p->last_total_ms, p->ev[0], p->ev[3]));
+  return ASP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int asp_sa_anneal(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_sweeps,
+                  uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0,
+                  uint64_t *out_x, double *out_e) {
+  asp_clear_error();
+  return run_chains(p, seed, betas, num_sweeps, repetitions, replica_offset, x0, false, out_x,
+                    out_e);
+}
+
+int asp_sa_greedy(asp_sa_plan *p, uint32_t max_sweeps, uint64_t *out_x, double *out_e,
+                  uint32_t *out_sweeps) {
+  asp_clear_error();
+  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  if (!out_x || !out_e) return asp::set_error(ASP_ERR_INVALID, "null argument");
+  const asp::SaHostLayout &L = p->host;
+  const uint64_t K = L.num_spins;
+  const uint32_t words = static_cast<uint32_t>((K + 63) / 64);
+  if (out_sweeps) *out_sweeps = 0;
+  if (K == 0) {
+    *out_e = 0.0;
+    return ASP_OK;
+  }
+  // 1. strongest-coupling-first cluster merging on the host (O(E log E))
+  std::vector<uint64_t> x(words, 0);
+  ASP_TRY(asp::greedy_tree_signs(L, x.data()));
+  // 2. strict-descent relaxation on the device, in chunks, until a chunk flips nothing
+  constexpr uint32_t kChunk = 8;
+  std::vector<double> zeros(kChunk, 0.0);
+  std::vector<uint64_t> next(words, 0);
+  uint32_t done = 0;
+  double energy = 0.0;
+  if (max_sweeps == 0) {
+    ASP_TRY(asp_sa_energy(p, 1, x.data(), &energy));
+  }
+  while (done < max_sweeps) {
+    const uint32_t chunk = std::min(kChunk, max_sweeps - done);
+    ASP_TRY(run_chains(p, 0, zeros.data(), chunk, 1, 0, x.data(), true, next.data(), &energy));
+    done += chunk;
+    x.swap(next);
+    if (p->last_accepted.empty() || p->last_accepted[0] == 0) break;
+  }
+  std::copy(x.begin(), x.end(), out_x);
+  *out_e = energy;
+  if (out_sweeps) *out_sweeps = done;
   return ASP_OK;
 }
 

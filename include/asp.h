@@ -182,6 +182,19 @@ int asp_sa_set_launch(asp_sa_plan *p, int replicas_per_group, int threads);
 int asp_sa_anneal(asp_sa_plan *p, uint64_t seed, double const *betas,
                   uint32_t num_sweeps, uint32_t repetitions, uint32_t replica_offset,
                   uint64_t const *x0, uint64_t *out_x, double *out_e);
+/* Replaces ising_glass_annealer.greedy_solve (call site common.py:250; the only in-tree
+ * description is the commented prototype at common.py:298-438): couplings are visited
+ * strongest first and clusters of already-signed spins are merged so that the visited
+ * coupling is satisfied (host, union-find with parity); then strict-descent sweeps
+ * (flip iff dE < 0, the sweep kernel without random numbers) run on the device until no
+ * spin flips or max_sweeps is reached.  Deterministic.  out_x: ceil(K/64) words. */
+int asp_sa_greedy(asp_sa_plan *p, uint32_t max_sweeps, uint64_t *out_x, double *out_e,
+                  uint32_t *out_sweeps);
+
+/* Host-only: the cluster-merging half of asp_sa_greedy (no relaxation, no device). */
+int asp_sa_greedy_tree_host(uint64_t num_spins, int64_t const *indptr, int32_t const *indices,
+                            double const *data, double const *field, uint64_t *out_x);
+
 /* Device time (ms, HIP events on the launch stream) of the sweep kernel of the
  * last asp_sa_anneal call, and of everything device-side in that call. */
 float asp_sa_last_sweep_ms(asp_sa_plan const *p);

@@ -212,3 +212,18 @@ def sa_layout(matrix):
     if rc != 0:
         raise RuntimeError("oracle_sa_layout failed")
     return colors[:n], order[:n], ncol.value, nnz.value, diag.value
+
+
+def greedy_solve(matrix, field, max_sweeps: int = 10000, relax: bool = True):
+    """ASP-GREEDY-1 on the CPU: (x uint64[words], e float)."""
+    n, indptr, indices, data = _csr_args(matrix)
+    field = np.ascontiguousarray(field, dtype=np.float64)
+    words = (n + 63) // 64
+    x = np.zeros(max(words, 1), dtype=np.uint64)
+    e = ctypes.c_double(0.0)
+    rc = lib().oracle_greedy_solve(_u64(n), _ptr(indptr), _ptr(indices), _ptr(data), _ptr(field),
+                                   _u32(max_sweeps), ctypes.c_int(1 if relax else 0), _ptr(x),
+                                   ctypes.byref(e))
+    if rc != 0:
+        raise RuntimeError("oracle_greedy_solve failed")
+    return x[:words], e.value

@@ -23,7 +23,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 REFERENCE_CBITS = "/root/reference/cbits"
 
-ORACLE_SOURCES = ["build_matrix_oracle.c", "sa_oracle.c"]
+ORACLE_SOURCES = ["build_matrix_oracle.c", "sa_oracle.c", "greedy_oracle.c"]
 ORACLE_LIB = os.path.join(HERE, "liboracle.so")
 REF_DIR = os.path.join(HERE, "_ref")
 REF_LIB = os.path.join(REF_DIR, "libbuild_matrix_ref.so")

@@ -181,3 +181,38 @@ def test_full_size_properties_kagome36_sized():
     assert len({x.tobytes() for x in xs}) == 64
     xs_short, es_short = sa.anneal_raw(ham, 42, betas[:2], 64)
     assert es.mean() < es_short.mean()
+
+
+def test_greedy_solve_matches_oracle_and_improves():
+    """sa.greedy_solve (common.py:250): host cluster merging + device strict-descent
+    relaxation vs the oracle, bit for bit; and the drop-in call through solve_ising_model."""
+    from annealing_sign_problem_amd import annealer as sa, common, synthetic
+
+    rng = np.random.default_rng(4)
+    cases = []
+    for n, seed in [(1, 1), (700, 2), (6000, 3)]:
+        J, h, _ = _planted(n, seed, mean_degree=min(14.0, max(n / 2, 1.0)))
+        cases.append((J, h))
+    J, h, _ = _planted(2500, 5)
+    cases.append((J, rng.normal(size=2500) * 1e-3))
+    Jsk, hsk = synthetic.sk_cluster(500, degree=100, seed=6)
+    cases.append((Jsk, hsk))
+    for J, h in cases:
+        ham = sa.Hamiltonian(J, h)
+        x, e = sa.greedy_solve(ham)
+        ox, oe = oracle.greedy_solve(J, h)
+        assert np.array_equal(x, ox) and e == oe
+        x_tree, e_tree = oracle.greedy_solve(J, h, relax=False)
+        assert e <= e_tree
+        n = J.shape[0]
+        s = sa.bits_to_signs(x, n)
+        ref = s @ (J @ s) + h @ s
+        assert abs(e - ref) <= 1e-12 * max(abs(ref), 1e-300)
+        # local minimum: no single flip lowers the energy
+        A = (J + J.T).tocsr()
+        A.setdiag(0)
+        de = -2.0 * s * (A @ s + h)
+        assert np.all(de >= -1e-12 * np.abs(de).max())
+    model = common.IsingModel(np.arange(J.shape[0], dtype=np.uint64), None, sa.Hamiltonian(J, h), None)
+    xg = common.solve_ising_model(model, mode="greedy")
+    assert np.array_equal(xg, oracle.greedy_solve(J, h)[0])

@@ -184,3 +184,42 @@ def test_shard_range_covers_everything():
             assert sum(c for _, c in parts) == total
             assert all(parts[k][0] + parts[k][1] == parts[k + 1][0] for k in range(world - 1))
             assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+def test_greedy_cluster_merging_matches_oracle():
+    """Host half of asp_sa_greedy (csrc/greedy.cpp) vs the oracle's restatement, incl. fields,
+    isolated spins and a non-symmetric J."""
+    from annealing_sign_problem_amd import _lib, synthetic
+
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    cases = []
+    for n, seed in [(2, 1), (300, 2), (4000, 3)]:
+        J, h, _ = synthetic.planted_cluster(n, seed=seed, mean_degree=min(12.0, n / 2))
+        cases.append((J, h))
+        cases.append((J, rng.normal(size=n) * 0.01))
+    m = scipy.sparse.random(500, 500, density=0.004, random_state=5, format="csr")
+    m.data = rng.normal(size=m.data.shape)
+    cases.append((m, rng.normal(size=500)))           # non-symmetric, isolated spins, field
+    cases.append((scipy.sparse.csr_matrix((70, 70)), rng.normal(size=70)))  # field only
+    for J, h in cases:
+        J = scipy.sparse.csr_matrix(J)
+        J.sum_duplicates()
+        J.sort_indices()
+        n = J.shape[0]
+        x = np.zeros((n + 63) // 64, np.uint64)
+        _lib.check(lib.asp_sa_greedy_tree_host(n, _lib.ptr(J.indptr.astype(np.int64)),
+                                               _lib.ptr(J.indices.astype(np.int32)),
+                                               _lib.ptr(J.data.astype(np.float64)), _lib.ptr(h),
+                                               _lib.ptr(x)))
+        ox, _ = oracle.greedy_solve(J, h, relax=False)
+        assert np.array_equal(x, ox)
+
+
+def test_greedy_solves_unfrustrated_instance_exactly():
+    from annealing_sign_problem_amd import synthetic
+
+    J, h, planted = synthetic.planted_cluster(3000, seed=16, frustrated_fraction=0.0,
+                                              diagonal_range=0)
+    x, e = oracle.greedy_solve(J, h)
+    assert abs(e - planted @ (J @ planted)) <= 1e-12 * abs(e)
