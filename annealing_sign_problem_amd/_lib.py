@@ -65,6 +65,7 @@ SIGNATURES = {
     "asp_build_download": (c_int, [c_void_p] * 5),
     "asp_build_destroy": (None, [c_void_p]),
     "asp_ising_elements": (c_int, [c_u64, c_void_p, c_void_p, c_u64] + [c_void_p] * 7),
+    "asp_ising_elements_last_ms": (c_float, []),
     "asp_sa_plan_create": (c_void_p, [c_u64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "asp_sa_plan_destroy": (None, [c_void_p]),
     "asp_sa_plan_info": (c_int, [c_void_p, ctypes.POINTER(SaInfo)]),

@@ -2,6 +2,8 @@
 // coupling-build kernels.  gfx950 only.
 #include "asp_common.hpp"
 
+#include <atomic>
+
 namespace asp {
 
 ErrorState &error_state() {
@@ -19,6 +21,18 @@ int set_error(int code, const char *fmt, ...) {
   return code;
 }
 
+namespace {
+std::atomic<int> g_device{-1};  // process-wide choice of asp_set_device; -1 = HIP's default
+}
+
+void remember_device(int device) { g_device.store(device); }
+
+int bind_device() {
+  const int device = g_device.load();
+  if (device >= 0) ASP_HIP_TRY(hipSetDevice(device));
+  return ASP_OK;
+}
+
 int require_device() {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -27,7 +41,7 @@ int require_device() {
                      "no HIP device available (%s); libasp_hip has no CPU fallback",
                      e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
   }
-  return ASP_OK;
+  return bind_device();
 }
 
 // ---------------------------------------------------------------------------
@@ -193,6 +207,7 @@ int asp_device_count(void) {
 int asp_set_device(int device) {
   ASP_TRY(asp::require_device());
   ASP_HIP_TRY(hipSetDevice(device));
+  asp::remember_device(device);
   return ASP_OK;
 }
 

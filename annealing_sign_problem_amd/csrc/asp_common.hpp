@@ -40,8 +40,12 @@ int set_error(int code, const char *fmt, ...);
     if (asp_rc_ != ASP_OK) return asp_rc_; \
   } while (0)
 
-// Fails (recording ASP_ERR_NO_DEVICE) unless a gfx950-class device is usable.
+// Fails (recording ASP_ERR_NO_DEVICE) unless a device is usable; binds the calling thread
+// to the device chosen with asp_set_device (HIP's current device is per thread).
 int require_device();
+// Only the binding (for entry points that receive an existing handle).
+int bind_device();
+void remember_device(int device);
 
 // ---- owning device buffer --------------------------------------------------
 template <typename T>
@@ -69,6 +73,12 @@ struct DeviceBuffer {
     }
     count = n;
     return ASP_OK;
+  }
+  // Grow-only: keep the allocation when it already holds n elements (no hipFree, which
+  // synchronises the whole device, on the hot path of repeated calls).
+  int ensure(size_t n) {
+    if (ptr != nullptr && count >= n) return ASP_OK;
+    return alloc(n);
   }
   int upload(const T *host, size_t n, hipStream_t stream) {
     if (n == 0) return ASP_OK;

@@ -72,24 +72,17 @@ __global__ __launch_bounds__(kThreads) void k_hash_insert(const uint64_t *__rest
   while (atomicCAS(&slots[at], 0ull, entry) != 0ull) at = (at + 1) & mask;
 }
 
-// Words 1..7 equal?  (word 0 already known equal)
-__device__ __forceinline__ bool tails_equal(const ls_bits512 *__restrict__ a,
-                                            const ls_bits512 *__restrict__ b) {
-  uint64_t diff = 0;
-#pragma unroll
-  for (int w = 1; w < 8; ++w) diff |= a->words[w] ^ b->words[w];
-  return diff == 0;
-}
-
-// Index of *needle in the table, or -1.
+// Index of the needle (its eight words in registers) in the table, or -1.
 __device__ __forceinline__ int32_t find_key(const unsigned long long *__restrict__ slots,
                                             uint64_t mask, const uint64_t *__restrict__ table0,
                                             const ls_bits512 *__restrict__ table,
-                                            bool table_has_tails,
-                                            const ls_bits512 *__restrict__ needle) {
-  const uint64_t n0 = needle->words[0];
+                                            bool table_has_tails, const uint64_t (&needle)[8]) {
+  const uint64_t n0 = needle[0];
   const uint64_t h = mix64(n0);
   const uint32_t fingerprint = static_cast<uint32_t>(h >> 32);
+  uint64_t needle_tail = 0;
+#pragma unroll
+  for (int w = 1; w < 8; ++w) needle_tail |= needle[w];
   for (uint64_t at = h & mask;; at = (at + 1) & mask) {
     const unsigned long long slot = slots[at];
     if (slot == 0) return -1;
@@ -99,12 +92,12 @@ __device__ __forceinline__ int32_t find_key(const unsigned long long *__restrict
     // word 0 matches: the full 512-bit keys must agree (cbits/build_matrix.c:11-18)
     bool same;
     if (table_has_tails) {
-      same = tails_equal(&table[idx], needle);
-    } else {
-      uint64_t tail = 0;
+      uint64_t diff = 0;
 #pragma unroll
-      for (int w = 1; w < 8; ++w) tail |= needle->words[w];
-      same = tail == 0;
+      for (int w = 1; w < 8; ++w) diff |= table[idx].words[w] ^ needle[w];
+      same = diff == 0;
+    } else {
+      same = needle_tail == 0;
     }
     if (same) return static_cast<int32_t>(idx);
   }
@@ -130,19 +123,42 @@ __global__ __launch_bounds__(kThreads) void k_search_rows(
   const int64_t end = row_ok ? offsets[r + 1] : 0;
   const bool has_tails = *tail_flag != 0;
   uint32_t hits = 0;
+  // The 32 needles a half-wavefront resolves per trip are 2 KiB of CONTIGUOUS memory (AoS
+  // keys of one row).  Each lane fetches four 16-byte chunks of that run (fully coalesced,
+  // 512 contiguous bytes per half and instruction) into LDS and then reads its own key
+  // back transposed, instead of eight loads per lane at a 64-byte stride.
+  __shared__ uint4 stage[kThreads * 4];
+  uint4 *mine = stage + (threadIdx.x / kRowLanes) * (kRowLanes * 4);
   // both halves of the wavefront iterate until the longer row is done, so the ballot is
   // always executed by all 64 lanes
   const int64_t other_len = __shfl_xor(end - begin, 32, 64);
   const int64_t trips = ((end - begin > other_len ? end - begin : other_len) + kRowLanes - 1) / kRowLanes;
   for (int64_t it = 0; it < trips; ++it) {
-    const int64_t e = begin + it * kRowLanes + sub;
+    const int64_t run = begin + it * kRowLanes;
+    const int64_t valid = end - run;  // needles of this trip that exist (may be <= 0)
+    const uint4 *src = reinterpret_cast<const uint4 *>(needles + run);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t chunk = i * kRowLanes + sub;  // 4 chunks per key
+      if (static_cast<int64_t>(chunk >> 2) < valid) mine[chunk] = src[chunk];
+    }
+    __builtin_amdgcn_wave_barrier();  // same wavefront: LDS ops are in order, keep them so
+    const int64_t e = run + sub;
     const bool active = e < end;
     int32_t idx = -1;
     if (active) {
-      idx = find_key(slots, mask, table0, table, has_tails, &needles[e]);
+      uint64_t key[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint4 q = mine[sub * 4 + j];
+        key[2 * j] = (static_cast<uint64_t>(q.y) << 32) | q.x;
+        key[2 * j + 1] = (static_cast<uint64_t>(q.w) << 32) | q.z;
+      }
+      idx = find_key(slots, mask, table0, table, has_tails, key);
       found[e] = idx;
     }
     hits += __popc(half_ballot(idx >= 0, lane));
+    __builtin_amdgcn_wave_barrier();  // the next trip overwrites the staging area
   }
   if (row_ok && sub == 0) row_hits[r] = hits;
 }
@@ -291,6 +307,7 @@ int asp_build_upload(asp_build *b, ls_bits512 const *spins, int64_t const *count
                      double const *other_coeffs, int64_t const *other_counts,
                      double const *other_psi) {
   if (!b) return asp::set_error(ASP_ERR_INVALID, "null build handle");
+  ASP_TRY(asp::bind_device());
   const uint64_t K = b->num_spins, N = b->num_other;
   if ((K && (!spins || !counts || !psi || !other_counts)) ||
       (N && (!other_spins || !other_coeffs || !other_psi))) {
@@ -325,6 +342,7 @@ int asp_build_upload(asp_build *b, ls_bits512 const *spins, int64_t const *count
 int asp_build_run(asp_build *b, uint64_t *nnz) {
   if (!b) return asp::set_error(ASP_ERR_INVALID, "null build handle");
   if (!b->uploaded) return asp::set_error(ASP_ERR_INVALID, "asp_build_run before asp_build_upload");
+  ASP_TRY(asp::bind_device());
   const uint64_t K = b->num_spins;
   hipStream_t s = b->stream;
   ASP_HIP_TRY(hipEventRecord(b->ev_start, s));
@@ -365,6 +383,7 @@ float asp_build_last_ms(asp_build const *b) { return b ? b->last_ms : 0.0f; }
 int asp_build_download(asp_build *b, uint32_t *row_indices, uint32_t *col_indices,
                        double *elements, double *field) {
   if (!b) return asp::set_error(ASP_ERR_INVALID, "null build handle");
+  ASP_TRY(asp::bind_device());
   const uint64_t n = b->last_nnz;
   if (row_indices) ASP_TRY(b->out_row.download(row_indices, n, b->stream));
   if (col_indices) ASP_TRY(b->out_col.download(col_indices, n, b->stream));

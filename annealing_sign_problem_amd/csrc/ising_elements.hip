@@ -68,7 +68,11 @@ __global__ __launch_bounds__(kThreads) void k_ising_elements(
   out_elements[e] = value;
 }
 
+thread_local float g_last_ms = 0.0f;
+
 }  // namespace
+
+extern "C" float asp_ising_elements_last_ms(void) { return g_last_ms; }
 
 extern "C" int asp_ising_elements(uint64_t num_spins, uint64_t const *keys, double const *psi,
                                   uint64_t num_other, uint64_t const *other_keys,
@@ -114,6 +118,10 @@ extern "C" int asp_ising_elements(uint64_t num_spins, uint64_t const *keys, doub
   ASP_TRY(d_psi.upload(psi, K, stream));
   ASP_TRY(d_coeffs.upload(other_coeffs, N, stream));
   ASP_TRY(d_counts.upload(other_counts, K, stream));
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  ASP_HIP_TRY(hipEventCreate(&ev0));
+  ASP_HIP_TRY(hipEventCreate(&ev1));
+  ASP_HIP_TRY(hipEventRecord(ev0, stream));
   ASP_TRY(asp::exclusive_scan_i64(d_counts.ptr, K, d_offsets.ptr, d_scratch.ptr, stream));
   if (N > 0) {
     const unsigned blocks = static_cast<unsigned>((N + kThreads - 1) / kThreads);
@@ -122,10 +130,14 @@ extern "C" int asp_ising_elements(uint64_t num_spins, uint64_t const *keys, doub
                        d_member.ptr, d_elements.ptr);
     ASP_HIP_TRY(hipGetLastError());
   }
+  ASP_HIP_TRY(hipEventRecord(ev1, stream));
   if (other_indices) ASP_TRY(d_index.download(other_indices, N, stream));
   if (member) ASP_TRY(d_member.download(member, N, stream));
   if (elements) ASP_TRY(d_elements.download(elements, N, stream));
   if (offsets) ASP_TRY(d_offsets.download(offsets, K + 1, stream));
   ASP_HIP_TRY(hipStreamSynchronize(stream));
+  (void)hipEventElapsedTime(&g_last_ms, ev0, ev1);
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
   return ASP_OK;
 }

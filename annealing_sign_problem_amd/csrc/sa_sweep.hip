@@ -622,6 +622,11 @@ struct asp_sa_plan {
   DeviceBuffer<uint32_t> color_block_start, block_width, ell_col, spin_of_pos, pos_of_spin;
   DeviceBuffer<uint64_t> ell_off;
   DeviceBuffer<double> ell_val, field_pos;
+  // per-call work buffers, grown on demand and kept (a plan is used by one thread at a time)
+  DeviceBuffer<double> w_betas, w_partial, w_e;
+  DeviceBuffer<uint64_t> w_best, w_x0, w_x0_perm, w_x;
+  DeviceBuffer<long long> w_tracked;
+  DeviceBuffer<unsigned long long> w_accepted;
 };
 
 namespace {
@@ -793,6 +798,7 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
                uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0, bool descent,
                uint64_t *out_x, double *out_e) {
   if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  ASP_TRY(asp::bind_device());
   if (repetitions == 0) return ASP_OK;
   if (!out_x || !out_e || (num_sweeps && !betas)) {
     return asp::set_error(ASP_ERR_INVALID, "null argument");
@@ -827,22 +833,23 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
   const uint64_t padded = static_cast<uint64_t>(groups) * m;
   hipStream_t s = p->stream;
 
-  DeviceBuffer<double> d_betas, d_partial, d_e;
-  DeviceBuffer<uint64_t> d_best, d_x0, d_x0_perm, d_x;
-  DeviceBuffer<long long> d_tracked;
-  DeviceBuffer<unsigned long long> d_accepted;
-  ASP_TRY(d_betas.alloc(num_sweeps));
-  ASP_TRY(d_best.alloc(padded * L.num_blocks));
-  ASP_TRY(d_tracked.alloc(padded));
-  ASP_TRY(d_accepted.alloc(padded));
-  ASP_TRY(d_partial.alloc(static_cast<uint64_t>(repetitions) * L.num_blocks));
-  ASP_TRY(d_e.alloc(repetitions));
-  ASP_TRY(d_x.alloc(static_cast<uint64_t>(repetitions) * words));
+  DeviceBuffer<double> &d_betas = p->w_betas, &d_partial = p->w_partial, &d_e = p->w_e;
+  DeviceBuffer<uint64_t> &d_best = p->w_best, &d_x0 = p->w_x0, &d_x0_perm = p->w_x0_perm,
+                         &d_x = p->w_x;
+  DeviceBuffer<long long> &d_tracked = p->w_tracked;
+  DeviceBuffer<unsigned long long> &d_accepted = p->w_accepted;
+  ASP_TRY(d_betas.ensure(num_sweeps));
+  ASP_TRY(d_best.ensure(padded * L.num_blocks));
+  ASP_TRY(d_tracked.ensure(padded));
+  ASP_TRY(d_accepted.ensure(padded));
+  ASP_TRY(d_partial.ensure(static_cast<uint64_t>(repetitions) * L.num_blocks));
+  ASP_TRY(d_e.ensure(repetitions));
+  ASP_TRY(d_x.ensure(static_cast<uint64_t>(repetitions) * words));
   ASP_TRY(d_betas.upload(betas, num_sweeps, s));
   ASP_HIP_TRY(hipMemsetAsync(d_accepted.ptr, 0, padded * sizeof(unsigned long long), s));
   if (x0) {
-    ASP_TRY(d_x0.alloc(words));
-    ASP_TRY(d_x0_perm.alloc(L.num_blocks));
+    ASP_TRY(d_x0.ensure(words));
+    ASP_TRY(d_x0_perm.ensure(L.num_blocks));
     ASP_TRY(d_x0.upload(x0, words, s));
     hipLaunchKernelGGL(k_permute_bits, dim3((L.num_blocks + 255) / 256), dim3(256), 0, s, d_x0.ptr,
                        words, p->spin_of_pos.ptr, L.num_blocks, 1u, d_x0_perm.ptr);
@@ -980,6 +987,7 @@ float asp_sa_last_total_ms(asp_sa_plan const *p) { return p ? p->last_total_ms :
 int asp_sa_energy(asp_sa_plan *p, uint32_t count, uint64_t const *x, double *out_e) {
   asp_clear_error();
   if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  ASP_TRY(asp::bind_device());
   if (count == 0) return ASP_OK;
   if (!x || !out_e) return asp::set_error(ASP_ERR_INVALID, "null argument");
   const asp::SaHostLayout &L = p->host;

@@ -1,0 +1,223 @@
+"""The sampled-cluster pipeline of ``make kagome_36 / pyrochlore_32 / sk_32_1``
+(Makefile:101-141 → experiments/sampled_connected_components.py) on the MI355X path.
+
+Same call sequence and CSV schema as the reference driver:
+
+    sample seeds ~ |psi|^p                          common.py:270-279
+    grow a cluster around each seed                 common.py:481-513
+    order 0: make_ising_model(cluster)              common.py:131-208        (GPU)
+    order i: make_hamiltonian_extension + sparsify  common.py:516-522, 647-692
+    solve: greedy, optionally SA                    common.py:232-261        (GPU)
+    score: accuracy / overlap / amplitude overlap   common.py:211-229; driver :719-723
+    one CSV line of 6 * (order + 1) numbers         driver :681-693, 804-830
+
+Differences forced by the environment, not by design: the ground state comes from exact
+diagonalisation of a symmetry-free model named in ``models.json`` (the reference loads an HDF5
+file that its Makefile downloads), and the operator is :mod:`.operators` instead of
+``lattice_symmetries``.  Like the reference, all host-side randomness is numpy's global legacy
+stream seeded once with ``--seed`` (driver :776).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+from dataclasses import dataclass
+from typing import List, Sequence
+
+import numpy as np
+
+from . import annealer as sa
+from . import common, operators, synthetic
+
+
+def create_small_cluster_around_point(s0: int, hamiltonian, required_size: int = 20,
+                                      keep_probability: float = 0.5) -> List[int]:
+    """Breadth-first growth: each new neighbour is kept with ``keep_probability``
+    (common.py:481-513)."""
+    assert hamiltonian.basis.number_spins <= 64
+    s0 = int(s0)
+    members = {s0}
+
+    def children_of(state):
+        targets, _ = hamiltonian.apply(state)
+        targets = np.asarray(targets)
+        if targets.ndim > 1:
+            targets = targets[:, 0]
+        kept = []
+        for x in targets:
+            if x in members:
+                continue
+            if np.random.rand() <= keep_probability:
+                kept.append(int(x))
+        return kept
+
+    frontier = children_of(s0)
+    while len(members) < required_size and len(frontier) > 0:
+        upcoming = set()
+        for child in frontier:
+            members.add(child)
+            if len(members) >= required_size:
+                break
+            upcoming |= set(children_of(child))
+        frontier = upcoming
+    return sorted(members)
+
+
+def random_cluster_size(min_size: float, max_size: float) -> int:
+    """Log-uniform in [min_size, max_size] (driver :645-649)."""
+    u = np.random.random_sample()
+    return int(round(np.exp(np.log(min_size) + (np.log(max_size) - np.log(min_size)) * u)))
+
+
+def generate_clusters(hamiltonian, ground_state, number_samples: int, sampled_power: float,
+                      min_cluster_size: int, max_cluster_size: int,
+                      keep_probability: float) -> List[np.ndarray]:
+    """driver :652-669."""
+    seeds = common.monte_carlo_sampling(hamiltonian.basis.states, ground_state,
+                                        number_samples=number_samples, sampled_power=sampled_power)
+    clusters = []
+    for s in seeds.spins:
+        size = random_cluster_size(min_cluster_size, max_cluster_size)
+        cluster = create_small_cluster_around_point(s, hamiltonian, required_size=size,
+                                                    keep_probability=keep_probability)
+        clusters.append(np.asarray(cluster, dtype=np.uint64))
+    return clusters
+
+
+@dataclass
+class OptimizationResult:
+    """driver :672-693."""
+
+    size: int
+    greedy_accuracy: float
+    greedy_overlap: float
+    sa_accuracy: float
+    sa_overlap: float
+    amplitude_overlap: float
+
+    def to_csv_str(self) -> str:
+        return "{},{:.8e},{:.8e},{:.8e},{:.8e},{:.8e}".format(
+            self.size, self.greedy_accuracy, self.greedy_overlap, self.sa_accuracy,
+            self.sa_overlap, self.amplitude_overlap)
+
+    @staticmethod
+    def csv_header() -> str:
+        return "size,greedy_accuracy,greedy_overlap,sa_accuracy,sa_overlap,amplitude_overlap"
+
+
+def solve_and_test_model(h: common.IsingModel, frozen_spins, exact_signs, weights,
+                         annealing: bool) -> OptimizationResult:
+    """Greedy always, SA when requested, both projected on the original cluster
+    (driver :696-716; NB the driver's --number-sweeps/--repetitions are not forwarded, the
+    defaults of solve_ising_model apply, common.py:236-239)."""
+    x = common.solve_ising_model(h, mode="greedy", frozen_spins=frozen_spins)
+    greedy_accuracy, greedy_overlap = common.compute_accuracy_and_overlap(x, exact_signs, weights)
+    if annealing:
+        x = common.solve_ising_model(h, mode="sa", frozen_spins=frozen_spins)
+        sa_accuracy, sa_overlap = common.compute_accuracy_and_overlap(x, exact_signs, weights)
+    else:
+        sa_accuracy = sa_overlap = float("nan")
+    return OptimizationResult(h.size, greedy_accuracy, greedy_overlap, sa_accuracy, sa_overlap,
+                              float("nan"))
+
+
+def amplitude_overlap(cluster, ground_state, noisy_ground_state, basis) -> float:
+    """driver :719-723."""
+    where = np.asarray(basis.batched_index(cluster), dtype=np.int64)
+    a = np.abs(ground_state[where])
+    b = np.abs(noisy_ground_state[where])
+    return float(np.dot(a, b) / np.linalg.norm(a) / np.linalg.norm(b))
+
+
+def process_cluster(cluster, hamiltonian, ground_state, noisy_ground_state, noisy_log_coeff_fn,
+                    order: int, global_cutoff: float, annealing: bool) -> List[OptimizationResult]:
+    """driver :726-751."""
+    basis = hamiltonian.basis
+    exact_psi = ground_state[np.asarray(basis.batched_index(cluster), dtype=np.int64)]
+    exact_signs = sa.signs_to_bits(np.sign(exact_psi))
+    weights = exact_psi ** 2
+    weights /= np.sum(weights)
+    results = []
+    h = None
+    for i in range(order + 1):
+        if i == 0:
+            h = common.make_ising_model(cluster, hamiltonian, log_psi_fn=noisy_log_coeff_fn)
+        else:
+            h = common.make_hamiltonian_extension(h, noisy_log_coeff_fn)
+            h = common.sparsify_using_global_cutoff(h, global_cutoff, cluster)
+        r = solve_and_test_model(h, cluster, exact_signs, weights, annealing)
+        r.amplitude_overlap = amplitude_overlap(h.spins, ground_state, noisy_ground_state, basis)
+        results.append(r)
+    return results
+
+
+def parse_command_line(argv=None):
+    parser = argparse.ArgumentParser(description="Test Simulated Annealing on sampled clusters.")
+    parser.add_argument("--model", type=str, required=True,
+                        help="name in models.json (stands in for --yaml/--hdf5)")
+    parser.add_argument("--output", type=str, required=True)
+    parser.add_argument("--order", type=int, required=True)
+    parser.add_argument("--noise", type=float, default=0)
+    parser.add_argument("--annealing", default=True, action=argparse.BooleanOptionalAction)
+    parser.add_argument("--global-cutoff", type=float, default=1e-4)
+    parser.add_argument("--number-samples", type=int, default=5)
+    parser.add_argument("--number-sweeps", type=int, default=5000)
+    parser.add_argument("--repetitions", type=int, default=64)
+    parser.add_argument("--min-cluster-size", type=int, default=50)
+    parser.add_argument("--max-cluster-size", type=int, default=1000)
+    parser.add_argument("--sampled-power", type=float, default=0.1)
+    parser.add_argument("--keep-probability", type=float, default=0.5)
+    parser.add_argument("--seed", type=int, default=12345)
+    parser.add_argument("--jobs", type=int, default=1,
+                        help="clusters optimised concurrently (independent plans and HIP streams "
+                             "on one GPU; the output does not depend on it)")
+    return parser.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_command_line(argv)
+    np.random.seed(args.seed)
+    if os.path.exists(args.output):
+        raise SystemExit("Output file '{}' already exists: refusing to overwrite".format(args.output))
+    models = synthetic.load_models()
+    hamiltonian = operators.Operator.from_config(models[args.model])
+    hamiltonian.basis.build()
+    _, ground_state = hamiltonian.ground_state()
+    if args.noise > 0:
+        noisy_ground_state = common.add_noise_to_amplitudes(ground_state, args.noise)
+    else:
+        noisy_ground_state = ground_state
+    noisy_log_coeff_fn = common.ground_state_to_log_coeff_fn(noisy_ground_state, hamiltonian.basis)
+    clusters = generate_clusters(hamiltonian, ground_state, args.number_samples,
+                                 args.sampled_power, args.min_cluster_size,
+                                 args.max_cluster_size, args.keep_probability)
+    with open(args.output, "w") as f:
+        f.write("# Generated by annealing_sign_problem_amd.sampled_components\n")
+        for key in ["seed", "order", "noise", "global_cutoff", "sampled_power", "min_cluster_size",
+                    "max_cluster_size", "keep_probability", "number_sweeps", "repetitions"]:
+            f.write("# {} = {}\n".format(key, getattr(args, key)))
+        f.write("# {}\n".format(OptimizationResult.csv_header()))
+    def work(cluster):
+        return process_cluster(cluster, hamiltonian, ground_state, noisy_ground_state,
+                               noisy_log_coeff_fn, args.order, args.global_cutoff, args.annealing)
+
+    # Clusters are independent problems: with --jobs > 1 several are in flight on
+    # the GPU at once — the C calls release the GIL and every Hamiltonian owns its stream.  All
+    # randomness was consumed above, so the lines written are identical for any --jobs.
+    if args.jobs > 1:
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=args.jobs) as pool:
+            results = pool.map(work, clusters)
+            for columns in results:
+                with open(args.output, "a") as f:
+                    f.write(",".join(r.to_csv_str() for r in columns) + "\n")
+    else:
+        for cluster in clusters:
+            columns = work(cluster)
+            with open(args.output, "a") as f:
+                f.write(",".join(r.to_csv_str() for r in columns) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -167,7 +167,31 @@ def bench_build(J, cores_unused, seconds=6.0):
         cpu = {"value": cut / t, "unit": "connections/s", "cores": 1, "kind": "reference",
                "sample": "oracle/_ref (cbits/build_matrix.c, serial), first %d of %d rows, %.2f s"
                          % (rows, n, t)}
+    # live path (common.make_ising_model's two numba kernels, 64-bit keys): device time of
+    # scan + fused kernel, next to a numpy restatement of common.py:71-82,116-128 on one core
+    from annealing_sign_problem_amd import common
+
+    common.ising_elements(keys, psi, other, coeffs, other_counts)
+    live_ms = []
+    for _ in range(5):
+        common.ising_elements(keys, psi, other, coeffs, other_counts)
+        live_ms.append(lib.asp_ising_elements_last_ms())
+    live = float(np.median(live_ms))
+    t0 = time.perf_counter()
+    idx = np.clip(np.searchsorted(keys, other), 0, n - 1)
+    member = other == keys[idx]
+    el = coeffs * np.abs(np.where(member, psi[idx], 0))
+    el *= np.abs(psi[np.repeat(np.arange(n), other_counts)])
+    t_np = time.perf_counter() - t0
+    live_path = {
+        "workload": "ising_elements K=%d, %d connections (64-bit keys)" % (n, m),
+        "connections_per_s": m / (live * 1e-3), "ms": live,
+        "algorithmic_GBps": m * 40 / (live * 1e-3) / 1e9,
+        "cpu_baseline": {"value": m / t_np, "unit": "connections/s", "cores": 1, "kind": "port",
+                         "sample": "numpy restatement of common.py:71-82,116-128, all %d connections, %.2f s" % (m, t_np)},
+    }
     return {
+        "live_path": live_path,
         "workload": "build_matrix K=%d, %d connections (512-bit keys)" % (n, m),
         "connections_per_s": m / (ms * 1e-3),
         "ms": ms,

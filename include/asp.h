@@ -41,7 +41,8 @@ void asp_clear_error(void);
 
 /* Number of HIP devices (>= 0) or a negative asp_status. */
 int asp_device_count(void);
-/* Select the device used by subsequently created objects of this thread. */
+/* Select the device used by this library in the whole process (every entry point binds
+ * its calling thread to it). */
 int asp_set_device(int device);
 /* Library version, "major.minor.patch". */
 const char *asp_version(void);
@@ -127,6 +128,10 @@ int asp_ising_elements(uint64_t num_spins, uint64_t const *keys, double const *p
                        double const *other_coeffs, int64_t const *other_counts,
                        int64_t *other_indices, uint8_t *member, double *elements,
                        int64_t *offsets);
+
+/* Device time (ms, HIP events) of the scan + kernel of this thread's last
+ * asp_ising_elements call, without the host<->HBM copies. */
+float asp_ising_elements_last_ms(void);
 
 /* ------------------------------------------------------------------------- */
 /* (4) Annealer: replaces ising_glass_annealer.{Hamiltonian,anneal}          */

@@ -223,3 +223,28 @@ def test_greedy_solves_unfrustrated_instance_exactly():
                                               diagonal_range=0)
     x, e = oracle.greedy_solve(J, h)
     assert abs(e - planted @ (J @ planted)) <= 1e-12 * abs(e)
+
+
+def test_cluster_growth_is_connected_and_sized(models):
+    from annealing_sign_problem_amd import operators, sampled_components
+
+    op = operators.Operator.from_config(models["heisenberg_kagome_16"])
+    op.basis.build()
+    np.random.seed(5)
+    start = int(op.basis.states[1234])
+    cluster = sampled_components.create_small_cluster_around_point(start, op, required_size=120)
+    assert cluster == sorted(cluster) and start in cluster and len(set(cluster)) == len(cluster)
+    assert 60 <= len(cluster) <= 120
+    # connected under the Hamiltonian's off-diagonal action
+    members = set(cluster)
+    seen, stack = {start}, [start]
+    while stack:
+        other, _ = op.apply(stack.pop())
+        for x in other[:, 0]:
+            x = int(x)
+            if x in members and x not in seen:
+                seen.add(x)
+                stack.append(x)
+    assert seen == members
+    sizes = [sampled_components.random_cluster_size(50, 1000) for _ in range(200)]
+    assert min(sizes) >= 50 and max(sizes) <= 1000 and np.median(sizes) < 400  # log-uniform
