@@ -146,6 +146,11 @@ def bench_build(J, cores_unused, seconds=6.0):
         times.append(lib.asp_build_last_ms(handle))
     lib.asp_build_destroy(handle)
     ms = float(np.median(times[1:]))
+    # the drop-in symbol itself: host pointers in and out (allocation + PCIe both ways + kernels)
+    _build_matrix.build_matrix(keys, counts, psi, other, coeffs, other_counts, other_psi)
+    t0 = time.perf_counter()
+    _build_matrix.build_matrix(keys, counts, psi, other, coeffs, other_counts, other_psi)
+    host_call_ms = (time.perf_counter() - t0) * 1e3
     # reference C (serial: cbits/build_matrix.c has no OpenMP) on a prefix of the rows; the
     # key table must stay whole, so the remaining rows get other_counts = 0
     rows = max(1, min(n, int(n * 0.2)))
@@ -195,6 +200,7 @@ def bench_build(J, cores_unused, seconds=6.0):
         "workload": "build_matrix K=%d, %d connections (512-bit keys)" % (n, m),
         "connections_per_s": m / (ms * 1e-3),
         "ms": ms,
+        "host_pointer_call_ms": host_call_ms,
         "nnz": int(nnz.value),
         "algorithmic_GBps": m * 96 / (ms * 1e-3) / 1e9,
         "cpu_baseline": cpu,
