@@ -72,6 +72,7 @@ SIGNATURES = {
     "asp_sa_layout_host": (c_int, [c_u64, c_void_p, c_void_p, c_void_p, c_void_p,
                                    ctypes.POINTER(SaInfo), c_void_p, c_void_p]),
     "asp_sa_set_launch": (c_int, [c_void_p, c_int, c_int]),
+    "asp_sa_set_packed": (c_int, [c_void_p, c_int]),
     "asp_sa_anneal": (c_int, [c_void_p, c_u64, c_void_p, c_u32, c_u32, c_u32, c_void_p, c_void_p,
                               c_void_p]),
     "asp_sa_greedy": (c_int, [c_void_p, c_u32, c_void_p, c_void_p, ctypes.POINTER(c_u32)]),
@@ -104,6 +105,8 @@ def load() -> ctypes.CDLL:
             raise AspError(-2, "libasp_hip.so is missing and could not be built: %s" % exc)
     lib = ctypes.CDLL(path)
     for name, (restype, argtypes) in SIGNATURES.items():
+        if _build._TAG and not hasattr(lib, name):
+            continue  # development A/B against an older tagged build (tools/ab_tags.sh)
         fn = getattr(lib, name)  # AttributeError here = ABI mismatch, fail loudly
         fn.restype = restype
         fn.argtypes = argtypes

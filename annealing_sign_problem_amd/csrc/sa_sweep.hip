@@ -189,14 +189,25 @@ __device__ __forceinline__ void load_quad(Quad &q, const uint4 *__restrict__ cpt
 #endif
 }
 
-template <int M>
+// PACKED = false: one LDS byte per position, bit m = replica m.  PACKED = true (M = 1 only):
+// one LDS bit per position, 64 positions (= one block) per u64 word.
+template <int M, bool PACKED>
 __device__ __forceinline__ void accumulate_quad(const Quad &q, const uint8_t *spins,
                                                 double (&acc)[M]) {
   uint32_t s[4];
+  const uint32_t cs[4] = {q.c.x, q.c.y, q.c.z, q.c.w};
 #if ASP_ABL_NO_LDS
-  s[0] = q.c.x & 15u; s[1] = q.c.y & 15u; s[2] = q.c.z & 15u; s[3] = q.c.w & 15u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s[j] = cs[j] & 15u;
 #else
-  s[0] = spins[q.c.x]; s[1] = spins[q.c.y]; s[2] = spins[q.c.z]; s[3] = spins[q.c.w];
+  if constexpr (PACKED) {
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(spins);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = (words[cs[j] >> 5] >> (cs[j] & 31u)) & 1u;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = spins[cs[j]];
+  }
 #endif
 #if ASP_ABL_NO_FMA
   asm volatile("" ::"v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(q.v01.x), "v"(q.v01.y),
@@ -232,9 +243,16 @@ struct SweepArgs {
   uint32_t num_colors, num_blocks, num_sweeps, replica_first;
 };
 
-template <int M>
+template <int M, bool PACKED>
 __device__ __forceinline__ void snapshot(const uint8_t *spins, const SweepArgs &a, uint32_t group,
                                          uint32_t mask) {
+  if constexpr (PACKED) {  // the LDS words already are the packed sign bits
+    const uint64_t *words = reinterpret_cast<const uint64_t *>(spins);
+    for (uint32_t w = threadIdx.x; w < a.num_blocks; w += blockDim.x) {
+      a.best_perm[static_cast<uint64_t>(group) * a.num_blocks + w] = words[w];
+    }
+    return;
+  }
   for (uint32_t w = threadIdx.x; w < a.num_blocks; w += blockDim.x) {
     const uint4 *src = reinterpret_cast<const uint4 *>(spins + 64u * w);
     uint4 q[4];
@@ -257,11 +275,13 @@ __device__ __forceinline__ void snapshot(const uint8_t *spins, const SweepArgs &
 
 // DESCENT = true: strict-descent sweeps (accept iff dE < 0, no random numbers), used by the
 // greedy solver's relaxation; the final configuration is snapshotted after every sweep.
-template <int M, bool DESCENT>
+template <int M, bool DESCENT, bool PACKED>
 __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
+  static_assert(!PACKED || M == 1, "the bit-packed layout holds one replica");
   extern __shared__ __align__(16) uint8_t lds[];
   uint8_t *spins = lds;
-  const uint32_t P = a.num_blocks * 64u;
+  // bytes of the spin area: one byte per position, or one bit (8 bytes per block) when PACKED
+  const uint32_t P = PACKED ? a.num_blocks * 8u : a.num_blocks * 64u;
   // P is a multiple of 64.  Per replica m: delta[m] = energy change of the running
   // sweep, book[m] = current tracked energy, book[8+m] = best, book[16+m] = accepted flips
   long long *delta = reinterpret_cast<long long *>(lds + P);
@@ -278,8 +298,9 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
   const uint32_t key0 = static_cast<uint32_t>(a.seed);
   const uint32_t key1 = static_cast<uint32_t>(a.seed >> 32);
 
-  // ---- initial configuration ----
-  for (uint32_t p = tid; p < P; p += blockDim.x) {
+  // ---- initial configuration ---- (a wavefront initialises whole 64-position blocks)
+  for (uint32_t b0 = tid >> 6; b0 < a.num_blocks; b0 += blockDim.x >> 6) {
+    const uint32_t p = b0 * 64u + (tid & 63u);
     const uint32_t spin = a.spin_of_pos[p];
     uint32_t byte = 0;
     if (spin != kDummySpin) {
@@ -300,7 +321,12 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
         }
       }
     }
-    spins[p] = static_cast<uint8_t>(byte);
+    if constexpr (PACKED) {
+      const uint64_t word = __ballot(byte & 1u);
+      if ((tid & 63u) == 0) reinterpret_cast<uint64_t *>(spins)[b0] = word;
+    } else {
+      spins[p] = static_cast<uint8_t>(byte);
+    }
   }
   for (uint32_t b = tid; b < a.num_blocks; b += blockDim.x) {
     meta[b] = make_uint2(static_cast<uint32_t>(a.ell_off[b]), a.block_width[b]);
@@ -308,7 +334,7 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
   if (tid < 32) delta[tid] = 0;  // delta[8] + book[24]
   if (tid == 0) *improved_flag = 0;
   __syncthreads();
-  snapshot<M>(spins, a, group, (1u << M) - 1u);
+  snapshot<M, PACKED>(spins, a, group, (1u << M) - 1u);
   __syncthreads();
 
   for (uint32_t t = 0; t < a.num_sweeps; ++t) {
@@ -376,19 +402,19 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
           for (; i + 3 <= quads_run; i += 3) {
             load_quad(q2, cptr, vptr, i + 2);
             __builtin_amdgcn_sched_barrier(0);
-            accumulate_quad<M>(q0, spins, acc);
+            accumulate_quad<M, PACKED>(q0, spins, acc);
             __builtin_amdgcn_sched_barrier(0);
             load_quad(q0, cptr, vptr, i + 3);
             __builtin_amdgcn_sched_barrier(0);
-            accumulate_quad<M>(q1, spins, acc);
+            accumulate_quad<M, PACKED>(q1, spins, acc);
             __builtin_amdgcn_sched_barrier(0);
             load_quad(q1, cptr, vptr, i + 4);
             __builtin_amdgcn_sched_barrier(0);
-            accumulate_quad<M>(q2, spins, acc);
+            accumulate_quad<M, PACKED>(q2, spins, acc);
             __builtin_amdgcn_sched_barrier(0);
           }
-          if (i < quads_run) accumulate_quad<M>(q0, spins, acc);
-          if (i + 1 < quads_run) accumulate_quad<M>(q1, spins, acc);
+          if (i < quads_run) accumulate_quad<M, PACKED>(q0, spins, acc);
+          if (i + 1 < quads_run) accumulate_quad<M, PACKED>(q1, spins, acc);
         } else {
           // M = 8 has no registers to spare: prefetch distance one (two buffers)
           Quad qa, qb;
@@ -397,17 +423,22 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
           for (; i + 2 <= quads_run; i += 2) {
             load_quad(qb, cptr, vptr, i + 1);
             __builtin_amdgcn_sched_barrier(0);
-            accumulate_quad<M>(qa, spins, acc);
+            accumulate_quad<M, PACKED>(qa, spins, acc);
             __builtin_amdgcn_sched_barrier(0);
             load_quad(qa, cptr, vptr, i + 2);
             __builtin_amdgcn_sched_barrier(0);
-            accumulate_quad<M>(qb, spins, acc);
+            accumulate_quad<M, PACKED>(qb, spins, acc);
             __builtin_amdgcn_sched_barrier(0);
           }
-          if (i < quads_run) accumulate_quad<M>(qa, spins, acc);
+          if (i < quads_run) accumulate_quad<M, PACKED>(qa, spins, acc);
         }
         const bool valid = spin != kDummySpin;
-        const uint32_t own = spins[p];
+        uint32_t own;
+        if constexpr (PACKED) {
+          own = static_cast<uint32_t>((reinterpret_cast<const uint64_t *>(spins)[b] >> lane) & 1ull);
+        } else {
+          own = spins[p];
+        }
         uint32_t flip = 0;
         Philox4 rnd{};
         uint32_t have = 0xFFFFFFFFu;
@@ -447,7 +478,13 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
             n_acc[m] += 1;
           }
         }
-        if (flip) spins[p] = static_cast<uint8_t>(own ^ flip);
+        if constexpr (PACKED) {
+          // the block's 64 proposals decided: one XOR of the ballot into the block's word
+          const uint64_t flips = __ballot(flip != 0);
+          if (lane == 0 && flips != 0) reinterpret_cast<uint64_t *>(spins)[b] ^= flips;
+        } else {
+          if (flip) spins[p] = static_cast<uint8_t>(own ^ flip);
+        }
       }
 #if !ASP_ABL_NO_BARRIER
       __syncthreads();
@@ -478,7 +515,7 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
     }
     __syncthreads();
     const uint32_t improved = DESCENT ? ((1u << M) - 1u) : *improved_flag;
-    if (improved) snapshot<M>(spins, a, group, improved);
+    if (improved) snapshot<M, PACKED>(spins, a, group, improved);
     __syncthreads();
     if (tid == 0) *improved_flag = 0;  // next write to it is two barriers away
   }
@@ -614,6 +651,7 @@ struct asp_sa_plan {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   float last_sweep_ms = 0.0f, last_total_ms = 0.0f;
   int force_m = 0, force_threads = 0;
+  bool force_packed = false;
   int last_m = 0, last_threads = 0, last_groups = 0;
   std::vector<int64_t> last_tracked;
   std::vector<uint64_t> last_accepted;
@@ -639,19 +677,20 @@ int upload_vector(DeviceBuffer<T> &dst, const std::vector<T> &src, hipStream_t s
 
 using SweepKernel = void (*)(SweepArgs);
 
-SweepKernel sweep_kernel_for(int m, bool descent = false) {
+SweepKernel sweep_kernel_for(int m, bool descent, bool packed) {
+  if (packed) return descent ? k_sa_sweep<1, true, true> : k_sa_sweep<1, false, true>;
   switch (m) {
-    case 1: return descent ? k_sa_sweep<1, true> : k_sa_sweep<1, false>;
-    case 2: return k_sa_sweep<2, false>;
-    case 4: return k_sa_sweep<4, false>;
-    case 8: return k_sa_sweep<8, false>;
+    case 1: return descent ? k_sa_sweep<1, true, false> : k_sa_sweep<1, false, false>;
+    case 2: return k_sa_sweep<2, false, false>;
+    case 4: return k_sa_sweep<4, false, false>;
+    case 8: return k_sa_sweep<8, false, false>;
     default: return nullptr;
   }
 }
 
-size_t sweep_lds_bytes(const asp::SaHostLayout &L) {
+size_t sweep_lds_bytes(const asp::SaHostLayout &L, bool packed) {
   // spins | delta[8] book[24] | flag (16 B) | meta[num_blocks]
-  return static_cast<size_t>(L.num_blocks) * 64 + 34 * sizeof(long long) +
+  return static_cast<size_t>(L.num_blocks) * (packed ? 8 : 64) + 34 * sizeof(long long) +
          static_cast<size_t>(L.num_blocks) * sizeof(uint2);
 }
 
@@ -778,7 +817,7 @@ int asp_sa_plan_info(asp_sa_plan const *p, asp_sa_info *info) {
 
 int asp_sa_set_launch(asp_sa_plan *p, int replicas_per_group, int threads) {
   if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
-  if (replicas_per_group != 0 && !sweep_kernel_for(replicas_per_group)) {
+  if (replicas_per_group != 0 && !sweep_kernel_for(replicas_per_group, false, false)) {
     return asp::set_error(ASP_ERR_INVALID, "replicas_per_group must be 0, 1, 2, 4 or 8");
   }
   if (threads != 0 && (threads < 64 || threads > 1024 || threads % 64 != 0)) {
@@ -786,6 +825,12 @@ int asp_sa_set_launch(asp_sa_plan *p, int replicas_per_group, int threads) {
   }
   p->force_m = replicas_per_group;
   p->force_threads = threads;
+  return ASP_OK;
+}
+
+int asp_sa_set_packed(asp_sa_plan *p, int packed) {
+  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  p->force_packed = packed != 0;
   return ASP_OK;
 }
 
@@ -823,10 +868,16 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
   int m = 1, threads = 64;
   choose_launch(p, repetitions, &m, &threads);
   if (descent) m = 1;
-  const size_t lds = sweep_lds_bytes(L);
+  // One byte per position when that fits the LDS; otherwise one BIT per position, one replica
+  // per workgroup (flips applied by wavefront ballot) — 8x the capacity.
+  bool packed = p->force_packed;
+  if (!packed && sweep_lds_bytes(L, false) > p->max_lds) packed = true;
+  if (packed) m = 1;
+  const size_t lds = sweep_lds_bytes(L, packed);
   if (lds > p->max_lds) {
     return asp::set_error(ASP_ERR_TOO_LARGE,
-                          "%llu spins (%zu B of LDS) exceed the %zu B one workgroup may hold",
+                          "%llu spins (%zu B of LDS even bit-packed) exceed the %zu B one "
+                          "workgroup may hold",
                           (unsigned long long)K, lds, p->max_lds);
   }
   const uint32_t groups = (repetitions + m - 1) / m;
@@ -875,7 +926,7 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
   args.num_sweeps = num_sweeps;
   args.replica_first = replica_offset;
 
-  SweepKernel kernel = sweep_kernel_for(m, descent);
+  SweepKernel kernel = sweep_kernel_for(m, descent, packed);
   if (lds > 64 * 1024) {
     ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,

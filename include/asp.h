@@ -176,6 +176,12 @@ int asp_sa_layout_host(uint64_t num_spins, int64_t const *indptr, int32_t const 
  * replicas_per_group in {1,2,4,8}; threads multiple of 64, <= 1024. */
 int asp_sa_set_launch(asp_sa_plan *p, int replicas_per_group, int threads);
 
+/* LDS layout of the spins: by default one byte per spin position (bit m = replica m of the
+ * workgroup), and automatically one BIT per position with one replica per workgroup when the
+ * byte layout does not fit (K beyond ~1.4e5; capacity ~6.5e5 spins).  packed != 0 forces the
+ * bit-packed layout (tests, measurements).  Results never depend on the layout. */
+int asp_sa_set_packed(asp_sa_plan *p, int packed);
+
 /* Run `repetitions` independent annealing chains (global replica ids
  * replica_offset .. replica_offset+repetitions-1) of num_sweeps sweeps, sweep t
  * at inverse temperature betas[t].  x0 == NULL: random initial spins from the

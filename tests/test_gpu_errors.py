@@ -51,8 +51,8 @@ def test_plan_rejects_bad_matrices_and_oversized_problems():
     with pytest.raises(_lib.AspError) as err:
         ham.plan()
     assert err.value.code == -3
-    # more spins than one workgroup's LDS can hold: refused, not truncated
-    n = 200000
+    # more spins than one workgroup's LDS can hold even bit-packed: refused, not truncated
+    n = 1500000
     big = sa.Hamiltonian(scipy.sparse.identity(n, format="csr"), np.zeros(n))
     with pytest.raises(_lib.AspError) as err:
         sa.anneal(big, seed=1, number_sweeps=1, repetitions=1)

@@ -216,3 +216,51 @@ def test_greedy_solve_matches_oracle_and_improves():
     model = common.IsingModel(np.arange(J.shape[0], dtype=np.uint64), None, sa.Hamiltonian(J, h), None)
     xg = common.solve_ising_model(model, mode="greedy")
     assert np.array_equal(xg, oracle.greedy_solve(J, h)[0])
+
+
+def _set_packed(h, packed):
+    from annealing_sign_problem_amd import _lib
+
+    _lib.check(_lib.load().asp_sa_set_packed(h.plan(), int(packed)))
+
+
+@pytest.mark.parametrize("threads", [64, 256, 1024])
+def test_bit_packed_layout_bit_exact(threads):
+    """One LDS bit per spin, flips by wavefront ballot (the layout used beyond ~1.4e5 spins),
+    forced on a small instance: same chains as the oracle."""
+    from annealing_sign_problem_amd import annealer as sa
+
+    J, h, _ = _planted(1500, 21)
+    field = np.random.default_rng(5).normal(size=1500) * 0.01
+    betas = np.geomspace(0.5, 2e4, 40)
+    ham = sa.Hamiltonian(J, field)
+    _set_packed(ham, True)
+    _set_launch(ham, 0, threads)
+    xs, es = sa.anneal_raw(ham, 4242, betas, 9, 3)
+    tracked, accepted = _stats(ham, 9)
+    oxs, oes, otr, oacc = oracle.sa_anneal(J, field, 4242, betas, 9, 3, None,
+                                           ham.info().energy_scale_exp, num_threads=8)
+    assert np.array_equal(accepted, oacc) and np.array_equal(tracked, otr)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    x0 = np.random.default_rng(6).integers(0, 2**63, size=(1500 + 63) // 64, dtype=np.uint64)
+    xs, es = sa.anneal_raw(ham, 1, betas[:10], 2, 0, x0)
+    oxs, oes, _, _ = oracle.sa_anneal(J, field, 1, betas[:10], 2, 0, x0, ham.info().energy_scale_exp)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+
+
+def test_beyond_byte_layout_capacity():
+    """K = 3e5 does not fit one byte per spin in LDS: the bit-packed kernel takes over by
+    itself; energies check against numpy, a short oracle run checks the chains."""
+    from annealing_sign_problem_amd import annealer as sa
+
+    J, h, _ = _planted(300000, 22, mean_degree=6.0, max_degree=14)
+    ham = sa.Hamiltonian(J, h)
+    info = ham.info()
+    betas = sa.make_schedule(info.beta0_auto, min(info.beta1_auto, 1e6), 3)
+    xs, es = sa.anneal_raw(ham, 77, betas, 4)
+    for r in range(4):
+        s = sa.bits_to_signs(xs[r], 300000)
+        ref = s @ (J @ s)
+        assert abs(es[r] - ref) <= 1e-12 * abs(ref)
+    oxs, oes, _, _ = oracle.sa_anneal(J, h, 77, betas, 2, 0, None, info.energy_scale_exp, num_threads=2)
+    assert np.array_equal(xs[:2], oxs) and es[:2].tobytes() == oes.tobytes()
