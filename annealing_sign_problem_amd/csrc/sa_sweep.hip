@@ -35,6 +35,9 @@
 #ifndef ASP_MAGIC_RINT
 #define ASP_MAGIC_RINT 1
 #endif
+#ifndef ASP_EXP_FILTER
+#define ASP_EXP_FILTER 1
+#endif
 #ifndef ASP_PREFETCH_DEPTH
 #define ASP_PREFETCH_DEPTH 2
 #endif
@@ -53,6 +56,15 @@
 #endif
 #ifndef ASP_ABL_NO_GLOAD
 #define ASP_ABL_NO_GLOAD 0
+#endif
+#ifndef ASP_ABL_NO_PHILOX
+#define ASP_ABL_NO_PHILOX 0
+#endif
+#ifndef ASP_ABL_NO_EXP
+#define ASP_ABL_NO_EXP 0
+#endif
+#ifndef ASP_ABL_HALF_BYTES
+#define ASP_ABL_HALF_BYTES 0
 #endif
 #ifndef ASP_ABL_NO_FMA
 #define ASP_ABL_NO_FMA 0
@@ -138,6 +150,22 @@ __device__ __forceinline__ double spin_factor(uint32_t spin_byte, int m) {
   return __hiloint2double(static_cast<int>(hi), 0);
 }
 
+// u < expneg(x), decided through a hardware-exp filter.  v_exp_f32 of the f32-rounded
+// argument is within ~2e-6 (relative) of expneg(x) for 0 < x < 23: 1 ulp of the instruction
+// plus |x| * log2(e) * 2^-24 * ln 2 from rounding x to f32.  Outside a +-1e-5 band around that
+// estimate the comparison is settled; inside it (probability ~2e-5 per proposal, so a wavefront
+// takes the branch about once per thousand blocks) the exact sequence of §4.4 decides.  The
+// result therefore ALWAYS equals `u < expneg(x)` — same bits as the oracle — at a fraction of
+// the sixteen dependent f64 FMAs.
+__device__ __forceinline__ bool metropolis_accept(double u, double x) {
+  if (!(x < 23.0)) return false;  // expneg(x) = 0 < u; also NaN
+  const float estimate = __builtin_amdgcn_exp2f(static_cast<float>(x) * -1.44269504f);
+  const double p = static_cast<double>(estimate);
+  if (u < p * (1.0 - 1e-5)) return true;
+  if (u > p * (1.0 + 1e-5)) return false;
+  return u < expneg(x);
+}
+
 // v with its sign flipped when bit 0 of `neg` is set (energy kernel, not hot).
 __device__ __forceinline__ double signed_coupling(double v, uint32_t neg, int m) {
   const unsigned long long flip = static_cast<unsigned long long>((neg >> m) & 1u) << 63;
@@ -185,7 +213,11 @@ __device__ __forceinline__ void load_quad(Quad &q, const uint4 *__restrict__ cpt
 #else
   q.c = cptr[quad * 64u];
   q.v01 = vptr[quad * 128u];
+#if ASP_ABL_HALF_BYTES
+  q.v23 = make_double2(q.v01.y, q.v01.x);  // timing only: skip one of the two value loads
+#else
   q.v23 = vptr[quad * 128u + 64u];
+#endif
 #endif
 }
 
@@ -454,7 +486,11 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
             const uint32_t r = r0 + m;
             if (m == 0 || (r >> 2) != have) {
               have = r >> 2;
+#if ASP_ABL_NO_PHILOX
+              rnd = Philox4{{spin * 2654435761u ^ t, spin ^ (t * 40503u), spin + have, t ^ key0}};
+#else
               rnd = philox4x32_10(spin, t, have, 0u, key0, key1);
+#endif
             }
             const uint32_t word = pick_word(rnd, r & 3u);
             const double u = __dmul_rn(__dadd_rn(static_cast<double>(word), 0.5), 0x1p-32);
@@ -462,7 +498,13 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
             asm volatile("" ::"v"(de), "v"(u));
             accept = false;
 #else
+#if ASP_ABL_NO_EXP
+            accept = valid && (de <= 0.0 || u < __dmul_rn(beta, de) * 1e-3);
+#elif ASP_EXP_FILTER
+            accept = valid && (de <= 0.0 || metropolis_accept(u, __dmul_rn(beta, de)));
+#else
             accept = valid && (de <= 0.0 || u < expneg(__dmul_rn(beta, de)));
+#endif
 #endif
           }
           if (accept) {
