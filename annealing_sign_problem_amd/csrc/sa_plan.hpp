@@ -2,7 +2,7 @@
 // layout the gfx950 sweep kernel streams.
 //
 //   A = offdiag(J + J^T) (exact zeros dropped)          -> dE_i = -2 s_i (sum_j A_ij s_j + h_i)
-//   greedy first-fit colouring of A's graph, index order -> same-colour spins are independent
+//   DSATUR colouring of A's graph                        -> same-colour spins are independent
 //   permutation by (colour, degree desc, index)          -> a colour class is a run of 64-row blocks
 //   sliced ELL: block b has width w_b (multiple of 4) and starts at slab ell_off[b]; entries
 //   are stored quad-interleaved (four consecutive k of a lane adjacent, see sa_plan.cpp) so a

@@ -752,10 +752,13 @@ void choose_launch(const asp_sa_plan *p, uint32_t repetitions, int *m_out, int *
   }
   int threads = p->force_threads;
   if (!threads) {
-    const uint32_t colors = p->host.num_colors ? p->host.num_colors : 1;
-    uint32_t per_color = (p->host.num_blocks + colors - 1) / colors;
-    per_color = std::min<uint32_t>(std::max<uint32_t>(per_color, 1), 16);
-    threads = static_cast<int>(per_color) * 64;
+    // one wavefront per block of the LARGEST colour class (first-fit classes are skewed, the
+    // first is the biggest), at most 16
+    uint32_t widest = 1;
+    for (uint32_t c = 0; c < p->host.num_colors; ++c) {
+      widest = std::max(widest, p->host.color_block_start[c + 1] - p->host.color_block_start[c]);
+    }
+    threads = static_cast<int>(std::min<uint32_t>(widest, 16)) * 64;
   }
   *m_out = m;
   *threads_out = threads;

@@ -144,7 +144,7 @@ typedef struct asp_sa_plan asp_sa_plan;
  * sum_i h_i s_i.  J is a square CSR matrix with sorted, duplicate-free column
  * indices per row (scipy "canonical format"); it may carry a diagonal and need
  * not be symmetric (the sweep uses J + J^T).  Host preprocessing: symmetrised
- * off-diagonal part, greedy first-fit colouring, colour-major permutation,
+ * off-diagonal part, DSATUR colouring, colour-major permutation,
  * 64-row sliced-ELL slabs; all uploaded once.  NULL on failure. */
 asp_sa_plan *asp_sa_plan_create(uint64_t num_spins, int64_t const *indptr,
                                 int32_t const *indices, double const *data,

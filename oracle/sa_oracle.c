@@ -101,7 +101,7 @@ typedef struct sa_problem {
   int32_t *a_col;
   double *a_val;
   double diag_sum;  /* sum_i J_ii */
-  int32_t *color;   /* greedy first-fit colour of every spin */
+  int32_t *color;   /* DSATUR colour of every spin */
   int32_t num_colors;
   int64_t *order;   /* permutation: position -> spin; key (colour, -degree, index) */
   int64_t *color_start; /* num_colors + 1 offsets into `order` */
@@ -165,22 +165,62 @@ static int sa_problem_init(sa_problem *p, uint64_t n, int64_t const *indptr,
   p->diag_sum = diag;
   free(t_ptr); free(t_col); free(t_val);
 
-  /* greedy first-fit colouring in index order */
+  /* DSATUR colouring: next spin = most distinct neighbour colours, then
+   * larger degree, then smaller index; colour = smallest one no neighbour has.  Own binary
+   * heap of (saturation, degree, index) records with lazy invalidation. */
   p->color = malloc((size_t)(n ? n : 1) * sizeof *p->color);
-  int32_t *mark = malloc((size_t)(n + 1) * sizeof *mark);
-  for (uint64_t i = 0; i <= n; ++i) mark[i] = -1;
   int32_t ncol = 0;
-  for (uint64_t i = 0; i < n; ++i) {
-    for (int64_t k = p->a_ptr[i]; k < p->a_ptr[i + 1]; ++k) {
-      int32_t const j = p->a_col[k];
-      if ((uint64_t)j < i) mark[p->color[j]] = (int32_t)i;
+  {
+    int64_t maxd = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+      int64_t const d = p->a_ptr[i + 1] - p->a_ptr[i];
+      if (d > maxd) maxd = d;
     }
-    int32_t c = 0;
-    while (mark[c] == (int32_t)i) ++c;
-    p->color[i] = c;
-    if (c + 1 > ncol) ncol = c + 1;
+    size_t const cap_colors = (size_t)maxd + 2;
+    /* has[v * cap_colors + c] = 1 when a neighbour of v already has colour c */
+    uint8_t *has = calloc((size_t)(n ? n : 1) * cap_colors, 1);
+    int32_t *sat = calloc(n + 1, sizeof *sat);
+    typedef struct { int32_t sat, deg, idx; } rec;
+    size_t heap_cap = (size_t)(n + p->a_ptr[n] + 8), heap_n = 0;
+    rec *heap = malloc(heap_cap * sizeof *heap);
+#define REC_ABOVE(x, y) ((x).sat != (y).sat ? (x).sat > (y).sat : ((x).deg != (y).deg ? (x).deg > (y).deg : (x).idx < (y).idx))
+#define HEAP_PUSH(r) do { size_t c_ = heap_n++; heap[c_] = (r); \
+      while (c_ > 0) { size_t u_ = (c_ - 1) / 2; if (!REC_ABOVE(heap[c_], heap[u_])) break; \
+        rec t_ = heap[c_]; heap[c_] = heap[u_]; heap[u_] = t_; c_ = u_; } } while (0)
+    for (uint64_t i = 0; i < n; ++i) {
+      p->color[i] = -1;
+      rec r = {0, (int32_t)(p->a_ptr[i + 1] - p->a_ptr[i]), (int32_t)i};
+      HEAP_PUSH(r);
+    }
+    while (heap_n > 0) {
+      rec const top = heap[0];
+      heap[0] = heap[--heap_n];
+      for (size_t c_ = 0;;) { /* sift down */
+        size_t l_ = 2 * c_ + 1, r_ = l_ + 1, m_ = c_;
+        if (l_ < heap_n && REC_ABOVE(heap[l_], heap[m_])) m_ = l_;
+        if (r_ < heap_n && REC_ABOVE(heap[r_], heap[m_])) m_ = r_;
+        if (m_ == c_) break;
+        rec t_ = heap[c_]; heap[c_] = heap[m_]; heap[m_] = t_; c_ = m_;
+      }
+      int32_t const v = top.idx;
+      if (p->color[v] >= 0 || top.sat != sat[v]) continue;
+      int32_t c = 0;
+      while (has[(size_t)v * cap_colors + (size_t)c]) ++c;
+      p->color[v] = c;
+      if (c + 1 > ncol) ncol = c + 1;
+      for (int64_t k = p->a_ptr[v]; k < p->a_ptr[v + 1]; ++k) {
+        int32_t const u = p->a_col[k];
+        if (p->color[u] >= 0 || has[(size_t)u * cap_colors + (size_t)c]) continue;
+        has[(size_t)u * cap_colors + (size_t)c] = 1;
+        sat[u] += 1;
+        rec r = {sat[u], (int32_t)(p->a_ptr[u + 1] - p->a_ptr[u]), u};
+        HEAP_PUSH(r);
+      }
+    }
+#undef HEAP_PUSH
+#undef REC_ABOVE
+    free(heap); free(sat); free(has);
   }
-  free(mark);
   p->num_colors = ncol;
 
   /* permutation: colour ascending, degree descending, index ascending.

@@ -71,11 +71,30 @@ def test_layout_is_a_proper_colouring_and_permutation():
     assert sorted(order.tolist()) == list(range(1500))            # permutation
     assert np.all(np.diff(colors[order]) >= 0) and ncol == colors.max() + 1
     assert nnz == A.nnz and abs(diag - J.diagonal().sum()) < 1e-12
-    # first-fit: every spin's colour is the smallest not used by lower-indexed neighbours
+    # DSATUR, restated in Python with the same tie-breaks: most distinct
+    # neighbour colours, then larger degree, then smaller index; smallest free colour
+    import heapq
+
     indptr, idx = A.indptr, A.indices
-    for i in range(0, 1500, 37):
-        used = {colors[j] for j in idx[indptr[i]:indptr[i + 1]] if j < i}
-        assert colors[i] == min(c for c in range(ncol + 1) if c not in used)
+    n = 1500
+    deg = np.diff(indptr)
+    col = np.full(n, -1)
+    seen = [set() for _ in range(n)]
+    heap = [(0, -int(deg[i]), i) for i in range(n)]
+    heapq.heapify(heap)
+    while heap:
+        s_neg, _, v = heapq.heappop(heap)
+        if col[v] >= 0 or -s_neg != len(seen[v]):
+            continue
+        c = 0
+        while c in seen[v]:
+            c += 1
+        col[v] = c
+        for u in idx[indptr[v]:indptr[v + 1]]:
+            if col[u] < 0 and c not in seen[u]:
+                seen[u].add(c)
+                heapq.heappush(heap, (-len(seen[u]), -int(deg[u]), int(u)))
+    assert np.array_equal(col, colors)
 
 
 def test_chain_single_spin_first_principles():
