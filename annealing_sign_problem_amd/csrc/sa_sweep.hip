@@ -8,18 +8,24 @@
 //     (all sweeps) is ONE launch, the spins never leave LDS;
 //   * LDS: one byte per (padded) spin position, bit m = sign bit of replica m
 //     (1 means s = -1), so one ds_read_u8 serves all M replicas of a neighbour;
+//     beyond the capacity of that layout, one BIT per position and one replica
+//     per workgroup (PACKED), flips applied by a wavefront ballot;
 //   * a wavefront owns a 64-row block of one colour class: lane = spin.  Same
 //     colour means no couplings inside the block, so the 64 x M proposals of a
 //     block are independent and are decided at once;
-//   * couplings stream from the sliced-ELL slabs: per k one coalesced 256-B
-//     column read and one 512-B value read per wavefront, shared by M replicas;
+//   * couplings stream from the quad-interleaved sliced ELL: per four terms a
+//     lane issues three 16-byte loads (every wavefront instruction covers 1 KiB
+//     of contiguous memory), shared by M replicas, one quad prefetched ahead;
 //   * dE is an f64 sum in fixed row order (bit-exact against the oracle), the
 //     acceptance uses a counter-based Philox4x32-10 word per (spin, sweep,
-//     replica) and a fixed-sequence exp, accepted flips are XOR-ed into LDS;
+//     replica) and a fixed-sequence exp reached through a hardware-exp filter,
+//     accepted flips are XOR-ed into LDS;
 //   * the running energy of each replica is tracked exactly in 2^-S fixed point
 //     (integer adds commute, so the parallel reduction is deterministic); the
-//     best configuration is snapshotted to HBM at sweep granularity.
-// Memory/latency-bound integer+f64 work: no MFMA.
+//     best configuration is snapshotted to HBM at sweep granularity;
+//   * DESCENT instantiation: strict-descent sweeps without random numbers (the
+//     greedy solver's relaxation).
+// f64-VALU- and vector-memory-bound integer+f64 work: no MFMA.
 #include <algorithm>
 #include <cmath>
 #include <initializer_list>
