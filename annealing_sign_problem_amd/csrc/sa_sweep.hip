@@ -28,6 +28,7 @@
 // f64-VALU- and vector-memory-bound integer+f64 work: no MFMA.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <initializer_list>
 #include <vector>
 
@@ -43,9 +44,6 @@
 #endif
 #ifndef ASP_EXP_FILTER
 #define ASP_EXP_FILTER 1
-#endif
-#ifndef ASP_PREFETCH_DEPTH
-#define ASP_PREFETCH_DEPTH 2
 #endif
 // Timing-only ablations (results are WRONG when any is set; never set in the product build).
 #ifndef ASP_ABL_NO_ACCEPT
@@ -279,6 +277,10 @@ struct SweepArgs {
   uint64_t seed;
   double scale;  // 2^S
   uint32_t num_colors, num_blocks, num_sweeps, replica_first;
+  // Field cache (nullptr = off): [group][block][m][lane] local fields (the row sums `acc`) of the
+  // last evaluation of every block, valid while the block's dirty byte in LDS is clear.
+  double *field_cache;
+  uint32_t cache_enter_flips;  // switch the cache on after a sweep with fewer flips than this
 };
 
 template <int M, bool PACKED>
@@ -326,6 +328,12 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
   long long *book = delta + 8;
   uint32_t *improved_flag = reinterpret_cast<uint32_t *>(book + 24);
   uint2 *meta = reinterpret_cast<uint2 *>(book + 26);  // per block {first ELL slab, width}
+  // cache control: [0] flips of the running sweep, [1] 1 while the field cache is in use,
+  // [2] 1 when the cache was just switched on (dirty bytes must be set);
+  // then one dirty byte per block (bit m: replica m's cached fields are stale)
+  uint32_t *cache_ctl = reinterpret_cast<uint32_t *>(meta + a.num_blocks);
+  uint8_t *dirty = reinterpret_cast<uint8_t *>(cache_ctl + 4);
+  const bool cache_available = !PACKED && a.field_cache != nullptr;
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -370,13 +378,20 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
     meta[b] = make_uint2(static_cast<uint32_t>(a.ell_off[b]), a.block_width[b]);
   }
   if (tid < 32) delta[tid] = 0;  // delta[8] + book[24]
-  if (tid == 0) *improved_flag = 0;
+  if (tid == 0) {
+    *improved_flag = 0;
+    cache_ctl[0] = 0;
+    cache_ctl[1] = 0;
+    cache_ctl[2] = 0;
+  }
   __syncthreads();
   snapshot<M, PACKED>(spins, a, group, (1u << M) - 1u);
   __syncthreads();
 
   for (uint32_t t = 0; t < a.num_sweeps; ++t) {
     const double beta = a.betas[t];
+    // wave-uniform: cached fields are in use during this sweep
+    const bool cached = cache_available && __builtin_amdgcn_readfirstlane(cache_ctl[1]) != 0;
     long long q_acc[M];
     uint32_t n_acc[M];  // accepted flips of this lane in this sweep (< 2^32 blocks per sweep)
 #pragma unroll
@@ -413,48 +428,35 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
         const uint32_t spin = a.spin_of_pos[p];
         const double h = a.field_pos[p];
         double acc[M];
+        // Field cache: when the workgroup is in cached mode and no neighbour of this block's
+        // spins has flipped since the block was last evaluated (dirty byte clear), the row
+        // sums are read back from HBM — the very same f64 values the k-loop would produce.
+        double *cache_row = nullptr;
+        bool reuse = false;
+        if (cached) {
+          cache_row = a.field_cache +
+                      ((static_cast<uint64_t>(group) * a.num_blocks + b) * M) * 64u + lane;
+          reuse = (__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(dirty[b])) &
+                   ((1u << M) - 1u)) == 0u;
+        }
+        if (reuse) {
 #pragma unroll
-        for (int m = 0; m < M; ++m) acc[m] = 0.0;
-        // Double-buffered k-loop: the next four (column, value) pairs are in flight while
-        // the current four are gathered from LDS and accumulated, in the order k = 0, 1, ...
-        // of the oracle.  The body has no conditional loads (hipcc would otherwise drain the
-        // queue with vmcnt(0) at the loop header): for an even quad count the last load
-        // reads one quad past the block — the next block's first slabs or the four slabs of
-        // tail padding the plan appends — and is never consumed.
-#if ASP_ABL_NO_KLOOP
-        const uint32_t quads_run = 0;
-        (void)quads;
-        (void)cptr;
-        (void)vptr;
-#else
-        const uint32_t quads_run = quads;
-#endif
-        if constexpr (M <= 4 && ASP_PREFETCH_DEPTH == 2) {
-          // Prefetch distance two: three register buffers rotate, so a quad's loads have two
-          // accumulate phases (of this wave, plus whatever the other waves of the SIMD issue)
-          // to land.  Up to two quads past the block are read and never consumed.
-          Quad q0, q1, q2;
-          load_quad(q0, cptr, vptr, 0);
-          load_quad(q1, cptr, vptr, 1);
-          uint32_t i = 0;
-          for (; i + 3 <= quads_run; i += 3) {
-            load_quad(q2, cptr, vptr, i + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            accumulate_quad<M, PACKED>(q0, spins, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            load_quad(q0, cptr, vptr, i + 3);
-            __builtin_amdgcn_sched_barrier(0);
-            accumulate_quad<M, PACKED>(q1, spins, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            load_quad(q1, cptr, vptr, i + 4);
-            __builtin_amdgcn_sched_barrier(0);
-            accumulate_quad<M, PACKED>(q2, spins, acc);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          if (i < quads_run) accumulate_quad<M, PACKED>(q0, spins, acc);
-          if (i + 1 < quads_run) accumulate_quad<M, PACKED>(q1, spins, acc);
+          for (int m = 0; m < M; ++m) acc[m] = cache_row[m * 64];
         } else {
-          // M = 8 has no registers to spare: prefetch distance one (two buffers)
+#pragma unroll
+          for (int m = 0; m < M; ++m) acc[m] = 0.0;
+#if ASP_ABL_NO_KLOOP
+          const uint32_t quads_run = 0;
+#else
+          const uint32_t quads_run = quads;
+#endif
+          // k-loop, prefetch distance one: the next quad's three 16-byte loads are in flight
+          // while the current quad is gathered from LDS and accumulated, in the oracle's order
+          // k = 0, 1, 2, ...  Loop control is scalar and the body has no conditional loads
+          // (hipcc would otherwise drain the queue with vmcnt(0) at the loop header);
+          // sched_barrier keeps each load group ahead of the accumulate it overlaps.  For an
+          // even quad count the last load reads one quad past the block — the next block's
+          // first slabs or the tail padding the plan appends — and is never consumed.
           Quad qa, qb;
           load_quad(qa, cptr, vptr, 0);
           uint32_t i = 0;
@@ -469,6 +471,11 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
             __builtin_amdgcn_sched_barrier(0);
           }
           if (i < quads_run) accumulate_quad<M, PACKED>(qa, spins, acc);
+          if (cached) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) cache_row[m * 64] = acc[m];
+            if (lane == 0) dirty[b] = 0;  // nobody marks a block during its own colour step
+          }
         }
         const bool valid = spin != kDummySpin;
         uint32_t own;
@@ -533,6 +540,24 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
         } else {
           if (flip) spins[p] = static_cast<uint8_t>(own ^ flip);
         }
+        if (cached && __ballot(flip != 0) != 0ull) {
+          // Every neighbour of a flipped spin sits in a block of ANOTHER colour: mark those
+          // blocks stale for the replicas that flipped.  The row's columns are streamed again
+          // (columns only); in cached mode flips are rare by construction.
+          uint32_t *dirty_words = reinterpret_cast<uint32_t *>(dirty);
+          for (uint32_t q = 0; q < quads; ++q) {
+            const uint4 c4 = cptr[q * 64u];
+            if (flip) {
+              const uint32_t cols[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                if (cols[j] == p) continue;  // padding entry (points at the lane itself)
+                const uint32_t blk = cols[j] >> 6;
+                atomicOr(&dirty_words[blk >> 2], flip << (8u * (blk & 3u)));
+              }
+            }
+          }
+        }
       }
 #if !ASP_ABL_NO_BARRIER
       __syncthreads();
@@ -549,9 +574,20 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
                   static_cast<unsigned long long>(v));
         atomicAdd(reinterpret_cast<unsigned long long *>(&book[16 + m]),
                   static_cast<unsigned long long>(n));
+        if (cache_available) atomicAdd(&cache_ctl[0], static_cast<uint32_t>(n));
       }
     }
     __syncthreads();
+    if (cache_available && tid == 0) {
+      // Cached mode pays when the flips of a sweep dirty only a fraction of the blocks:
+      // enter below `cache_enter_flips` flips per sweep, leave above twice that.
+      const uint32_t flips = cache_ctl[0];
+      cache_ctl[0] = 0;
+      const bool was = cache_ctl[1] != 0;
+      const bool now = was ? flips < 2u * a.cache_enter_flips : flips < a.cache_enter_flips;
+      cache_ctl[1] = now ? 1u : 0u;
+      cache_ctl[2] = (now && !was) ? 1u : 0u;  // entering: every block starts stale
+    }
     if (tid < M) {
       const long long e = book[tid] + delta[tid];
       book[tid] = e;
@@ -564,8 +600,14 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
     __syncthreads();
     const uint32_t improved = DESCENT ? ((1u << M) - 1u) : *improved_flag;
     if (improved) snapshot<M, PACKED>(spins, a, group, improved);
+    if (cache_available && cache_ctl[2] != 0) {
+      for (uint32_t b = tid; b < a.num_blocks; b += blockDim.x) dirty[b] = 0xFF;
+    }
     __syncthreads();
-    if (tid == 0) *improved_flag = 0;  // next write to it is two barriers away
+    if (tid == 0) {
+      *improved_flag = 0;  // next write to it is two barriers away
+      if (cache_available) cache_ctl[2] = 0;
+    }
   }
 
   if (tid < M) {
@@ -713,6 +755,8 @@ struct asp_sa_plan {
   DeviceBuffer<uint64_t> w_best, w_x0, w_x0_perm, w_x;
   DeviceBuffer<long long> w_tracked;
   DeviceBuffer<unsigned long long> w_accepted;
+  DeviceBuffer<double> w_field_cache;  // [groups][blocks][M][64], see SweepArgs::field_cache
+  bool use_field_cache = true;
 };
 
 namespace {
@@ -738,8 +782,10 @@ SweepKernel sweep_kernel_for(int m, bool descent, bool packed) {
 
 size_t sweep_lds_bytes(const asp::SaHostLayout &L, bool packed) {
   // spins | delta[8] book[24] | flag (16 B) | meta[num_blocks]
+  // ... | cache_ctl[4] | dirty[num_blocks] (rounded up to 16 B)
   return static_cast<size_t>(L.num_blocks) * (packed ? 8 : 64) + 34 * sizeof(long long) +
-         static_cast<size_t>(L.num_blocks) * sizeof(uint2);
+         static_cast<size_t>(L.num_blocks) * sizeof(uint2) + 16 +
+         ((static_cast<size_t>(L.num_blocks) + 15) / 16) * 16;
 }
 
 // Launch geometry: as many replicas per group as still leaves one group per CU,
@@ -879,6 +925,12 @@ int asp_sa_set_launch(asp_sa_plan *p, int replicas_per_group, int threads) {
   return ASP_OK;
 }
 
+int asp_sa_set_field_cache(asp_sa_plan *p, int enable) {
+  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  p->use_field_cache = enable != 0;
+  return ASP_OK;
+}
+
 int asp_sa_set_packed(asp_sa_plan *p, int packed) {
   if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
   p->force_packed = packed != 0;
@@ -976,6 +1028,23 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
   args.num_blocks = L.num_blocks;
   args.num_sweeps = num_sweeps;
   args.replica_first = replica_offset;
+  args.field_cache = nullptr;
+  args.cache_enter_flips = 0;
+  if (p->use_field_cache && !packed) {
+    // 512 B per block and replica; skipped when it would not fit comfortably in HBM
+    const uint64_t cache_elems = padded * L.num_blocks * 64ull;
+    if (cache_elems * sizeof(double) <= (32ull << 30) && p->w_field_cache.ensure(cache_elems) == ASP_OK) {
+      args.field_cache = p->w_field_cache.ptr;
+      // a flip stales ~degree blocks: cached mode pays while that is a fraction of all blocks
+      const double degree = std::max(1.0, static_cast<double>(L.a_col.size()) / static_cast<double>(K));
+      double factor = 0.7;
+      if (const char *env = std::getenv("ASP_CACHE_FACTOR")) factor = std::atof(env);  // tuning aid
+      args.cache_enter_flips =
+          static_cast<uint32_t>(std::max(1.0, factor * static_cast<double>(L.num_blocks) / degree));
+    } else {
+      asp_clear_error();  // the cache is an optimisation: run without it
+    }
+  }
 
   SweepKernel kernel = sweep_kernel_for(m, descent, packed);
   if (lds > 64 * 1024) {

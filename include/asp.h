@@ -182,6 +182,11 @@ int asp_sa_set_launch(asp_sa_plan *p, int replicas_per_group, int threads);
  * bit-packed layout (tests, measurements).  Results never depend on the layout. */
 int asp_sa_set_packed(asp_sa_plan *p, int packed);
 
+/* Field cache (default on): once a sweep flips few spins, a workgroup keeps the local fields
+ * of every block in HBM and re-evaluates a block only after one of its neighbours flipped.
+ * Pure optimisation of frozen sweeps; results are identical with it on or off. */
+int asp_sa_set_field_cache(asp_sa_plan *p, int enable);
+
 /* Run `repetitions` independent annealing chains (global replica ids
  * replica_offset .. replica_offset+repetitions-1) of num_sweeps sweeps, sweep t
  * at inverse temperature betas[t].  x0 == NULL: random initial spins from the

@@ -264,3 +264,39 @@ def test_beyond_byte_layout_capacity():
         assert abs(es[r] - ref) <= 1e-12 * abs(ref)
     oxs, oes, _, _ = oracle.sa_anneal(J, h, 77, betas, 2, 0, None, info.energy_scale_exp, num_threads=2)
     assert np.array_equal(xs[:2], oxs) and es[:2].tobytes() == oes.tobytes()
+
+
+def _set_cache(h, enable):
+    from annealing_sign_problem_amd import _lib
+
+    _lib.check(_lib.load().asp_sa_set_field_cache(h.plan(), int(enable)))
+
+
+@pytest.mark.parametrize("m,threads", [(1, 128), (4, 512), (8, 1024)])
+def test_field_cache_in_frozen_tail_is_exact(m, threads):
+    """A ladder with a long frozen tail drives the workgroups into cached mode (local fields
+    kept in HBM, re-evaluated only after a neighbour flipped).  Chains must equal the oracle's
+    and the cache-off run bit for bit, including chains that still flip occasionally."""
+    from annealing_sign_problem_amd import annealer as sa
+
+    J, h, _ = _planted(4000, 31)
+    field = np.random.default_rng(7).normal(size=4000) * 1e-4
+    betas = np.concatenate([np.geomspace(0.5, 3e3, 25), np.geomspace(3e3, 1e11, 150)])
+    ham = sa.Hamiltonian(J, field)
+    _set_launch(ham, m, threads)
+    xs, es = sa.anneal_raw(ham, 2024, betas, 16, 5)
+    tracked, accepted = _stats(ham, 16)
+    _set_cache(ham, False)
+    xs_off, es_off = sa.anneal_raw(ham, 2024, betas, 16, 5)
+    tracked_off, accepted_off = _stats(ham, 16)
+    assert np.array_equal(xs, xs_off) and es.tobytes() == es_off.tobytes()
+    assert np.array_equal(tracked, tracked_off) and np.array_equal(accepted, accepted_off)
+    oxs, oes, otr, oacc = oracle.sa_anneal(J, field, 2024, betas, 16, 5, None,
+                                           ham.info().energy_scale_exp, num_threads=8)
+    assert np.array_equal(accepted, oacc) and np.array_equal(tracked, otr)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    # the tail really is frozen for most chains but not dead: some flips happen after sweep 100
+    _, _, _, acc_head = oracle.sa_anneal(J, field, 2024, betas[:100], 16, 5, None,
+                                         ham.info().energy_scale_exp, num_threads=8)
+    late = oacc.astype(np.int64) - acc_head.astype(np.int64)
+    assert late.sum() > 0 and late.max() < 4000
