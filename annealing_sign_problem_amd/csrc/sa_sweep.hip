@@ -45,6 +45,9 @@
 #ifndef ASP_EXP_FILTER
 #define ASP_EXP_FILTER 1
 #endif
+#ifndef ASP_INERT_SKIP
+#define ASP_INERT_SKIP 1
+#endif
 // Timing-only ablations (results are WRONG when any is set; never set in the product build).
 #ifndef ASP_ABL_NO_ACCEPT
 #define ASP_ABL_NO_ACCEPT 0
@@ -333,6 +336,10 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
   // then one dirty byte per block (bit m: replica m's cached fields are stale)
   uint32_t *cache_ctl = reinterpret_cast<uint32_t *>(meta + a.num_blocks);
   uint8_t *dirty = reinterpret_cast<uint8_t *>(cache_ctl + 4);
+  // one "inert" byte per block, meaningful while the dirty byte is clear: at the block's last
+  // evaluation every proposal was a certain rejection (beta * dE >= 23 -> expneg = 0, or
+  // dE >= 0 in descent mode) and beta has not decreased since, so the visit can be skipped
+  uint8_t *inert = dirty + ((a.num_blocks + 15u) & ~15u);
   const bool cache_available = !PACKED && a.field_cache != nullptr;
 
   const uint32_t tid = threadIdx.x;
@@ -392,6 +399,11 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
     const double beta = a.betas[t];
     // wave-uniform: cached fields are in use during this sweep
     const bool cached = cache_available && __builtin_amdgcn_readfirstlane(cache_ctl[1]) != 0;
+    if (cached && t > 0 && beta < a.betas[t - 1]) {
+      // certain rejections are only certain for non-decreasing beta (workgroup-uniform branch)
+      for (uint32_t b = tid; b < a.num_blocks; b += blockDim.x) inert[b] = 0;
+      __syncthreads();
+    }
     long long q_acc[M];
     uint32_t n_acc[M];  // accepted flips of this lane in this sweep (< 2^32 blocks per sweep)
 #pragma unroll
@@ -416,6 +428,17 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
       for (uint32_t b = b_begin + wave; b < b_end; b += waves) {
 #endif
         const uint32_t p = b * 64u + lane;
+        bool reuse = false;
+        if (cached) {
+          reuse = (__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(dirty[b])) &
+                   ((1u << M) - 1u)) == 0u;
+#if ASP_INERT_SKIP
+          // fields unchanged and every proposal certain to be rejected again: nothing to do
+          if (reuse && __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(inert[b])) != 0u) {
+            continue;
+          }
+#endif
+        }
         const uint2 info = meta[b];  // {first slab, width}: one broadcast LDS read
         // wave-uniform by construction; readfirstlane makes the loop control scalar
         const uint32_t quads = __builtin_amdgcn_readfirstlane(info.y) >> 2;
@@ -432,12 +455,9 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
         // spins has flipped since the block was last evaluated (dirty byte clear), the row
         // sums are read back from HBM — the very same f64 values the k-loop would produce.
         double *cache_row = nullptr;
-        bool reuse = false;
         if (cached) {
           cache_row = a.field_cache +
                       ((static_cast<uint64_t>(group) * a.num_blocks + b) * M) * 64u + lane;
-          reuse = (__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(dirty[b])) &
-                   ((1u << M) - 1u)) == 0u;
         }
         if (reuse) {
 #pragma unroll
@@ -485,6 +505,7 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
           own = spins[p];
         }
         uint32_t flip = 0;
+        bool open = false;  // some proposal of this lane is not a certain rejection
         Philox4 rnd{};
         uint32_t have = 0xFFFFFFFFu;
 #pragma unroll
@@ -495,7 +516,9 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
           bool accept;
           if constexpr (DESCENT) {
             accept = valid && de < 0.0;
+            open = open || accept;
           } else {
+            open = open || (valid && !(__dmul_rn(beta, de) >= 23.0));
             const uint32_t r = r0 + m;
             if (m == 0 || (r >> 2) != have) {
               have = r >> 2;
@@ -540,6 +563,12 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
         } else {
           if (flip) spins[p] = static_cast<uint8_t>(own ^ flip);
         }
+#if ASP_INERT_SKIP
+        if (cached) {
+          const bool none_open = __ballot(open) == 0ull;
+          if (lane == 0) inert[b] = none_open ? 1 : 0;
+        }
+#endif
         if (cached && __ballot(flip != 0) != 0ull) {
           // Every neighbour of a flipped spin sits in a block of ANOTHER colour: mark those
           // blocks stale for the replicas that flipped.  The row's columns are streamed again
@@ -782,10 +811,10 @@ SweepKernel sweep_kernel_for(int m, bool descent, bool packed) {
 
 size_t sweep_lds_bytes(const asp::SaHostLayout &L, bool packed) {
   // spins | delta[8] book[24] | flag (16 B) | meta[num_blocks]
-  // ... | cache_ctl[4] | dirty[num_blocks] (rounded up to 16 B)
+  // ... | cache_ctl[4] | dirty[num_blocks] | inert[num_blocks] (each rounded up to 16 B)
   return static_cast<size_t>(L.num_blocks) * (packed ? 8 : 64) + 34 * sizeof(long long) +
          static_cast<size_t>(L.num_blocks) * sizeof(uint2) + 16 +
-         ((static_cast<size_t>(L.num_blocks) + 15) / 16) * 16;
+         2 * (((static_cast<size_t>(L.num_blocks) + 15) / 16) * 16);
 }
 
 // Launch geometry: as many replicas per group as still leaves one group per CU,

@@ -300,3 +300,32 @@ def test_field_cache_in_frozen_tail_is_exact(m, threads):
                                          ham.info().energy_scale_exp, num_threads=8)
     late = oacc.astype(np.int64) - acc_head.astype(np.int64)
     assert late.sum() > 0 and late.max() < 4000
+
+
+@pytest.mark.parametrize("m,threads", [(2, 256), (4, 1024)])
+def test_field_cache_survives_reheating(m, threads):
+    """Blocks whose proposals were all certain rejections are skipped while their fields are
+    clean — valid only for non-decreasing beta.  A schedule that freezes, reheats and freezes
+    again must still follow the oracle bit for bit."""
+    from annealing_sign_problem_amd import annealer as sa
+
+    J, h, _ = _planted(3000, 5)
+    field = np.random.default_rng(11).normal(size=3000) * 1e-4
+    freeze = np.geomspace(1.0, 1e12, 60)
+    betas = np.concatenate([freeze, np.full(10, 1e12), np.geomspace(1e12, 2e2, 6),
+                            np.geomspace(2e2, 1e12, 40), [1e3, 1e12, 1e12, 1e5, 1e12]])
+    ham = sa.Hamiltonian(J, field)
+    _set_launch(ham, m, threads)
+    xs, es = sa.anneal_raw(ham, 99, betas, 8, 3)
+    tracked, accepted = _stats(ham, 8)
+    oxs, oes, otr, oacc = oracle.sa_anneal(J, field, 99, betas, 8, 3, None,
+                                           ham.info().energy_scale_exp, num_threads=8)
+    assert np.array_equal(accepted, oacc) and np.array_equal(tracked, otr)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    # the reheating really unfreezes chains that were dead at the end of the first freeze
+    _, _, _, acc_a = oracle.sa_anneal(J, field, 99, betas[:70], 8, 3, None,
+                                      ham.info().energy_scale_exp, num_threads=8)
+    _, _, _, acc_b = oracle.sa_anneal(J, field, 99, betas[:60], 8, 3, None,
+                                      ham.info().energy_scale_exp, num_threads=8)
+    assert np.array_equal(acc_a, acc_b)            # sweeps 60..69: nothing moves
+    assert (oacc.astype(np.int64) - acc_a.astype(np.int64)).min() > 100
