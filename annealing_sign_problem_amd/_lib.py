@@ -66,6 +66,18 @@ SIGNATURES = {
     "asp_build_destroy": (None, [c_void_p]),
     "asp_ising_elements": (c_int, [c_u64, c_void_p, c_void_p, c_u64] + [c_void_p] * 7),
     "asp_ising_elements_last_ms": (c_float, []),
+    "asp_operator_create": (c_int, [ctypes.c_uint32, ctypes.c_uint32, c_void_p, c_void_p, c_void_p,
+                                    ctypes.POINTER(c_void_p)]),
+    "asp_operator_destroy": (None, [c_void_p]),
+    "asp_operator_unique_targets": (c_int, [c_void_p]),
+    "asp_operator_max_connections": (ctypes.c_uint32, [c_void_p]),
+    "asp_operator_apply": (c_int, [c_void_p, c_u64, c_void_p, c_u64, c_void_p, c_void_p, c_void_p,
+                                   ctypes.POINTER(c_u64)]),
+    "asp_operator_ising": (c_int, [c_void_p, c_u64, c_void_p, c_void_p, c_u64, c_void_p, c_void_p,
+                                   c_void_p, ctypes.POINTER(c_u64)]),
+    "asp_operator_extend": (c_int, [c_void_p, c_u64, c_void_p, c_u64, c_void_p,
+                                    ctypes.POINTER(c_u64)]),
+    "asp_operator_last_ms": (c_float, []),
     "asp_sa_plan_create": (c_void_p, [c_u64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "asp_sa_plan_destroy": (None, [c_void_p]),
     "asp_sa_plan_info": (c_int, [c_void_p, ctypes.POINTER(SaInfo)]),

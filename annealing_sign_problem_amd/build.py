@@ -28,6 +28,7 @@ SOURCES = [
     "asp_common.hip",
     "build_matrix.hip",
     "ising_elements.hip",
+    "operator_apply.hip",
     "sa_plan.cpp",
     "greedy.cpp",
     "sa_sweep.hip",

@@ -60,11 +60,24 @@ def _normalize_spins(spins) -> np.ndarray:
     return as_bits512(spins)
 
 
+def _on_device(hamiltonian) -> bool:
+    """True for this package's symmetry-free operators with real matrices (the stand-in for
+    ``ls.Operator``): their action has a HIP implementation.  Foreign operator objects keep
+    the reference's route through their own ``batched_apply``."""
+    from . import operators
+
+    return isinstance(hamiltonian, operators.Operator) and hamiltonian.is_real
+
+
 def _batched_apply(hamiltonian, spins, chunk_size: int = APPLY_CHUNK):
     """Chunked ``hamiltonian.batched_apply`` returning flat
     ``(other_spins u64[N], other_coeffs f64[N], other_counts i64[K])`` (common.py:85-106)."""
     if hamiltonian.basis.number_spins > 64:
         raise AssertionError("TODO: only works with up to 64 bits")
+    if _on_device(hamiltonian):
+        # this package's own operator: the action runs on the GPU in one call
+        flat = np.ascontiguousarray(np.asarray(spins, dtype=np.uint64).reshape(len(spins), -1)[:, 0])
+        return hamiltonian.device().apply(flat)
     keys, coeffs, counts = [], [], []
     total = spins.shape[0]
     for start in range(0, total, chunk_size):
@@ -142,21 +155,25 @@ def make_ising_model(
         spins = np.ascontiguousarray(spins[:, 0])
     n = spins.shape[0]
 
-    other_spins, other_coeffs, other_counts = _batched_apply(quantum_hamiltonian, spins)
-
     psi = np.exp(log_psi, dtype=np.complex128)
     if not np.allclose(psi.imag, 0, atol=1e-6):
         raise ValueError("expected all wavefunction coefficients to be real")
     psi = np.ascontiguousarray(psi.real)
     psi /= np.linalg.norm(psi)
 
-    other_indices, _member, elements, offsets = ising_elements(
-        spins, psi, other_spins, other_coeffs, other_counts)
-
-    matrix = scipy.sparse.csr_matrix((elements, other_indices, offsets), shape=(n, n))
-    matrix = 0.5 * (matrix + matrix.T)
-    matrix.sort_indices()
-    matrix = matrix.tocoo()
+    if _on_device(quantum_hamiltonian) and quantum_hamiltonian.device().unique_targets:
+        # action, search, elements and (M + M^T)/2 fused in one pass on the GPU; the
+        # connections are never materialised (csrc/operator_apply.hip)
+        row, col, val = quantum_hamiltonian.device().ising(spins, psi)
+        matrix = scipy.sparse.coo_matrix((val, (row, col)), shape=(n, n))
+    else:
+        other_spins, other_coeffs, other_counts = _batched_apply(quantum_hamiltonian, spins)
+        other_indices, _member, elements, offsets = ising_elements(
+            spins, psi, other_spins, other_coeffs, other_counts)
+        matrix = scipy.sparse.csr_matrix((elements, other_indices, offsets), shape=(n, n))
+        matrix = 0.5 * (matrix + matrix.T)
+        matrix.sort_indices()
+        matrix = matrix.tocoo()
 
     field = np.zeros(n, dtype=np.float64)
     ising_hamiltonian = sa.Hamiltonian(matrix, field)
@@ -225,8 +242,11 @@ def solve_ising_model(
 
 def make_hamiltonian_extension(model: IsingModel, log_psi_fn) -> IsingModel:
     """One-hop extension of a cluster: every state connected to it (common.py:516-522)."""
-    spins, _, _ = _batched_apply(model.quantum_hamiltonian, model.spins)
-    spins = np.unique(spins, axis=0)
+    if _on_device(model.quantum_hamiltonian):
+        spins = model.quantum_hamiltonian.device().extend(model.spins)  # sorted and unique
+    else:
+        spins, _, _ = _batched_apply(model.quantum_hamiltonian, model.spins)
+        spins = np.unique(spins, axis=0)
     return make_ising_model(spins, model.quantum_hamiltonian, log_psi_fn=log_psi_fn)
 
 

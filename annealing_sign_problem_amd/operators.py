@@ -116,6 +116,28 @@ class Operator:
                  for t in config["hamiltonian"]["terms"]]
         return cls(basis, terms)
 
+    # -- the same action on the GPU --------------------------------------------
+    def bond_table(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """``(site_a u8[B], site_b u8[B], matrices f64[B, 16])`` in term order, then site-pair
+        order: the arguments of ``asp_operator_create`` (include/asp.h)."""
+        a = [x for t in self.terms for x, _ in t.sites]
+        b = [y for t in self.terms for _, y in t.sites]
+        m = [t.matrix.real.reshape(16) for t in self.terms for _ in t.sites]
+        return (np.asarray(a, dtype=np.uint8), np.asarray(b, dtype=np.uint8),
+                np.ascontiguousarray(np.asarray(m, dtype=np.float64).reshape(len(a), 16)))
+
+    @property
+    def is_real(self) -> bool:
+        return all(not np.any(t.matrix.imag) for t in self.terms)
+
+    def device(self) -> "DeviceOperator":
+        """HIP-side twin (created on first use; needs a GPU and real matrices)."""
+        if getattr(self, "_device", None) is None:
+            if not self.is_real:
+                raise ValueError("the HIP operator needs real matrices")
+            self._device = DeviceOperator(self.basis.number_spins, *self.bond_table())
+        return self._device
+
     # -- action on basis states ------------------------------------------------
     def batched_apply(self, spins):
         """``(other_spins (m, 8) u64, coeffs c128[m], counts i64[n])``: per input state one
@@ -192,3 +214,99 @@ class Operator:
         psi = vectors[:, 0]
         psi = psi * np.sign(psi[np.argmax(np.abs(psi))])
         return float(values[0]), np.ascontiguousarray(psi / np.linalg.norm(psi))
+
+
+class DeviceOperator:
+    """``asp_operator`` handle: Hamiltonian action, fused coupling build and one-hop extension
+    on the GPU (csrc/operator_apply.hip).  No CPU fallback: construction fails without a GPU."""
+
+    def __init__(self, number_spins: int, site_a: np.ndarray, site_b: np.ndarray,
+                 matrices: np.ndarray):
+        import ctypes
+
+        from . import _lib
+
+        self._lib_module = _lib
+        self._lib = _lib.load()
+        _lib.require_gpu()
+        handle = ctypes.c_void_p()
+        _lib.check(self._lib.asp_operator_create(
+            int(number_spins), int(site_a.shape[0]), _lib.ptr(site_a), _lib.ptr(site_b),
+            _lib.ptr(matrices), ctypes.byref(handle)))
+        self._handle = handle
+        self.number_spins = int(number_spins)
+        self.unique_targets = bool(self._lib.asp_operator_unique_targets(handle))
+        self.max_connections = int(self._lib.asp_operator_max_connections(handle))
+
+    def __del__(self):
+        handle, self._handle = getattr(self, "_handle", None), None
+        if handle:
+            try:
+                self._lib.asp_operator_destroy(handle)
+            except Exception:
+                pass
+
+    @property
+    def last_ms(self) -> float:
+        return float(self._lib.asp_operator_last_ms())
+
+    def apply(self, keys) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """Flat ``(other_keys u64[N], other_coeffs f64[N], other_counts i64[n])``."""
+        import ctypes
+
+        _lib = self._lib_module
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        n = keys.shape[0]
+        capacity = n * self.max_connections
+        other = np.empty(max(capacity, 1), dtype=np.uint64)
+        coeffs = np.empty(max(capacity, 1), dtype=np.float64)
+        counts = np.zeros(max(n, 1), dtype=np.int64)
+        total = ctypes.c_uint64(0)
+        _lib.check(self._lib.asp_operator_apply(self._handle, n, _lib.ptr(keys), capacity,
+                                                _lib.ptr(other), _lib.ptr(coeffs),
+                                                _lib.ptr(counts), ctypes.byref(total)))
+        t = int(total.value)
+        return other[:t].copy(), coeffs[:t].copy(), counts[:n]
+
+    def ising(self, keys, psi) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """COO ``(row i32, col i32, val f64)`` of ``0.5 * (M + M^T)`` sorted by (row, col)."""
+        import ctypes
+
+        _lib = self._lib_module
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        psi = np.ascontiguousarray(psi, dtype=np.float64)
+        if psi.shape != keys.shape:
+            raise ValueError("psi and keys differ in length")
+        k = keys.shape[0]
+        # rows hold at most max_connections entries unless a matrix has one-directional
+        # elements; then the library reports the size and the call is repeated
+        capacity = k * self.max_connections
+        nnz = ctypes.c_uint64(0)
+        while True:
+            row = np.empty(max(capacity, 1), dtype=np.int32)
+            col = np.empty(max(capacity, 1), dtype=np.int32)
+            val = np.empty(max(capacity, 1), dtype=np.float64)
+            rc = self._lib.asp_operator_ising(self._handle, k, _lib.ptr(keys), _lib.ptr(psi),
+                                              capacity, _lib.ptr(row), _lib.ptr(col),
+                                              _lib.ptr(val), ctypes.byref(nnz))
+            if rc != 0 and int(nnz.value) > capacity:
+                capacity = int(nnz.value)
+                continue
+            _lib.check(rc)
+            break
+        z = int(nnz.value)
+        return row[:z].copy(), col[:z].copy(), val[:z].copy()
+
+    def extend(self, keys) -> np.ndarray:
+        """Sorted unique union of the targets of ``keys`` (their own states included)."""
+        import ctypes
+
+        _lib = self._lib_module
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        n = keys.shape[0]
+        capacity = n * self.max_connections
+        out = np.empty(max(capacity, 1), dtype=np.uint64)
+        count = ctypes.c_uint64(0)
+        _lib.check(self._lib.asp_operator_extend(self._handle, n, _lib.ptr(keys), capacity,
+                                                 _lib.ptr(out), ctypes.byref(count)))
+        return out[:int(count.value)].copy()

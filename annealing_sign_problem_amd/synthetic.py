@@ -134,3 +134,71 @@ def load_models() -> Dict[str, dict]:
     in physical_systems/*.yaml, converted to JSON by tests/golden/generate_golden.py."""
     with open(os.path.join(_HERE, "models.json")) as f:
         return json.load(f)
+
+
+def kagome_lattice(l1: int = 4, l2: int = 3, coupling: float = 1.0) -> dict:
+    """Heisenberg model on an l1 x l2 periodic kagome lattice as a models.json-style config
+    (3 sites and 6 bonds per unit cell; 4 x 3 gives the 36 sites / 72 bonds of
+    physical_systems/heisenberg_kagome_36.yaml:30-37, here WITHOUT its lattice symmetries).
+    Site (x, y, s) has index 3 * (y * l1 + x) + s."""
+    def site(x, y, s):
+        return 3 * ((y % l2) * l1 + (x % l1)) + s
+
+    bonds = []
+    for y in range(l2):
+        for x in range(l1):
+            bonds += [(site(x, y, 0), site(x, y, 1)), (site(x, y, 0), site(x, y, 2)),
+                      (site(x, y, 1), site(x, y, 2)),                      # up triangle
+                      (site(x, y, 1), site(x + 1, y, 0)),
+                      (site(x + 1, y, 0), site(x + 1, y - 1, 2)),
+                      (site(x, y, 1), site(x + 1, y - 1, 2))]              # down triangle
+    unique = sorted({(min(a, b), max(a, b)) for a, b in bonds})
+    if len(unique) != len(bonds):
+        raise ValueError("lattice too small: periodic images coincide")
+    c = float(coupling)
+    matrix = [[c, 0, 0, 0], [0, -c, 2 * c, 0], [0, 2 * c, -c, 0], [0, 0, 0, c]]
+    n = 3 * l1 * l2
+    return {"basis": {"number_spins": n, "hamming_weight": n // 2, "symmetries": []},
+            "hamiltonian": {"terms": [{"matrix": matrix, "sites": [list(b) for b in unique]}]}}
+
+
+def hashed_log_amplitudes(spins, sigma: float = 1.5, seed: int = 0) -> np.ndarray:
+    """Deterministic stand-in for a wavefunction on states that cannot be enumerated:
+    ``log psi(s) = sigma * N(0,1) + i*pi*bit`` with the normal and the bit drawn from a
+    splitmix64 hash of the state (reproducible for any subset, like an NN amplitude)."""
+    x = np.asarray(spins, dtype=np.uint64)
+    if x.ndim > 1:
+        x = x[:, 0]
+
+    def mix(z):
+        z = (z + np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+    with np.errstate(over="ignore"):
+        a = mix(x ^ np.uint64(seed))
+        b = mix(a)
+    u1 = ((a >> np.uint64(11)).astype(np.float64) + 0.5) * 2.0 ** -53
+    u2 = ((b >> np.uint64(11)).astype(np.float64) + 0.5) * 2.0 ** -53
+    normal = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+    negative = (b & np.uint64(1)).astype(np.float64)
+    return sigma * normal + 1j * np.pi * negative
+
+
+def grow_cluster(hamiltonian, start: int, size: int, keep_probability: float = 0.5,
+                 seed: int = 0) -> np.ndarray:
+    """Breadth-first cluster around ``start`` with whole frontiers applied at once (a batched
+    version of common.py:481-513 for clusters of 1e4..1e5 states)."""
+    rng = np.random.default_rng(seed)
+    members = np.array([start], dtype=np.uint64)
+    frontier = members
+    while members.shape[0] < size and frontier.shape[0] > 0:
+        other, _, _ = hamiltonian.batched_apply(frontier)
+        cand = np.setdiff1d(np.unique(other[:, 0]), members)
+        cand = cand[rng.random(cand.shape[0]) <= keep_probability]
+        if members.shape[0] + cand.shape[0] > size:
+            cand = rng.permutation(cand)[: size - members.shape[0]]
+        members = np.union1d(members, cand)
+        frontier = cand
+    return members

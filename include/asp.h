@@ -134,6 +134,66 @@ int asp_ising_elements(uint64_t num_spins, uint64_t const *keys, double const *p
 float asp_ising_elements_last_ms(void);
 
 /* ------------------------------------------------------------------------- */
+/* (3b) Hamiltonian action on bit-packed basis states, and the coupling      */
+/*      build fused with it                                                  */
+/* ------------------------------------------------------------------------- */
+
+/* A sum of two-site terms on <= 64 spin-1/2 sites without lattice symmetries:
+ * what the reference obtains from lattice_symmetries' ls.Operator built from
+ * physical_systems/<model>.yaml (`terms: [{matrix, sites}]`, e.g.
+ * heisenberg_kagome_16.yaml:5-12; call sites annealing_sign_problem/common.py:96,
+ * 283,516-522).  Bit i of a key is site i; a 4x4 matrix acts on |b_a b_b> with
+ * row/column index 2*b_a + b_b, `matrices[bond*16 + dst*4 + src]`.  Bonds are
+ * listed in term order, then site-pair order.  Matrices are real (the reference
+ * rejects |Im| > 1e-6, common.py:99-101). */
+typedef struct asp_operator asp_operator;
+
+int asp_operator_create(uint32_t number_spins, uint32_t num_bonds, uint8_t const *site_a,
+                        uint8_t const *site_b, double const *matrices, asp_operator **out);
+void asp_operator_destroy(asp_operator *op);
+
+/* 1 when every row's targets are pairwise distinct for every input state (distinct flip
+ * masks), which asp_operator_ising and asp_operator_extend require; 0 otherwise. */
+int asp_operator_unique_targets(asp_operator const *op);
+/* Upper bound of other_counts[i] (diagonal entry included). */
+uint32_t asp_operator_max_connections(asp_operator const *op);
+
+/* Replaces `hamiltonian.batched_apply` + the flattening of _batched_apply
+ * (common.py:85-106) for n keys: per key one diagonal entry (the sum of the
+ * bonds' diagonal matrix elements, added in bond order), then one entry per
+ * non-zero off-diagonal element m[dst][src] in (bond, dst) order:
+ *   other_keys[e] = key ^ flip(src ^ dst), other_coeffs[e] = m[dst][src].
+ * other_counts[i] receives the number of entries of key i; *total their sum.
+ * Fails with ASP_ERR_INVALID when *total > capacity (nothing is written then
+ * except other_counts and *total). */
+int asp_operator_apply(asp_operator const *op, uint64_t n, uint64_t const *keys,
+                       uint64_t capacity, uint64_t *other_keys, double *other_coeffs,
+                       int64_t *other_counts, uint64_t *total);
+
+/* make_ising_model's arithmetic (common.py:131-208) without materialising the
+ * connections: for sorted unique keys[K] and amplitudes psi[K] (already
+ * L2-normalised over the cluster) computes
+ *   M_ij = (H_ij * |psi_j|) * |psi_i|   for i, j both in the cluster,
+ *   J    = 0.5 * (M + M^T), zeros dropped, as COO sorted by (row, col)
+ * — the matrix `0.5 * (matrix + matrix.T); sort_indices(); tocoo()` of
+ * common.py:194-196, bit for bit.  *nnz receives the length; row/col/val need
+ * capacity >= *nnz (call with capacity 0 and NULL outputs to size them).
+ * Requires asp_operator_unique_targets(op). */
+int asp_operator_ising(asp_operator const *op, uint64_t num_spins, uint64_t const *keys,
+                       double const *psi, uint64_t capacity, int32_t *row, int32_t *col,
+                       double *val, uint64_t *nnz);
+
+/* make_hamiltonian_extension's state set (common.py:516-522): the sorted unique
+ * union of every key's targets (its own diagonal entry included).  *count receives
+ * the size; out needs capacity >= *count (capacity 0 / NULL sizes it). */
+int asp_operator_extend(asp_operator const *op, uint64_t n, uint64_t const *keys,
+                        uint64_t capacity, uint64_t *out, uint64_t *count);
+
+/* Device time (ms, HIP events, no host<->HBM copies) of this thread's last
+ * asp_operator_apply / _ising / _extend call. */
+float asp_operator_last_ms(void);
+
+/* ------------------------------------------------------------------------- */
 /* (4) Annealer: replaces ising_glass_annealer.{Hamiltonian,anneal}          */
 /*     call sites: common.py:204,242-248; full_hilbert_space.py:212-218      */
 /* ------------------------------------------------------------------------- */

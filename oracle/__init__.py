@@ -227,3 +227,63 @@ def greedy_solve(matrix, field, max_sweeps: int = 10000, relax: bool = True):
     if rc != 0:
         raise RuntimeError("oracle_greedy_solve failed")
     return x[:words], e.value
+
+
+# ----------------------------------------------------------------------------
+# Hamiltonian action + fused coupling build (operator_oracle.c)
+# ----------------------------------------------------------------------------
+
+def _bond_args(bond_table):
+    a, b, m = bond_table
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    m = np.ascontiguousarray(m, dtype=np.float64).reshape(a.shape[0], 16)
+    return a, b, m
+
+
+def operator_apply(bond_table, keys):
+    """Flat batched_apply: (other_keys u64[N], other_coeffs f64[N], other_counts i64[n])."""
+    a, b, m = _bond_args(bond_table)
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    n = keys.shape[0]
+    per = 1 + 3 * a.shape[0]
+    other = np.zeros(max(n * per, 1), dtype=np.uint64)
+    coeff = np.zeros(max(n * per, 1), dtype=np.float64)
+    counts = np.zeros(max(n, 1), dtype=np.int64)
+    fn = lib().oracle_operator_apply
+    fn.restype = _u64
+    total = fn(_u32(a.shape[0]), _ptr(a), _ptr(b), _ptr(m), _u64(n), _ptr(keys), _ptr(other),
+               _ptr(coeff), _ptr(counts))
+    return other[:total].copy(), coeff[:total].copy(), counts[:n]
+
+
+def operator_ising(bond_table, keys, psi):
+    """COO (row i32, col i32, val f64) of 0.5 * (M + M^T), the reference's way."""
+    a, b, m = _bond_args(bond_table)
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    psi = np.ascontiguousarray(psi, dtype=np.float64)
+    k = keys.shape[0]
+    cap = max(2 * k * (1 + 3 * a.shape[0]), 1)
+    row = np.zeros(cap, dtype=np.int32)
+    col = np.zeros(cap, dtype=np.int32)
+    val = np.zeros(cap, dtype=np.float64)
+    fn = lib().oracle_operator_ising
+    fn.restype = _u64
+    nnz = fn(_u32(a.shape[0]), _ptr(a), _ptr(b), _ptr(m), _u64(k), _ptr(keys), _ptr(psi),
+             _ptr(row), _ptr(col), _ptr(val))
+    if nnz == 2 ** 64 - 1:
+        raise MemoryError("oracle_operator_ising")
+    return row[:nnz].copy(), col[:nnz].copy(), val[:nnz].copy()
+
+
+def operator_extend(bond_table, keys):
+    a, b, m = _bond_args(bond_table)
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    n = keys.shape[0]
+    out = np.zeros(max(n * (1 + 3 * a.shape[0]), 1), dtype=np.uint64)
+    fn = lib().oracle_operator_extend
+    fn.restype = _u64
+    count = fn(_u32(a.shape[0]), _ptr(a), _ptr(b), _ptr(m), _u64(n), _ptr(keys), _ptr(out))
+    if count == 2 ** 64 - 1:
+        raise MemoryError("oracle_operator_extend")
+    return out[:count].copy()

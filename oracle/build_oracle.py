@@ -3,7 +3,8 @@
 Two artefacts, both git-ignored:
 
 * ``oracle/liboracle.so``   — this directory's own C restatements
-  (``build_matrix_oracle.c``, ``sa_oracle.c``).
+  (``build_matrix_oracle.c``, ``sa_oracle.c``, ``greedy_oracle.c``,
+  ``operator_oracle.c``).
 * ``oracle/_ref/libbuild_matrix_ref.so`` — the REFERENCE's coupling build,
   compiled from its sources where they lie (``/root/reference/cbits``); no
   reference source is copied into this repository.  Only built when the
@@ -23,7 +24,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 REFERENCE_CBITS = "/root/reference/cbits"
 
-ORACLE_SOURCES = ["build_matrix_oracle.c", "sa_oracle.c", "greedy_oracle.c"]
+ORACLE_SOURCES = ["build_matrix_oracle.c", "sa_oracle.c", "greedy_oracle.c", "operator_oracle.c"]
 ORACLE_LIB = os.path.join(HERE, "liboracle.so")
 REF_DIR = os.path.join(HERE, "_ref")
 REF_LIB = os.path.join(REF_DIR, "libbuild_matrix_ref.so")
