@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <limits>
 #include <numeric>
 #include <queue>
@@ -65,14 +66,15 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
 
   // ---- J^T by rows (bucket the entries by column; rows are visited in order so
   //      every bucket ends up sorted by original row) --------------------------
-  std::vector<std::vector<Entry>> transposed(n);
+  std::vector<int64_t> t_ptr(n + 1, 0);
+  std::vector<Entry> t_entries(static_cast<size_t>(nnz));
   {
-    std::vector<uint32_t> per_col(n, 0);
-    for (int64_t k = 0; k < nnz; ++k) per_col[indices[k]]++;
-    for (uint64_t j = 0; j < n; ++j) transposed[j].reserve(per_col[j]);
+    for (int64_t k = 0; k < nnz; ++k) t_ptr[indices[k] + 1]++;
+    for (uint64_t j = 0; j < n; ++j) t_ptr[j + 1] += t_ptr[j];
+    std::vector<int64_t> cursor(t_ptr.begin(), t_ptr.end() - 1);
     for (uint64_t i = 0; i < n; ++i) {
       for (int64_t k = indptr[i]; k < indptr[i + 1]; ++k) {
-        transposed[indices[k]].push_back(Entry{static_cast<int32_t>(i), data[k]});
+        t_entries[cursor[indices[k]]++] = Entry{static_cast<int32_t>(i), data[k]};
       }
     }
   }
@@ -83,8 +85,8 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
   L.a_val.reserve(static_cast<size_t>(2 * nnz));
   double diag = 0.0;
   for (uint64_t i = 0; i < n; ++i) {
-    const Entry *t = transposed[i].data();
-    const Entry *t_end = t + transposed[i].size();
+    const Entry *t = t_entries.data() + t_ptr[i];
+    const Entry *t_end = t_entries.data() + t_ptr[i + 1];
     int64_t k = indptr[i];
     const int64_t k_end = indptr[i + 1];
     while (k < k_end || t < t_end) {
@@ -108,15 +110,13 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
     L.a_ptr[i + 1] = static_cast<int64_t>(L.a_col.size());
   }
   L.diag_sum = diag;
-  transposed.clear();
-  transposed.shrink_to_fit();
+  std::vector<Entry>().swap(t_entries);
 
   // ---- DSATUR colouring (Brelaz 1979) --------------------------------
   // Repeatedly colour the uncoloured spin with the most DISTINCT colours among its
   // neighbours (ties: larger degree, then smaller index) with the smallest colour none of
   // its neighbours has.  About a third fewer colours than first-fit in index order, i.e. a
-  // third fewer barriers per sweep.  Max-heap with lazy invalidation; per-spin bitset of the
-  // colours seen so far.
+  // third fewer barriers per sweep.  Per-spin bitset of the colours seen so far.
   L.color.assign(n, -1);
   {
     uint32_t max_deg = 0;
@@ -126,29 +126,50 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
     const size_t words = (static_cast<size_t>(max_deg) + 2 + 63) / 64;  // colours <= max_deg + 1
     std::vector<uint64_t> seen(n * words, 0);
     std::vector<uint32_t> saturation(n, 0);
-    struct Candidate {
-      uint32_t saturation, degree, index;
-      bool operator<(const Candidate &o) const {  // priority_queue: largest on top
-        if (saturation != o.saturation) return saturation < o.saturation;
-        if (degree != o.degree) return degree < o.degree;
-        return index > o.index;
-      }
+    // Priority = (saturation, degree) with the smallest index first among equals.  Both are
+    // small integers, so the queue is an array of buckets keyed saturation * (max_deg + 1) +
+    // degree, each a min-heap of indices with lazy deletion, plus a two-level bitmap of the
+    // non-empty buckets (find-last-set gives the best bucket).
+    const uint32_t stride = max_deg + 1;
+    const size_t num_buckets = static_cast<size_t>(max_deg + 2) * stride;
+    using MinHeap = std::priority_queue<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>>;
+    std::vector<MinHeap> buckets(num_buckets);
+    std::vector<uint64_t> level0((num_buckets + 63) / 64, 0);
+    std::vector<uint64_t> level1((level0.size() + 63) / 64, 0);
+    auto mark = [&](size_t key) {
+      level0[key >> 6] |= 1ull << (key & 63);
+      level1[key >> 12] |= 1ull << ((key >> 6) & 63);
     };
-    std::priority_queue<Candidate> heap;
+    auto unmark = [&](size_t key) {
+      level0[key >> 6] &= ~(1ull << (key & 63));
+      if (level0[key >> 6] == 0) level1[key >> 12] &= ~(1ull << ((key >> 6) & 63));
+    };
+    auto degree_of = [&](uint32_t i) { return static_cast<uint32_t>(L.a_ptr[i + 1] - L.a_ptr[i]); };
     for (uint64_t i = 0; i < n; ++i) {
-      heap.push(Candidate{0u, static_cast<uint32_t>(L.a_ptr[i + 1] - L.a_ptr[i]),
-                          static_cast<uint32_t>(i)});
+      const size_t key = degree_of(static_cast<uint32_t>(i));
+      buckets[key].push(static_cast<uint32_t>(i));
+      mark(key);
     }
     uint32_t ncol = 0;
-    while (!heap.empty()) {
-      const Candidate top = heap.top();
-      heap.pop();
-      const uint32_t v = top.index;
-      if (L.color[v] >= 0 || top.saturation != saturation[v]) continue;  // stale entry
+    uint64_t remaining = n;
+    while (remaining > 0) {
+      size_t top1 = level1.size();
+      while (top1 > 0 && level1[top1 - 1] == 0) --top1;
+      const size_t w1 = top1 - 1;  // remaining > 0: some bucket is marked
+      const size_t w0 = w1 * 64 + (63 - static_cast<size_t>(__builtin_clzll(level1[w1])));
+      const size_t key = w0 * 64 + (63 - static_cast<size_t>(__builtin_clzll(level0[w0])));
+      MinHeap &bucket = buckets[key];
+      const uint32_t v = bucket.top();
+      bucket.pop();
+      if (bucket.empty()) unmark(key);
+      if (L.color[v] >= 0 || key != static_cast<size_t>(saturation[v]) * stride + degree_of(v)) {
+        continue;  // stale entry
+      }
       const uint64_t *mine = &seen[static_cast<size_t>(v) * words];
       uint32_t c = 0;
       while ((mine[c >> 6] >> (c & 63)) & 1ull) ++c;
       L.color[v] = static_cast<int32_t>(c);
+      --remaining;
       ncol = std::max(ncol, c + 1);
       for (int64_t k = L.a_ptr[v]; k < L.a_ptr[v + 1]; ++k) {
         const uint32_t u = static_cast<uint32_t>(L.a_col[k]);
@@ -157,7 +178,9 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
         if ((word >> (c & 63)) & 1ull) continue;
         word |= 1ull << (c & 63);
         saturation[u] += 1;
-        heap.push(Candidate{saturation[u], static_cast<uint32_t>(L.a_ptr[u + 1] - L.a_ptr[u]), u});
+        const size_t moved = static_cast<size_t>(saturation[u]) * stride + degree_of(u);
+        buckets[moved].push(u);
+        mark(moved);
       }
     }
     L.num_colors = ncol;
