@@ -195,7 +195,53 @@ def bench_build(J, cores_unused, seconds=6.0):
         "cpu_baseline": {"value": m / t_np, "unit": "connections/s", "cores": 1, "kind": "port",
                          "sample": "numpy restatement of common.py:71-82,116-128, all %d connections, %.2f s" % (m, t_np)},
     }
+    # action fused with the build (asp_operator_ising): 36-site kagome, 72 bonds, a 1e5-state
+    # cluster; connections = what batched_apply would have materialised; CPU side = the numpy
+    # operator + numpy/scipy restatement of the reference route on one core
+    from annealing_sign_problem_amd import operators
+
+    op = operators.Operator.from_config(synthetic.kagome_lattice())
+    cluster = synthetic.grow_cluster(op, int("01" * 18, 2), 100000, seed=1)
+    amp = np.ascontiguousarray(np.exp(synthetic.hashed_log_amplitudes(cluster)).real)
+    amp /= np.linalg.norm(amp)
+    dev = op.device()
+    fused_ms, call_ms = [], []
+    for _ in range(6):
+        t0 = time.perf_counter()
+        r_, c_, v_ = dev.ising(cluster, amp)
+        call_ms.append((time.perf_counter() - t0) * 1e3)
+        fused_ms.append(dev.last_ms)
+    fused = float(np.median(fused_ms[1:]))
+    t0 = time.perf_counter()
+    o_, co_, cn_ = op.batched_apply(cluster)
+    o_ = o_[:, 0]
+    ix_ = np.clip(np.searchsorted(cluster, o_), 0, cluster.size - 1)
+    el_ = co_.real * np.abs(np.where(o_ == cluster[ix_], amp[ix_], 0))
+    el_ *= np.abs(amp[np.repeat(np.arange(cluster.size), cn_)])
+    import scipy.sparse
+    m_ = scipy.sparse.csr_matrix((el_, ix_, np.concatenate([[0], np.cumsum(cn_)])),
+                                 shape=(cluster.size,) * 2)
+    m_ = 0.5 * (m_ + m_.T)
+    m_.sort_indices()
+    m_ = m_.tocoo()
+    t_host = time.perf_counter() - t0
+    if not (np.array_equal(m_.row, r_) and np.array_equal(m_.col, c_)
+            and m_.data.tobytes() == v_.tobytes()):
+        raise RuntimeError("fused coupling build disagrees with the reference route")
+    conn = int(cn_.sum())
+    fused_path = {
+        "workload": "asp_operator_ising, kagome 36 sites / 72 bonds, K=%d, %d connections, nnz %d"
+                    % (cluster.size, conn, v_.size),
+        "connections_per_s": conn / (fused * 1e-3), "ms": fused,
+        "host_pointer_call_ms": float(np.median(call_ms[1:])),
+        "algorithmic_GBps": (cluster.size * 16 + v_.size * 16) / (fused * 1e-3) / 1e9,
+        "cpu_baseline": {"value": conn / t_host, "unit": "connections/s", "cores": 1,
+                         "kind": "port",
+                         "sample": "numpy operator + numpy/scipy restatement of common.py:85-196, "
+                                   "same cluster, %.2f s; outputs compared bit for bit" % t_host},
+    }
     return {
+        "fused_operator_path": fused_path,
         "live_path": live_path,
         "workload": "build_matrix K=%d, %d connections (512-bit keys)" % (n, m),
         "connections_per_s": m / (ms * 1e-3),

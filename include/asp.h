@@ -153,7 +153,7 @@ int asp_operator_create(uint32_t number_spins, uint32_t num_bonds, uint8_t const
 void asp_operator_destroy(asp_operator *op);
 
 /* 1 when every row's targets are pairwise distinct for every input state (distinct flip
- * masks), which asp_operator_ising and asp_operator_extend require; 0 otherwise. */
+ * masks), which asp_operator_ising requires; 0 otherwise. */
 int asp_operator_unique_targets(asp_operator const *op);
 /* Upper bound of other_counts[i] (diagonal entry included). */
 uint32_t asp_operator_max_connections(asp_operator const *op);

@@ -71,3 +71,17 @@ for rep in range(2):  # second pass = warm
 e_g = h.energy(xg)
 e_s = h.energy(xs)
 print("energies: greedy %.12g  sa %.12g" % (e_g, e_s))
+
+# order-1 extension + sparsify of a smaller cluster (the sampled_components pipeline step)
+small = synthetic.grow_cluster(op, start, max(size // 28, 50), seed=2)
+log_fn = synthetic.hashed_log_amplitudes
+for rep in range(2):
+    T = Timed()
+    m0 = T("make(order 0)", common.make_ising_model, small, op, log_psi_fn=log_fn)
+    m1 = T("extension", common.make_hamiltonian_extension, m0, log_fn)
+    m2 = T("sparsify", common.sparsify_using_global_cutoff, m1, 1e-4, small)
+    T("plan", m2.ising_hamiltonian.plan)
+    T("greedy", common.solve_ising_model, m2, mode="greedy", frozen_spins=small)
+    print("order-1 pass %d  K0=%d -> %d -> %d (nnz %d):" % (rep, m0.size, m1.size, m2.size,
+          m2.ising_hamiltonian.exchange.nnz), "  ".join("%s %.3f s" % kv for kv in T.t.items()),
+          flush=True)
