@@ -48,6 +48,12 @@
 #ifndef ASP_INERT_SKIP
 #define ASP_INERT_SKIP 1
 #endif
+#ifndef ASP_ABS_LDS
+#define ASP_ABS_LDS 1
+#endif
+#ifndef ASP_MAX_THREADS
+#define ASP_MAX_THREADS 1024  // launch bound of the sweep kernel (VGPR budget = 512 / waves per SIMD)
+#endif
 // Timing-only ablations (results are WRONG when any is set; never set in the product build).
 #ifndef ASP_ABL_NO_ACCEPT
 #define ASP_ABL_NO_ACCEPT 0
@@ -230,6 +236,8 @@ __device__ __forceinline__ void load_quad(Quad &q, const uint4 *__restrict__ cpt
 
 // PACKED = false: one LDS byte per position, bit m = replica m.  PACKED = true (M = 1 only):
 // one LDS bit per position, 64 positions (= one block) per u64 word.
+using LdsByte = __attribute__((address_space(3))) const uint8_t;
+
 template <int M, bool PACKED>
 __device__ __forceinline__ void accumulate_quad(const Quad &q, const uint8_t *spins,
                                                 double (&acc)[M]) {
@@ -244,8 +252,17 @@ __device__ __forceinline__ void accumulate_quad(const Quad &q, const uint8_t *sp
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] = (words[cs[j] >> 5] >> (cs[j] & 31u)) & 1u;
   } else {
+#if ASP_ABS_LDS
+    // the spin bytes start at LDS address 0 (checked in the kernel prologue), so a position IS
+    // its LDS address: no base add in front of every ds_read_u8
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s[j] = *reinterpret_cast<LdsByte *>(static_cast<uintptr_t>(cs[j]));
+    }
+#else
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] = spins[cs[j]];
+#endif
   }
 #endif
 #if ASP_ABL_NO_FMA
@@ -319,7 +336,7 @@ __device__ __forceinline__ void snapshot(const uint8_t *spins, const SweepArgs &
 // DESCENT = true: strict-descent sweeps (accept iff dE < 0, no random numbers), used by the
 // greedy solver's relaxation; the final configuration is snapshotted after every sweep.
 template <int M, bool DESCENT, bool PACKED>
-__global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
+__global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep(SweepArgs a) {
   static_assert(!PACKED || M == 1, "the bit-packed layout holds one replica");
   extern __shared__ __align__(16) uint8_t lds[];
   uint8_t *spins = lds;
@@ -342,6 +359,13 @@ __global__ __launch_bounds__(1024) void k_sa_sweep(SweepArgs a) {
   uint8_t *inert = dirty + ((a.num_blocks + 15u) & ~15u);
   const bool cache_available = !PACKED && a.field_cache != nullptr;
 
+#if ASP_ABS_LDS
+  // accumulate_quad addresses the spin bytes absolutely: the dynamic LDS block must be the
+  // first (this kernel declares no static LDS)
+  if (reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t *)lds) != 0) {
+    __builtin_trap();
+  }
+#endif
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
   const uint32_t wave = tid >> 6;
@@ -839,7 +863,11 @@ void choose_launch(const asp_sa_plan *p, uint32_t repetitions, int *m_out, int *
     for (uint32_t c = 0; c < p->host.num_colors; ++c) {
       widest = std::max(widest, p->host.color_block_start[c + 1] - p->host.color_block_start[c]);
     }
-    threads = static_cast<int>(std::min<uint32_t>(widest, 16)) * 64;
+    // 16 wavefronts pay once a colour step is many rounds long; below ~80 blocks per colour
+    // 12 (three per SIMD) finish the same rounds sooner (measured: +7 % at K = 1e4, +5 % at
+    // 3e4, -4 % at 5e4; tools/tune_sweep.py --threads)
+    const uint32_t most = widest >= 80 ? 16u : 12u;
+    threads = static_cast<int>(std::min<uint32_t>(widest, most)) * 64;
   }
   *m_out = m;
   *threads_out = threads;
