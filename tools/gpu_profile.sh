@@ -16,5 +16,5 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-form
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/pmc_sq1 -- python $ARGS > $OUT/pmc_sq1.log 2>&1 || exit 4
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmc_sq2 -- python $ARGS > $OUT/pmc_sq2.log 2>&1 || exit 5
 python tools/summarise_profile.py $OUT ${1:-r01} > $OUT/summary.log 2>&1
-cp profiles/${1:-r01}_* $OUT/ 2>/dev/null
+cp profiles/${1:-r01}_* profiles/traffic.json $OUT/ 2>/dev/null
 tail -5 $OUT/bench_trace.log | cut -c1-600
