@@ -329,3 +329,75 @@ def test_field_cache_survives_reheating(m, threads):
                                       ham.info().energy_scale_exp, num_threads=8)
     assert np.array_equal(acc_a, acc_b)            # sweeps 60..69: nothing moves
     assert (oacc.astype(np.int64) - acc_a.astype(np.int64)).min() > 100
+
+
+def test_full_size_properties_sk32_sized():
+    """BASELINE config 5 (sk_32_1 + NOISE 0.79 shape): K = 8192, 256 neighbours per spin.  The
+    first chains are checked against the oracle on a short ladder; at full width (512 chains,
+    every group size) the size-independent properties: energies equal E(x) recomputed with
+    numpy (1e-12), launch geometries agree bit for bit, any shard of the chains equals the same
+    chains of the full run (what the multi-GPU split relies on)."""
+    from annealing_sign_problem_amd import annealer as sa, synthetic
+
+    J, h = synthetic.sk_cluster(8192, degree=256, seed=783494)
+    ham = sa.Hamiltonian(J, h)
+    info = ham.info()
+    assert info.max_degree >= 200
+    betas = sa.make_schedule(info.beta0_auto, info.beta1_auto, 12)
+    xs, es = sa.anneal_raw(ham, 783494, betas, 512)
+    oxs, oes, _, _ = oracle.sa_anneal(J, h, 783494, betas[:4], 8, 0, None, info.energy_scale_exp,
+                                      num_threads=8)
+    xs4, es4 = sa.anneal_raw(ham, 783494, betas[:4], 8)
+    assert np.array_equal(xs4, oxs) and es4.tobytes() == oes.tobytes()
+    _set_launch(ham, 1, 256)
+    xs1, es1 = sa.anneal_raw(ham, 783494, betas, 512)
+    assert np.array_equal(xs, xs1) and es.tobytes() == es1.tobytes()
+    _set_launch(ham, 0, 0)
+    part_x, part_e = sa.anneal_raw(ham, 783494, betas, 100, 300)   # chains 300..399
+    assert np.array_equal(part_x, xs[300:400]) and part_e.tobytes() == es[300:400].tobytes()
+    Js = J.tocsr()
+    for r in [0, 255, 511]:
+        s = sa.bits_to_signs(xs[r], 8192)
+        ref = s @ (Js @ s) + h @ s
+        assert abs(es[r] - ref) <= 1e-12 * abs(ref)
+    assert len({x.tobytes() for x in xs}) == 512
+
+
+def test_full_size_properties_pyrochlore_sized_with_cutoff():
+    """BASELINE config 4 shape: a pyrochlore-sized cluster (mean degree 40, capped at 49),
+    sparsified with CUTOFF = 2e-6 around a frozen core (common.py:634-692), then annealed:
+    the kept component holds every frozen spin, its couplings are the un-pruned block
+    (common.py:674), energies equal numpy's, launch geometries agree."""
+    from annealing_sign_problem_amd import annealer as sa, common, synthetic
+
+    J, h, planted = synthetic.planted_cluster(40000, mean_degree=40.0, max_degree=49, seed=674385)
+    spins = np.arange(40000, dtype=np.uint64) * np.uint64(3) + np.uint64(7)   # sorted unique keys
+    model = common.IsingModel(spins, None, sa.Hamiltonian(J, h),
+                              sa.signs_to_bits(np.ones(40000)))
+    # frozen core: spin 0 and its strongest chain of neighbours
+    csr = J.tocsr()
+    core, at = [0], 0
+    for _ in range(30):
+        lo, hi = csr.indptr[at], csr.indptr[at + 1]
+        cand = [(abs(v), j) for v, j in zip(csr.data[lo:hi], csr.indices[lo:hi]) if j not in core]
+        if not cand:
+            break
+        at = max(cand)[1]
+        core.append(int(at))
+    frozen = spins[np.sort(np.array(core))]
+    small = common.sparsify_using_global_cutoff(model, 2e-6, frozen)
+    keep = np.searchsorted(spins, small.spins)
+    assert np.all(np.isin(frozen, small.spins)) and 100 < small.size <= 40000
+    block = csr[keep][:, keep]
+    assert (abs(small.ising_hamiltonian.exchange - block)).nnz == 0
+    ham = small.ising_hamiltonian
+    info = ham.info()
+    betas = sa.make_schedule(info.beta0_auto, min(info.beta1_auto, 1e9), 16)
+    xs, es = sa.anneal_raw(ham, 674385, betas, 128)
+    _set_launch(ham, 2, 512)
+    xs2, es2 = sa.anneal_raw(ham, 674385, betas, 128)
+    assert np.array_equal(xs, xs2) and es.tobytes() == es2.tobytes()
+    for r in [0, 64, 127]:
+        s = sa.bits_to_signs(xs[r], small.size)
+        ref = s @ (block @ s) + ham.field @ s
+        assert abs(es[r] - ref) <= 1e-12 * abs(ref)
