@@ -3,6 +3,12 @@
 #include "asp_common.hpp"
 
 #include <atomic>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <utility>
+#include <vector>
 
 namespace asp {
 
@@ -42,6 +48,198 @@ int require_device() {
                      e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
   }
   return bind_device();
+}
+
+// ---------------------------------------------------------------------------
+// Device memory pool
+// ---------------------------------------------------------------------------
+
+namespace {
+
+struct PoolBlock {
+  size_t bytes;
+  int device;
+};
+
+struct Pool {
+  std::mutex mutex;
+  std::unordered_map<void *, PoolBlock> live;                 // handed out
+  std::map<std::pair<int, size_t>, std::vector<void *>> idle;  // (device, class) -> blocks
+  size_t idle_bytes = 0;
+  size_t cap = 1ull << 30;
+  Pool() {
+    if (const char *env = std::getenv("ASP_POOL_BYTES")) cap = std::strtoull(env, nullptr, 10);
+  }
+};
+
+Pool &pool() {
+  static Pool *p = new Pool;  // never destroyed: no HIP calls from static destructors
+  return *p;
+}
+
+// Smallest of {4, 5, 6, 7} * 2^k (>= 512) that holds `bytes`.
+size_t size_class(size_t bytes) {
+  size_t base = 128;
+  while (base * 7 < bytes) base <<= 1;
+  for (size_t q = 4; q <= 7; ++q) {
+    if (base * q >= bytes) return base * q;
+  }
+  return base * 8;
+}
+
+}  // namespace
+
+int pool_alloc(size_t bytes, void **out) {
+  Pool &p = pool();
+  int device = 0;
+  ASP_HIP_TRY(hipGetDevice(&device));
+  const size_t cls = size_class(bytes);
+  {
+    std::lock_guard<std::mutex> lock(p.mutex);
+    auto it = p.idle.find({device, cls});
+    if (it != p.idle.end() && !it->second.empty()) {
+      void *ptr = it->second.back();
+      it->second.pop_back();
+      p.idle_bytes -= cls;
+      p.live[ptr] = PoolBlock{cls, device};
+      *out = ptr;
+      return ASP_OK;
+    }
+  }
+  void *ptr = nullptr;
+  hipError_t e = hipMalloc(&ptr, cls);
+  if (e != hipSuccess) {
+    // give the idle blocks of this device back and try once more
+    std::vector<void *> drop;
+    {
+      std::lock_guard<std::mutex> lock(p.mutex);
+      for (auto &kv : p.idle) {
+        if (kv.first.first != device) continue;
+        p.idle_bytes -= kv.first.second * kv.second.size();
+        drop.insert(drop.end(), kv.second.begin(), kv.second.end());
+        kv.second.clear();
+      }
+    }
+    for (void *d : drop) (void)hipFree(d);
+    e = hipMalloc(&ptr, cls);
+  }
+  if (e != hipSuccess) {
+    return set_error(ASP_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", cls, hipGetErrorString(e));
+  }
+  std::lock_guard<std::mutex> lock(p.mutex);
+  p.live[ptr] = PoolBlock{cls, device};
+  *out = ptr;
+  return ASP_OK;
+}
+
+void pool_free(void *ptr) {
+  if (!ptr) return;
+  Pool &p = pool();
+  PoolBlock block{0, 0};
+  {
+    std::lock_guard<std::mutex> lock(p.mutex);
+    auto it = p.live.find(ptr);
+    if (it == p.live.end()) {  // not ours (cannot happen): release directly
+      (void)hipFree(ptr);
+      return;
+    }
+    block = it->second;
+    p.live.erase(it);
+    if (p.idle_bytes + block.bytes <= p.cap) {
+      p.idle[{block.device, block.bytes}].push_back(ptr);
+      p.idle_bytes += block.bytes;
+      return;
+    }
+  }
+  (void)hipFree(ptr);  // hipFree accepts a pointer of any device
+}
+
+namespace {
+
+struct StreamPool {
+  std::mutex mutex;
+  std::map<int, std::vector<hipStream_t>> idle;  // device -> streams
+  std::unordered_map<hipStream_t, int> device_of;
+  struct Limits {
+    int num_cus;
+    size_t max_lds;
+  };
+  std::map<int, Limits> limits;
+};
+
+StreamPool &stream_pool() {
+  static StreamPool *p = new StreamPool;
+  return *p;
+}
+
+}  // namespace
+
+int stream_acquire(hipStream_t *out) {
+  StreamPool &p = stream_pool();
+  int device = 0;
+  ASP_HIP_TRY(hipGetDevice(&device));
+  {
+    std::lock_guard<std::mutex> lock(p.mutex);
+    auto &idle = p.idle[device];
+    if (!idle.empty()) {
+      *out = idle.back();
+      idle.pop_back();
+      return ASP_OK;
+    }
+  }
+  hipStream_t stream = nullptr;
+  ASP_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  std::lock_guard<std::mutex> lock(p.mutex);
+  p.device_of[stream] = device;
+  *out = stream;
+  return ASP_OK;
+}
+
+void stream_release(hipStream_t stream) {
+  if (!stream) return;
+  StreamPool &p = stream_pool();
+  std::lock_guard<std::mutex> lock(p.mutex);
+  auto it = p.device_of.find(stream);
+  if (it == p.device_of.end()) {
+    (void)hipStreamDestroy(stream);
+    return;
+  }
+  auto &idle = p.idle[it->second];
+  if (idle.size() < 64) {
+    idle.push_back(stream);
+  } else {
+    p.device_of.erase(it);
+    (void)hipStreamDestroy(stream);
+  }
+}
+
+int device_limits(int *num_cus, size_t *max_lds) {
+  StreamPool &p = stream_pool();
+  int device = 0;
+  ASP_HIP_TRY(hipGetDevice(&device));
+  {
+    std::lock_guard<std::mutex> lock(p.mutex);
+    auto it = p.limits.find(device);
+    if (it != p.limits.end()) {
+      *num_cus = it->second.num_cus;
+      *max_lds = it->second.max_lds;
+      return ASP_OK;
+    }
+  }
+  hipDeviceProp_t prop;
+  ASP_HIP_TRY(hipGetDeviceProperties(&prop, device));
+  StreamPool::Limits l{256, 160 * 1024};
+  if (prop.multiProcessorCount > 0) l.num_cus = prop.multiProcessorCount;
+  if (prop.sharedMemPerBlockOptin > 0) {
+    l.max_lds = prop.sharedMemPerBlockOptin;
+  } else if (prop.maxSharedMemoryPerMultiProcessor > 0) {
+    l.max_lds = prop.maxSharedMemoryPerMultiProcessor;
+  }
+  std::lock_guard<std::mutex> lock(p.mutex);
+  p.limits[device] = l;
+  *num_cus = l.num_cus;
+  *max_lds = l.max_lds;
+  return ASP_OK;
 }
 
 // ---------------------------------------------------------------------------

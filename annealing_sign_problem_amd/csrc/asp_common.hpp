@@ -47,6 +47,23 @@ int require_device();
 int bind_device();
 void remember_device(int device);
 
+// ---- pooled device memory ---------------------------------------------------
+// hipMalloc/hipFree cost ~0.1-0.5 ms each and hipFree synchronises the device; a sampled-
+// cluster run builds and drops three plans per cluster, tens of thousands of times.  Freed
+// blocks are therefore kept per device in size classes (four per octave) up to a cap
+// (ASP_POOL_BYTES, default 1 GiB; 0 disables) and handed out again.  Every entry point
+// synchronises its stream before returning, so a block is idle when it comes back.
+int pool_alloc(size_t bytes, void **out);
+void pool_free(void *ptr);
+
+// Non-blocking streams are recycled the same way (creating and destroying one costs more
+// than a small plan's kernels); a released stream must be idle.
+int stream_acquire(hipStream_t *out);
+void stream_release(hipStream_t stream);
+
+// Compute units and opt-in LDS bytes per workgroup of the current device (queried once).
+int device_limits(int *num_cus, size_t *max_lds);
+
 // ---- owning device buffer --------------------------------------------------
 template <typename T>
 struct DeviceBuffer {
@@ -57,7 +74,7 @@ struct DeviceBuffer {
   DeviceBuffer &operator=(const DeviceBuffer &) = delete;
   ~DeviceBuffer() { release(); }
   void release() {
-    if (ptr) (void)hipFree(ptr);
+    if (ptr) pool_free(ptr);
     ptr = nullptr;
     count = 0;
   }
@@ -65,12 +82,13 @@ struct DeviceBuffer {
   int alloc(size_t n) {
     release();
     size_t bytes = (n ? n : 1) * sizeof(T);
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&ptr), bytes);
-    if (e != hipSuccess) {
+    void *raw = nullptr;
+    const int rc = pool_alloc(bytes, &raw);
+    if (rc != ASP_OK) {
       ptr = nullptr;
-      return set_error(ASP_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", bytes,
-                       hipGetErrorString(e));
+      return rc;
     }
+    ptr = static_cast<T *>(raw);
     count = n;
     return ASP_OK;
   }

@@ -270,7 +270,7 @@ asp_build *asp_build_create(uint64_t num_spins, uint64_t num_other) {
   b->num_spins = num_spins;
   b->num_other = num_other;
   const uint64_t K = num_spins, N = num_other;
-  bool ok = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess &&
+  bool ok = asp::stream_acquire(&b->stream) == ASP_OK &&
             hipEventCreate(&b->ev_start) == hipSuccess && hipEventCreate(&b->ev_stop) == hipSuccess;
   if (!ok) asp::set_error(ASP_ERR_HIP, "could not create HIP stream/events");
   uint64_t slot_count = 64;
@@ -298,7 +298,10 @@ void asp_build_destroy(asp_build *b) {
   if (!b) return;
   if (b->ev_start) (void)hipEventDestroy(b->ev_start);
   if (b->ev_stop) (void)hipEventDestroy(b->ev_stop);
-  if (b->stream) (void)hipStreamDestroy(b->stream);
+  if (b->stream) {
+    (void)hipStreamSynchronize(b->stream);
+    asp::stream_release(b->stream);
+  }
   delete b;
 }
 

@@ -914,16 +914,14 @@ asp_sa_plan *asp_sa_plan_create(uint64_t num_spins, int64_t const *indptr, int32
     return nullptr;
   }
   const asp::SaHostLayout &L = p->host;
-  bool ok = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) == hipSuccess;
+  bool ok = asp::stream_acquire(&p->stream) == ASP_OK;
   for (auto &e : p->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
   if (!ok) asp::set_error(ASP_ERR_HIP, "could not create HIP stream/events");
-  int device = 0;
-  hipDeviceProp_t prop;
-  if (ok && hipGetDevice(&device) == hipSuccess &&
-      hipGetDeviceProperties(&prop, device) == hipSuccess) {
-    p->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (prop.sharedMemPerBlockOptin > 0) p->max_lds = prop.sharedMemPerBlockOptin;
-    else if (prop.maxSharedMemoryPerMultiProcessor > 0) p->max_lds = prop.maxSharedMemoryPerMultiProcessor;
+  int num_cus = 0;
+  size_t max_lds = 0;
+  if (ok && asp::device_limits(&num_cus, &max_lds) == ASP_OK) {
+    p->num_cus = num_cus;
+    p->max_lds = max_lds;
   }
   ok = ok && upload_vector(p->color_block_start, L.color_block_start, p->stream) == ASP_OK &&
        upload_vector(p->block_width, L.block_width, p->stream) == ASP_OK &&
@@ -949,7 +947,10 @@ void asp_sa_plan_destroy(asp_sa_plan *p) {
   for (auto &e : p->ev) {
     if (e) (void)hipEventDestroy(e);
   }
-  if (p->stream) (void)hipStreamDestroy(p->stream);
+  if (p->stream) {
+    (void)hipStreamSynchronize(p->stream);  // idle before it is recycled
+    asp::stream_release(p->stream);
+  }
   delete p;
 }
 

@@ -38,11 +38,15 @@ def create_small_cluster_around_point(s0: int, hamiltonian, required_size: int =
     s0 = int(s0)
     members = {s0}
 
-    def children_of(state):
-        targets, _ = hamiltonian.apply(state)
-        targets = np.asarray(targets)
-        if targets.ndim > 1:
-            targets = targets[:, 0]
+    def connections(states):
+        """Targets of every state (own state first), one array per state.  The action does not
+        depend on the cluster grown so far, so a whole frontier is applied in one call — the
+        GPU action for this package's operators, ``batched_apply`` for foreign ones — instead
+        of the reference's one ``hamiltonian.apply`` per state (common.py:492)."""
+        flat, _, counts = common._batched_apply(hamiltonian, np.asarray(states, dtype=np.uint64))
+        return np.split(flat, np.cumsum(counts)[:-1])
+
+    def children_of(targets):
         kept = []
         for x in targets:
             if x in members:
@@ -51,14 +55,20 @@ def create_small_cluster_around_point(s0: int, hamiltonian, required_size: int =
                 kept.append(int(x))
         return kept
 
-    frontier = children_of(s0)
+    frontier = children_of(connections([s0])[0])
     while len(members) < required_size and len(frontier) > 0:
         upcoming = set()
-        for child in frontier:
+        order = list(frontier)
+        # applied lazily in chunks: the loop usually stops long before a big frontier is used up
+        chunk, at = [], 0
+        for k, child in enumerate(order):
             members.add(child)
             if len(members) >= required_size:
                 break
-            upcoming |= set(children_of(child))
+            if k >= at + len(chunk):
+                at = k
+                chunk = connections(order[k:k + 256])
+            upcoming |= set(children_of(chunk[k - at]))
         frontier = upcoming
     return sorted(members)
 

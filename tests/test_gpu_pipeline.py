@@ -51,3 +51,27 @@ def test_concurrent_clusters_give_identical_output(tmp_path):
     sampled_components.main(common_args + ["--output", str(a)])
     sampled_components.main(common_args + ["--output", str(b), "--jobs", "4"])
     assert a.read_text().replace("serial", "") == b.read_text().replace("jobs4", "")
+
+
+def test_cluster_growth_on_gpu_action_equals_host_action(models):
+    """create_small_cluster_around_point applies whole frontiers through asp_operator_apply;
+    with the same numpy seed it must grow the very cluster the host action grows."""
+    from annealing_sign_problem_amd import operators, sampled_components
+
+    op = operators.Operator.from_config(models["j1j2_square_4x4"])
+    op.basis.build()
+
+    class Foreign:
+        basis = op.basis
+
+        def batched_apply(self, x):
+            return op.batched_apply(x)
+
+    for seed, size in [(1, 40), (2, 700), (3, 2500)]:
+        start = int(op.basis.states[seed * 1000])
+        np.random.seed(seed)
+        on_gpu = sampled_components.create_small_cluster_around_point(start, op, required_size=size)
+        np.random.seed(seed)
+        on_host = sampled_components.create_small_cluster_around_point(start, Foreign(),
+                                                                       required_size=size)
+        assert on_gpu == on_host and len(on_gpu) == size

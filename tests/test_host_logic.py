@@ -232,7 +232,39 @@ def test_cluster_growth_is_connected_and_sized(models):
     op.basis.build()
     np.random.seed(5)
     start = int(op.basis.states[1234])
-    cluster = sampled_components.create_small_cluster_around_point(start, op, required_size=120)
+
+    class Foreign:  # not this package's Operator type: growth uses its batched_apply on the host
+        basis = op.basis
+
+        def batched_apply(self, x):
+            return op.batched_apply(x)
+
+    cluster = sampled_components.create_small_cluster_around_point(start, Foreign(),
+                                                                   required_size=120)
+    # the frontier-at-once growth consumes the random stream exactly like the reference's
+    # state-by-state loop (common.py:481-513), restated here
+    np.random.seed(5)
+    members = {start}
+
+    def children_of(state):
+        kept = []
+        for x in op.apply(state)[0][:, 0]:
+            if x in members:
+                continue
+            if np.random.rand() <= 0.5:
+                kept.append(int(x))
+        return kept
+
+    frontier = children_of(start)
+    while len(members) < 120 and len(frontier) > 0:
+        upcoming = set()
+        for child in frontier:
+            members.add(child)
+            if len(members) >= 120:
+                break
+            upcoming |= set(children_of(child))
+        frontier = upcoming
+    assert cluster == sorted(members)
     assert cluster == sorted(cluster) and start in cluster and len(set(cluster)) == len(cluster)
     assert 60 <= len(cluster) <= 120
     # connected under the Hamiltonian's off-diagonal action
