@@ -242,6 +242,13 @@ int asp_sa_set_launch(asp_sa_plan *p, int replicas_per_group, int threads);
  * bit-packed layout (tests, measurements).  Results never depend on the layout. */
 int asp_sa_set_packed(asp_sa_plan *p, int packed);
 
+/* With four replicas per workgroup and up to ~4e4 spins the kernel keeps a 32-bit word
+ * per position (one byte per replica), which makes the sign of a coupling term a single SDWA
+ * instruction.  allow = 0 keeps the byte layout (tests, measurements); default 1.
+ * asp_sa_last_layout: 0 = bytes, 1 = bits, 2 = words, for the last anneal/greedy call. */
+int asp_sa_set_wide(asp_sa_plan *p, int allow);
+int asp_sa_last_layout(asp_sa_plan const *p);
+
 /* Field cache (default on): once a sweep flips few spins, a workgroup keeps the local fields
  * of every block in HBM and re-evaluates a block only after one of its neighbours flipped.
  * Pure optimisation of frozen sweeps; results are identical with it on or off. */

@@ -27,12 +27,25 @@ def _set_launch(h, m, threads):
 
 
 def _compare(J, field, seed, betas, reps, offset=0, x0=None, m=0, threads=0):
+    from annealing_sign_problem_amd import _lib
     from annealing_sign_problem_amd import annealer as sa
 
     h = sa.Hamiltonian(J, field)
     _set_launch(h, m, threads)
     xs, es = sa.anneal_raw(h, seed, betas, reps, offset, x0)
     tracked, accepted = _stats(h, reps)
+    lib = _lib.load()
+    h.layout_used = lib.asp_sa_last_layout(h.plan())
+    if h.layout_used == 2:
+        # the word-per-position layout ran (four replicas per workgroup): the byte
+        # layout must give the very same chains
+        _lib.check(lib.asp_sa_set_wide(h.plan(), 0))
+        xs_b, es_b = sa.anneal_raw(h, seed, betas, reps, offset, x0)
+        tracked_b, accepted_b = _stats(h, reps)
+        assert lib.asp_sa_last_layout(h.plan()) == 0
+        assert np.array_equal(xs, xs_b) and es.tobytes() == es_b.tobytes()
+        assert np.array_equal(tracked, tracked_b) and np.array_equal(accepted, accepted_b)
+        _lib.check(lib.asp_sa_set_wide(h.plan(), 1))
     S = h.info().energy_scale_exp
     oxs, oes, otracked, oaccepted = oracle.sa_anneal(J, field, seed, betas, reps, offset, x0, S,
                                                     num_threads=8)
@@ -51,9 +64,33 @@ def _planted(n, seed, **kw):
 
 @pytest.mark.parametrize("m", [1, 2, 4, 8])
 def test_sweep_bit_exact_every_group_width(m):
+    from annealing_sign_problem_amd import _lib
+
     J, h, _ = _planted(1500, 11)
     betas = np.geomspace(0.5, 2e4, 40)
-    _compare(J, h, 12345, betas, 16, m=m, threads=256)
+    ham, _, _ = _compare(J, h, 12345, betas, 16, m=m, threads=256)
+    # layouts: words for 4 replicas per workgroup at this size, bytes otherwise
+    assert ham.layout_used == (2 if m == 4 else 0)
+
+
+def test_wide_layout_limits_and_initial_configuration():
+    """The word layout stops at ~4e4 spins (LDS) and is never used by the descent kernel; with
+    a given x0 and a ragged last group it still follows the oracle."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    lib = _lib.load()
+    J, h, planted = _planted(36000, 21)
+    x0 = sa.signs_to_bits(np.where(np.random.default_rng(3).random(36000) < 0.5, 1.0, -1.0))
+    betas = np.geomspace(2.0, 1e6, 12)
+    ham, _, _ = _compare(J, h, 5, betas, 7, offset=3, x0=x0, m=4, threads=512)
+    assert ham.layout_used == 2
+    big = sa.Hamiltonian(*_planted(45000, 22)[:2])
+    _set_launch(big, 4, 512)
+    sa.anneal_raw(big, 5, betas[:3], 4)
+    assert lib.asp_sa_last_layout(big.plan()) == 0
+    sa.greedy_solve(ham)
+    assert lib.asp_sa_last_layout(ham.plan()) == 0
 
 
 @pytest.mark.parametrize("threads", [64, 192, 1024])

@@ -23,6 +23,7 @@ def main():
     p.add_argument("--threads", default="256,512,1024")
     p.add_argument("--kind", default="planted")
     p.add_argument("--cache", default="1", help="comma list of field-cache settings to time (0/1)")
+    p.add_argument("--wide", default="1", help="comma list: 0 = byte layout only, 1 = word layout allowed")
     a = p.parse_args()
     lib = _lib.load()
     for k in [int(s) for s in a.sizes.split(",")]:
@@ -41,14 +42,17 @@ def main():
                 _lib.check(lib.asp_sa_set_launch(ham.plan(), m, th))
                 for cache in [int(c) for c in a.cache.split(",")]:
                     _lib.check(lib.asp_sa_set_field_cache(ham.plan(), cache))
-                    best = None
-                    for _ in range(2):
-                        sa.anneal_raw(ham, 1, betas, a.replicas)
-                        ms = lib.asp_sa_last_sweep_ms(ham.plan())
-                        best = ms if best is None else min(best, ms)
-                    flips = k * a.replicas * a.sweeps
-                    print("  M=%d threads=%4d cache=%d  sweep %8.2f ms  %7.2f Gflips/s  total %.2f ms" % (
-                        m, th, cache, best, flips / best / 1e6, lib.asp_sa_last_total_ms(ham.plan())), flush=True)
+                    for wide in [int(c) for c in a.wide.split(",")]:
+                        _lib.check(lib.asp_sa_set_wide(ham.plan(), wide))
+                        best = None
+                        for _ in range(2):
+                            sa.anneal_raw(ham, 1, betas, a.replicas)
+                            ms = lib.asp_sa_last_sweep_ms(ham.plan())
+                            best = ms if best is None else min(best, ms)
+                        flips = k * a.replicas * a.sweeps
+                        print("  M=%d threads=%4d cache=%d layout=%d  sweep %8.2f ms  %7.2f Gflips/s  total %.2f ms" % (
+                            m, th, cache, lib.asp_sa_last_layout(ham.plan()), best, flips / best / 1e6,
+                            lib.asp_sa_last_total_ms(ham.plan())), flush=True)
 
 
 if __name__ == "__main__":
