@@ -252,7 +252,9 @@ using LdsWord = __attribute__((address_space(3))) const uint32_t;
 //   kBits:  one bit per position, one replica (8x the capacity);
 //   kWide:  one 32-bit word per position, byte m = 0x80 * sign bit of replica m (M <= 4; fits
 //           up to ~4e4 spins): the +-1.0 multiplier of a term is then ONE SDWA instruction.
-constexpr int kBytes = 0, kBits = 1, kWide = 2;
+//   kGlobal: the bit words of kBits kept in HBM (one replica): no LDS limit on the size, every
+//           neighbour gather is an L2 access — the slow path for clusters beyond ~1.3e6 spins.
+constexpr int kBytes = 0, kBits = 1, kWide = 2, kGlobal = 3;
 
 // kWide: byte m of `word` (0x00 / 0x80) OR 0x3F becomes byte 3 of `hi`, whose lower three bytes
 // keep 0xF00000 — i.e. hi = high word of +1.0 or -1.0 — in one v_or_b32_sdwa (byte select on
@@ -292,7 +294,17 @@ __device__ __forceinline__ void accumulate_quad(const Quad &q, const uint8_t *sp
 #pragma unroll
   for (int j = 0; j < 4; ++j) s[j] = cs[j] & 15u;
 #else
-  if constexpr (LAYOUT == kWide) {
+  if constexpr (LAYOUT == kGlobal) {
+    // words written by other wavefronts of the workgroup during earlier colour steps: read at
+    // device scope (past the CU's vector L1)
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(spins);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t w = __hip_atomic_load(words + (cs[j] >> 5), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+      s[j] = (w >> (cs[j] & 31u)) & 1u;
+    }
+  } else if constexpr (LAYOUT == kWide) {
     // columns of the wide plan are LDS byte addresses (position * 4)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -376,7 +388,27 @@ struct SweepArgs {
   // last evaluation of every block, valid while the block's dirty byte in LDS is clear.
   double *field_cache;
   uint32_t cache_enter_flips;  // switch the cache on after a sweep with fewer flips than this
+  uint64_t *spin_words;        // kGlobal: [groups][num_blocks] sign-bit words in HBM
 };
+
+// One 64-spin word of the bit-packed layouts; device-scope accesses when it lives in HBM and
+// other wavefronts of the workgroup read it after the colour barrier.
+template <bool GLOBAL>
+__device__ __forceinline__ uint64_t load_word(const uint64_t *p) {
+  if constexpr (GLOBAL) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    return *p;
+  }
+}
+template <bool GLOBAL>
+__device__ __forceinline__ void store_word(uint64_t *p, uint64_t v) {
+  if constexpr (GLOBAL) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    *p = v;
+  }
+}
 
 template <int M, int LAYOUT>
 __device__ __forceinline__ void snapshot(const uint8_t *spins, const SweepArgs &a, uint32_t group,
@@ -397,10 +429,16 @@ __device__ __forceinline__ void snapshot(const uint8_t *spins, const SweepArgs &
     }
     return;
   }
-  if constexpr (LAYOUT == kBits) {  // the LDS words already are the packed sign bits
+  if constexpr (LAYOUT == kBits || LAYOUT == kGlobal) {  // the words already are the sign bits
     const uint64_t *words = reinterpret_cast<const uint64_t *>(spins);
     for (uint32_t w = threadIdx.x; w < a.num_blocks; w += blockDim.x) {
-      a.best_perm[static_cast<uint64_t>(group) * a.num_blocks + w] = words[w];
+      uint64_t word;
+      if constexpr (LAYOUT == kGlobal) {
+        word = __hip_atomic_load(words + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        word = words[w];
+      }
+      a.best_perm[static_cast<uint64_t>(group) * a.num_blocks + w] = word;
     }
     return;
   }
@@ -428,14 +466,18 @@ __device__ __forceinline__ void snapshot(const uint8_t *spins, const SweepArgs &
 // greedy solver's relaxation; the final configuration is snapshotted after every sweep.
 template <int M, bool DESCENT, int LAYOUT>
 __global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep(SweepArgs a) {
-  constexpr bool PACKED = LAYOUT == kBits;
+  constexpr bool GLOBAL = LAYOUT == kGlobal;
+  constexpr bool PACKED = LAYOUT == kBits || GLOBAL;  // one bit per position
   constexpr bool WIDE = LAYOUT == kWide;
-  static_assert(!PACKED || M == 1, "the bit-packed layout holds one replica");
+  static_assert(!PACKED || M == 1, "the bit-packed layouts hold one replica");
   static_assert(!WIDE || (M <= 4 && !DESCENT), "the wide layout holds up to four replicas");
   extern __shared__ __align__(16) uint8_t lds[];
-  uint8_t *spins = lds;
+  // kGlobal: this workgroup's bit words live in HBM, the LDS holds the bookkeeping only
+  uint8_t *spins = GLOBAL ? reinterpret_cast<uint8_t *>(a.spin_words +
+                                                       static_cast<uint64_t>(blockIdx.x) * a.num_blocks)
+                          : lds;
   // bytes of the spin area per block: 64 (a byte per position), 8 (a bit) or 256 (a word)
-  const uint32_t P = a.num_blocks * (PACKED ? 8u : (WIDE ? 256u : 64u));
+  const uint32_t P = GLOBAL ? 0u : a.num_blocks * (PACKED ? 8u : (WIDE ? 256u : 64u));
   // P is a multiple of 64.  Per replica m: delta[m] = energy change of the running
   // sweep, book[m] = current tracked energy, book[8+m] = best, book[16+m] = accepted flips
   long long *delta = reinterpret_cast<long long *>(lds + P);
@@ -445,7 +487,9 @@ __global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep(SweepArgs a) {
   // cache control: [0] flips of the running sweep, [1] 1 while the field cache is in use,
   // [2] 1 when the cache was just switched on (dirty bytes must be set);
   // then one dirty byte per block (bit m: replica m's cached fields are stale)
-  uint32_t *cache_ctl = reinterpret_cast<uint32_t *>(meta + a.num_blocks);
+  // (the bit-packed layout keeps no per-block arrays in LDS besides the spin words: block
+  // metadata is read from HBM with scalar loads, the field cache is not available)
+  uint32_t *cache_ctl = reinterpret_cast<uint32_t *>(meta + (PACKED ? 0u : a.num_blocks));
   uint8_t *dirty = reinterpret_cast<uint8_t *>(cache_ctl + 4);
   // one "inert" byte per block, meaningful while the dirty byte is clear: at the block's last
   // evaluation every proposal was a certain rejection (beta * dE >= 23 -> expneg = 0, or
@@ -494,15 +538,17 @@ __global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep(SweepArgs a) {
     }
     if constexpr (PACKED) {
       const uint64_t word = __ballot(byte & 1u);
-      if ((tid & 63u) == 0) reinterpret_cast<uint64_t *>(spins)[b0] = word;
+      if ((tid & 63u) == 0) store_word<GLOBAL>(reinterpret_cast<uint64_t *>(spins) + b0, word);
     } else if constexpr (WIDE) {
       reinterpret_cast<uint32_t *>(spins)[p] = spread_mask(byte);
     } else {
       spins[p] = static_cast<uint8_t>(byte);
     }
   }
-  for (uint32_t b = tid; b < a.num_blocks; b += blockDim.x) {
-    meta[b] = make_uint2(static_cast<uint32_t>(a.ell_off[b]), a.block_width[b]);
+  if constexpr (!PACKED) {
+    for (uint32_t b = tid; b < a.num_blocks; b += blockDim.x) {
+      meta[b] = make_uint2(static_cast<uint32_t>(a.ell_off[b]), a.block_width[b]);
+    }
   }
   if (tid < 32) delta[tid] = 0;  // delta[8] + book[24]
   if (tid == 0) {
@@ -560,7 +606,9 @@ __global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep(SweepArgs a) {
           }
 #endif
         }
-        const uint2 info = meta[b];  // {first slab, width}: one broadcast LDS read
+        // {first slab, width}: one broadcast LDS read (two scalar loads when bit-packed)
+        const uint2 info =
+            PACKED ? make_uint2(static_cast<uint32_t>(a.ell_off[b]), a.block_width[b]) : meta[b];
         // wave-uniform by construction; readfirstlane makes the loop control scalar
         const uint32_t quads = __builtin_amdgcn_readfirstlane(info.y) >> 2;
         // info.x = first slab of the block (a multiple of 4): quad index = slab / 4
@@ -621,7 +669,8 @@ __global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep(SweepArgs a) {
         const bool valid = spin != kDummySpin;
         uint32_t own;
         if constexpr (PACKED) {
-          own = static_cast<uint32_t>((reinterpret_cast<const uint64_t *>(spins)[b] >> lane) & 1ull);
+          own = static_cast<uint32_t>(
+              (load_word<GLOBAL>(reinterpret_cast<const uint64_t *>(spins) + b) >> lane) & 1ull);
         } else if constexpr (WIDE) {
           own = reinterpret_cast<const uint32_t *>(spins)[p];
         } else {
@@ -682,7 +731,10 @@ __global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep(SweepArgs a) {
         if constexpr (PACKED) {
           // the block's 64 proposals decided: one XOR of the ballot into the block's word
           const uint64_t flips = __ballot(flip != 0);
-          if (lane == 0 && flips != 0) reinterpret_cast<uint64_t *>(spins)[b] ^= flips;
+          if (lane == 0 && flips != 0) {
+            uint64_t *word = reinterpret_cast<uint64_t *>(spins) + b;
+            store_word<GLOBAL>(word, load_word<GLOBAL>(word) ^ flips);
+          }
         } else if constexpr (WIDE) {
           if (flip) reinterpret_cast<uint32_t *>(spins)[p] = own ^ spread_mask(flip);
         } else {
@@ -788,13 +840,20 @@ struct EnergyArgs {
   uint32_t num_blocks;
 };
 
+// STAGED: the configuration's sign words are copied to LDS first; otherwise (more blocks than the
+// LDS holds) they are gathered from HBM/L2 directly.
+template <bool STAGED>
 __global__ __launch_bounds__(512) void k_sa_energy_blocks(EnergyArgs a) {
   extern __shared__ __align__(16) uint8_t lds[];
-  uint64_t *bits = reinterpret_cast<uint64_t *>(lds);
   const uint32_t r = blockIdx.x;
   const uint64_t *mine = a.perm_words + static_cast<uint64_t>(r) * a.num_blocks;
-  for (uint32_t w = threadIdx.x; w < a.num_blocks; w += blockDim.x) bits[w] = mine[w];
-  __syncthreads();
+  const uint64_t *bits = mine;
+  if constexpr (STAGED) {
+    uint64_t *staged = reinterpret_cast<uint64_t *>(lds);
+    for (uint32_t w = threadIdx.x; w < a.num_blocks; w += blockDim.x) staged[w] = mine[w];
+    __syncthreads();
+    bits = staged;
+  }
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t waves = blockDim.x >> 6;
   for (uint32_t b = threadIdx.x >> 6; b < a.num_blocks; b += waves) {
@@ -896,7 +955,7 @@ struct asp_sa_plan {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   float last_sweep_ms = 0.0f, last_total_ms = 0.0f;
   int force_m = 0, force_threads = 0;
-  bool force_packed = false;
+  int force_packed = 0;  // asp_sa_set_packed: 0 auto, 1 bits in LDS, 2 bits in HBM
   bool allow_wide = true;  // asp_sa_set_wide
   int last_m = 0, last_threads = 0, last_groups = 0;
   std::vector<int64_t> last_tracked;
@@ -914,6 +973,7 @@ struct asp_sa_plan {
   DeviceBuffer<long long> w_tracked;
   DeviceBuffer<unsigned long long> w_accepted;
   DeviceBuffer<double> w_field_cache;  // [groups][blocks][M][64], see SweepArgs::field_cache
+  DeviceBuffer<uint64_t> w_spins;      // [groups][blocks] sign words of the HBM-resident layout
   bool use_field_cache = true;
 };
 
@@ -929,6 +989,9 @@ using SweepKernel = void (*)(SweepArgs);
 
 SweepKernel sweep_kernel_for(int m, bool descent, int layout) {
   if (layout == kBits) return descent ? k_sa_sweep<1, true, kBits> : k_sa_sweep<1, false, kBits>;
+  if (layout == kGlobal) {
+    return descent ? k_sa_sweep<1, true, kGlobal> : k_sa_sweep<1, false, kGlobal>;
+  }
   if (layout == kWide) return m == 4 ? k_sa_sweep<4, false, kWide> : nullptr;
   switch (m) {
     case 1: return descent ? k_sa_sweep<1, true, kBytes> : k_sa_sweep<1, false, kBytes>;
@@ -942,7 +1005,10 @@ SweepKernel sweep_kernel_for(int m, bool descent, int layout) {
 size_t sweep_lds_bytes(const asp::SaHostLayout &L, int layout) {
   // spins | delta[8] book[24] | flag (16 B) | meta[num_blocks]
   // ... | cache_ctl[4] | dirty[num_blocks] | inert[num_blocks] (each rounded up to 16 B)
-  const size_t per_block = layout == kBits ? 8 : (layout == kWide ? 256 : 64);
+  // bit-packed: spin words | delta book | flag | cache_ctl only
+  if (layout == kGlobal) return 34 * sizeof(long long) + 32;
+  if (layout == kBits) return static_cast<size_t>(L.num_blocks) * 8 + 34 * sizeof(long long) + 32;
+  const size_t per_block = layout == kWide ? 256 : 64;
   return static_cast<size_t>(L.num_blocks) * per_block + 34 * sizeof(long long) +
          static_cast<size_t>(L.num_blocks) * sizeof(uint2) + 16 +
          2 * (((static_cast<size_t>(L.num_blocks) + 15) / 16) * 16);
@@ -988,15 +1054,15 @@ int energies_of_perm(asp_sa_plan *p, const uint64_t *perm_words, uint32_t count,
                 p->field_pos.ptr,   perm_words,     partial,        L.num_blocks};
   const size_t lds = static_cast<size_t>(L.num_blocks) * sizeof(uint64_t);
   if (lds > p->max_lds) {
-    return asp::set_error(ASP_ERR_TOO_LARGE, "%u blocks do not fit the energy kernel's LDS",
-                          L.num_blocks);
+    hipLaunchKernelGGL(k_sa_energy_blocks<false>, dim3(count), dim3(512), 0, p->stream, ea);
+  } else {
+    if (lds > 64 * 1024) {
+      ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sa_energy_blocks<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(lds)));
+    }
+    hipLaunchKernelGGL(k_sa_energy_blocks<true>, dim3(count), dim3(512), lds, p->stream, ea);
   }
-  if (lds > 64 * 1024) {
-    ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sa_energy_blocks),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    static_cast<int>(lds)));
-  }
-  hipLaunchKernelGGL(k_sa_energy_blocks, dim3(count), dim3(512), lds, p->stream, ea);
   hipLaunchKernelGGL(k_sa_energy_fold, dim3(count), dim3(64), 0, p->stream, partial, L.num_blocks,
                      L.diag_sum, out_e);
   ASP_HIP_TRY(hipGetLastError());
@@ -1112,7 +1178,7 @@ int asp_sa_last_layout(asp_sa_plan const *p) { return p ? p->last_layout : -1; }
 
 int asp_sa_set_packed(asp_sa_plan *p, int packed) {
   if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
-  p->force_packed = packed != 0;
+  p->force_packed = packed < 0 ? 0 : (packed > 2 ? 2 : packed);
   return ASP_OK;
 }
 
@@ -1152,25 +1218,26 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
   if (descent) m = 1;
   // One byte per position when that fits the LDS; otherwise one BIT per position, one replica
   // per workgroup (flips applied by wavefront ballot) — 8x the capacity.
-  bool packed = p->force_packed;
+  bool packed = p->force_packed != 0;
   if (!packed && sweep_lds_bytes(L, kBytes) > p->max_lds) packed = true;
+  // not even a bit per position fits the LDS: keep the words in HBM (no size limit, slow)
+  const bool global = p->force_packed == 2 || (packed && sweep_lds_bytes(L, kBits) > p->max_lds);
   if (packed) m = 1;
   // A word per position (SDWA sign trick) when four replicas share the
   // workgroup and the words fit; results do not depend on the layout.
   // (measured: +2..12 % with four replicas per workgroup, nothing with two)
   const bool wide = !packed && !descent && p->allow_wide && m == 4 &&
                     p->ell_col4.ptr != nullptr && sweep_lds_bytes(L, kWide) <= p->max_lds;
-  const int layout = packed ? kBits : (wide ? kWide : kBytes);
+  const int layout = global ? kGlobal : (packed ? kBits : (wide ? kWide : kBytes));
   const size_t lds = sweep_lds_bytes(L, layout);
   if (lds > p->max_lds) {
-    return asp::set_error(ASP_ERR_TOO_LARGE,
-                          "%llu spins (%zu B of LDS even bit-packed) exceed the %zu B one "
-                          "workgroup may hold",
-                          (unsigned long long)K, lds, p->max_lds);
+    return asp::set_error(ASP_ERR_TOO_LARGE, "%zu B of LDS needed, %zu B available", lds,
+                          p->max_lds);
   }
   const uint32_t groups = (repetitions + m - 1) / m;
   const uint64_t padded = static_cast<uint64_t>(groups) * m;
   hipStream_t s = p->stream;
+  if (global) ASP_TRY(p->w_spins.ensure(static_cast<uint64_t>(groups) * L.num_blocks));
 
   DeviceBuffer<double> &d_betas = p->w_betas, &d_partial = p->w_partial, &d_e = p->w_e;
   DeviceBuffer<uint64_t> &d_best = p->w_best, &d_x0 = p->w_x0, &d_x0_perm = p->w_x0_perm,
@@ -1215,6 +1282,7 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
   args.replica_first = replica_offset;
   args.field_cache = nullptr;
   args.cache_enter_flips = 0;
+  args.spin_words = global ? p->w_spins.ptr : nullptr;
   if (p->use_field_cache && !packed) {  // (both the byte and the wide layout)
     // 512 B per block and replica; skipped when it would not fit comfortably in HBM
     const uint64_t cache_elems = padded * L.num_blocks * 64ull;

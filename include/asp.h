@@ -236,16 +236,19 @@ int asp_sa_layout_host(uint64_t num_spins, int64_t const *indptr, int32_t const 
  * replicas_per_group in {1,2,4,8}; threads multiple of 64, <= 1024. */
 int asp_sa_set_launch(asp_sa_plan *p, int replicas_per_group, int threads);
 
-/* LDS layout of the spins: by default one byte per spin position (bit m = replica m of the
- * workgroup), and automatically one BIT per position with one replica per workgroup when the
- * byte layout does not fit (K beyond ~1.4e5; capacity ~6.5e5 spins).  packed != 0 forces the
- * bit-packed layout (tests, measurements).  Results never depend on the layout. */
+/* Layout of the spins: by default one LDS byte per spin position (bit m = replica m of the
+ * workgroup); automatically one LDS BIT per position with one replica per workgroup when the
+ * bytes do not fit (K beyond ~1.4e5), and the same bit words kept in HBM when not even the
+ * bits fit (K beyond ~1.3e6; slow, but no size limit).  packed = 1 / 2 forces the LDS-bit /
+ * HBM-bit layout (tests, measurements), 0 restores the automatic choice.  Results never
+ * depend on the layout. */
 int asp_sa_set_packed(asp_sa_plan *p, int packed);
 
 /* With four replicas per workgroup and up to ~4e4 spins the kernel keeps a 32-bit word
  * per position (one byte per replica), which makes the sign of a coupling term a single SDWA
  * instruction.  allow = 0 keeps the byte layout (tests, measurements); default 1.
- * asp_sa_last_layout: 0 = bytes, 1 = bits, 2 = words, for the last anneal/greedy call. */
+ * asp_sa_last_layout: 0 = bytes, 1 = bits in LDS, 2 = words, 3 = bits in HBM, for the last
+ * anneal/greedy call. */
 int asp_sa_set_wide(asp_sa_plan *p, int allow);
 int asp_sa_last_layout(asp_sa_plan const *p);
 

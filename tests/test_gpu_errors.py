@@ -51,12 +51,11 @@ def test_plan_rejects_bad_matrices_and_oversized_problems():
     with pytest.raises(_lib.AspError) as err:
         ham.plan()
     assert err.value.code == -3
-    # more spins than one workgroup's LDS can hold even bit-packed: refused, not truncated
+    # more spins than one workgroup's LDS can hold even bit-packed: the sign words move to HBM
     n = 1500000
     big = sa.Hamiltonian(scipy.sparse.identity(n, format="csr"), np.zeros(n))
-    with pytest.raises(_lib.AspError) as err:
-        sa.anneal(big, seed=1, number_sweeps=1, repetitions=1)
-    assert err.value.code == -4
+    x, e = sa.anneal(big, seed=1, number_sweeps=1, repetitions=1)
+    assert e == float(n) and _lib.load().asp_sa_last_layout(big.plan()) == 3
     # arguments of anneal
     ok = sa.Hamiltonian(scipy.sparse.identity(5, format="csr"), np.zeros(5))
     with pytest.raises(ValueError):

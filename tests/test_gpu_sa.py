@@ -261,19 +261,22 @@ def _set_packed(h, packed):
     _lib.check(_lib.load().asp_sa_set_packed(h.plan(), int(packed)))
 
 
-@pytest.mark.parametrize("threads", [64, 256, 1024])
-def test_bit_packed_layout_bit_exact(threads):
-    """One LDS bit per spin, flips by wavefront ballot (the layout used beyond ~1.4e5 spins),
-    forced on a small instance: same chains as the oracle."""
+@pytest.mark.parametrize("threads,where", [(64, 1), (256, 1), (1024, 1), (64, 2), (512, 2)])
+def test_bit_packed_layout_bit_exact(threads, where):
+    """One bit per spin, flips by wavefront ballot, forced on a small instance: same chains as
+    the oracle.  where = 1: words in LDS (the layout used beyond ~1.4e5 spins); 2: words in HBM
+    (the layout used beyond ~1.3e6 spins, when not even the bits fit the LDS)."""
+    from annealing_sign_problem_amd import _lib
     from annealing_sign_problem_amd import annealer as sa
 
     J, h, _ = _planted(1500, 21)
     field = np.random.default_rng(5).normal(size=1500) * 0.01
     betas = np.geomspace(0.5, 2e4, 40)
     ham = sa.Hamiltonian(J, field)
-    _set_packed(ham, True)
+    _set_packed(ham, where)
     _set_launch(ham, 0, threads)
     xs, es = sa.anneal_raw(ham, 4242, betas, 9, 3)
+    assert _lib.load().asp_sa_last_layout(ham.plan()) == (1 if where == 1 else 3)
     tracked, accepted = _stats(ham, 9)
     oxs, oes, otr, oacc = oracle.sa_anneal(J, field, 4242, betas, 9, 3, None,
                                            ham.info().energy_scale_exp, num_threads=8)
@@ -283,6 +286,32 @@ def test_bit_packed_layout_bit_exact(threads):
     xs, es = sa.anneal_raw(ham, 1, betas[:10], 2, 0, x0)
     oxs, oes, _, _ = oracle.sa_anneal(J, field, 1, betas[:10], 2, 0, x0, ham.info().energy_scale_exp)
     assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+
+
+def test_beyond_lds_capacity_spins_in_hbm():
+    """K = 1.6e6 does not fit the LDS even at one bit per spin: the sign words move to HBM by
+    themselves.  Chains against a short oracle run, energies against numpy, and the greedy
+    solver (descent kernel in the same layout) against its oracle."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    n = 1600000
+    J, h, _ = _planted(n, 23, mean_degree=3.0, max_degree=8)
+    ham = sa.Hamiltonian(J, h)
+    info = ham.info()
+    betas = sa.make_schedule(info.beta0_auto, min(info.beta1_auto, 1e6), 3)
+    xs, es = sa.anneal_raw(ham, 78, betas, 3)
+    assert _lib.load().asp_sa_last_layout(ham.plan()) == 3
+    for r in range(3):
+        s = sa.bits_to_signs(xs[r], n)
+        ref = s @ (J @ s)
+        assert abs(es[r] - ref) <= 1e-12 * abs(ref)
+    oxs, oes, _, _ = oracle.sa_anneal(J, h, 78, betas, 2, 0, None, info.energy_scale_exp,
+                                      num_threads=2)
+    assert np.array_equal(xs[:2], oxs) and es[:2].tobytes() == oes.tobytes()
+    xg, eg = sa.greedy_solve(ham)
+    oxg, oeg = oracle.greedy_solve(J, h)
+    assert np.array_equal(xg, oxg) and eg == oeg
 
 
 def test_beyond_byte_layout_capacity():
