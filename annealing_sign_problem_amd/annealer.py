@@ -211,16 +211,19 @@ def anneal(hamiltonian: Hamiltonian, x0=None, seed=None, number_sweeps: int = 51
     repetitions = int(repetitions)
     if repetitions < 1:
         raise ValueError("'repetitions' must be positive")
-    seed = _resolve_seed(seed)
+    from . import distributed as _dist  # late import: torch is optional plumbing
+
+    sharded = distributed and _dist.world_size() > 1
+    seed = _dist.agree_on_seed(seed) if sharded else _resolve_seed(seed)
     if beta0 is None or beta1 is None:
         info = hamiltonian.info()
         beta0 = info.beta0_auto if beta0 is None else beta0
         beta1 = info.beta1_auto if beta1 is None else beta1
     betas = make_schedule(float(beta0), float(beta1), number_sweeps)
 
-    from . import distributed as _dist  # late import: torch is optional plumbing
-
-    if distributed and _dist.world_size() > 1:
+    if sharded and only_best:
+        return _dist.anneal_sharded_best(hamiltonian, seed, betas, repetitions, x0)
+    if sharded:
         xs, es = _dist.anneal_sharded(hamiltonian, seed, betas, repetitions, x0)
     else:
         xs, es = anneal_raw(hamiltonian, seed, betas, repetitions, 0, x0)

@@ -92,3 +92,70 @@ def anneal_sharded(hamiltonian, seed: int, betas: np.ndarray, repetitions: int, 
     xs_all = np.ascontiguousarray(full[:, :words]).view(np.uint64)
     es_all = np.ascontiguousarray(full[:, words]).view(np.float64)
     return xs_all, es_all
+
+
+def _device_for(group=None):
+    import torch
+    import torch.distributed as dist
+
+    backend = dist.get_backend(group)
+    return torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+
+
+def agree_on_seed(seed: Optional[int], group=None) -> int:
+    """``seed=None`` means "draw one": rank 0 draws, everybody uses it (otherwise the ranks would
+    run chains of different random streams and the gathered result would depend on the world
+    size).  A given seed passes through."""
+    import torch
+    import torch.distributed as dist
+
+    from .annealer import _resolve_seed
+
+    value = _resolve_seed(seed)
+    if seed is not None:
+        return value
+    box = torch.tensor([value - (1 << 64) if value >= (1 << 63) else value], dtype=torch.int64,
+                       device=_device_for(group))
+    dist.broadcast(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return int(box.item()) & (2**64 - 1)
+
+
+def anneal_sharded_best(hamiltonian, seed: int, betas: np.ndarray, repetitions: int, x0=None,
+                        group=None):
+    """``only_best=True`` without moving every chain: each rank reduces its own block, one
+    all_gather of (energy, global replica id) per rank names the winner — lowest energy, lowest
+    id among equals, i.e. the first minimum of the single-GPU result — and the winner's rank
+    broadcasts its configuration.  16 B per rank + one configuration instead of R of them."""
+    import torch
+    import torch.distributed as dist
+
+    from .annealer import anneal_raw
+
+    world = dist.get_world_size(group)
+    me = dist.get_rank(group)
+    offset, count = shard_range(repetitions, world, me)
+    words = (hamiltonian.size + 63) // 64
+    device = _device_for(group)
+    mine = np.array([np.iinfo(np.int64).max, np.iinfo(np.int64).max], dtype=np.int64)
+    local_x = np.zeros(max(words, 1), dtype=np.uint64)
+    local_e = np.inf
+    if count > 0:
+        xs, es = anneal_raw(hamiltonian, seed, betas, count, offset, x0)
+        best = int(np.argmin(es))
+        local_x[:words] = xs[best]
+        local_e = float(es[best])
+        mine[0] = np.float64(local_e).view(np.int64)
+        mine[1] = offset + best
+    parts = [torch.empty(2, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(parts, torch.from_numpy(mine).to(device), group=group)
+    table = np.stack([p.cpu().numpy() for p in parts])
+    energies = table[:, 0].copy().view(np.float64)
+    energies[table[:, 1] == np.iinfo(np.int64).max] = np.inf  # ranks without chains
+    lowest = energies.min()
+    candidates = np.nonzero(energies == lowest)[0]
+    winner = int(candidates[np.argmin(table[candidates, 1])])
+    box = torch.from_numpy(local_x.view(np.int64).copy()).to(device)
+    src = dist.get_global_rank(group, winner) if group is not None else winner
+    dist.broadcast(box, src=src, group=group)
+    x = box.cpu().numpy().view(np.uint64)[:words].copy()
+    return x, float(lowest)

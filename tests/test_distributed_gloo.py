@@ -46,11 +46,17 @@ def _worker(rank, world, port, repetitions, out_dir):
     ham.info = lambda: annealer_info
     x, e = annealer.anneal(ham, seed=999, number_sweeps=15, repetitions=repetitions)
     np.savez(os.path.join(out_dir, "best%d.npz" % rank), x=x, e=e)
+    xs_all, es_all = annealer.anneal(ham, seed=999, number_sweeps=15, repetitions=repetitions,
+                                     only_best=False)
+    assert np.array_equal(xs_all, xs) and es_all.tobytes() == es.tobytes()
+    # seed=None: rank 0 draws, every rank must run the same stream
+    xr, er = annealer.anneal(ham, seed=None, number_sweeps=15, repetitions=repetitions)
+    np.savez(os.path.join(out_dir, "drawn%d.npz" % rank), x=xr, e=er)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("repetitions", [7, 2])
+@pytest.mark.parametrize("repetitions", [7, 2, 1])
 def test_sharded_anneal_equals_single_process(tmp_path, repetitions):
     import torch.multiprocessing as mp
 
@@ -69,3 +75,5 @@ def test_sharded_anneal_equals_single_process(tmp_path, repetitions):
         best = np.load(tmp_path / ("best%d.npz" % rank))
         k = int(np.argmin(es))
         assert np.array_equal(best["x"], xs[k]) and float(best["e"]) == es[k]
+    drawn = [np.load(tmp_path / ("drawn%d.npz" % rank)) for rank in range(world)]
+    assert np.array_equal(drawn[0]["x"], drawn[1]["x"]) and float(drawn[0]["e"]) == float(drawn[1]["e"])
