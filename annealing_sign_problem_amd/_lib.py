@@ -78,6 +78,10 @@ SIGNATURES = {
     "asp_operator_extend": (c_int, [c_void_p, c_u64, c_void_p, c_u64, c_void_p,
                                     ctypes.POINTER(c_u64)]),
     "asp_operator_last_ms": (c_float, []),
+    "asp_sparsify_component": (c_int, [c_u64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       ctypes.c_double, c_u64, c_void_p, ctypes.POINTER(c_u64),
+                                       c_u64, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_u64)]),
+    "asp_sparsify_last_ms": (c_float, []),
     "asp_sa_plan_create": (c_void_p, [c_u64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "asp_sa_plan_destroy": (None, [c_void_p]),
     "asp_sa_plan_info": (c_int, [c_void_p, ctypes.POINTER(SaInfo)]),

@@ -16,7 +16,6 @@ from typing import Any, Callable, Optional, Tuple
 
 import numpy as np
 import scipy.sparse
-from scipy.sparse.csgraph import connected_components
 
 from . import _lib
 from . import annealer as sa
@@ -260,34 +259,49 @@ def get_strongest_off_diag(matrix) -> np.ndarray:
     return out
 
 
+def sparsify_component(exchange, is_frozen, reltol: float, anchor: int):
+    """``(keep bool[K], block csr_matrix)`` through ``asp_sparsify_component``: cutoff, component
+    of ``anchor`` and the un-pruned block on it, all on the GPU (csrc/sparsify.hip)."""
+    lib = _lib.load()
+    _lib.require_gpu()
+    full = scipy.sparse.csr_matrix(exchange)
+    if not full.has_sorted_indices:
+        full = full.sorted_indices()
+    full.sum_duplicates()
+    k = full.shape[0]
+    indptr = np.ascontiguousarray(full.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(full.indices, dtype=np.int32)
+    data = np.ascontiguousarray(full.data, dtype=np.float64)
+    frozen = np.ascontiguousarray(is_frozen, dtype=np.uint8)
+    keep = np.zeros(max(k, 1), dtype=np.uint8)
+    kept, nnz = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    capacity = int(data.shape[0])
+    out_indptr = np.zeros(k + 1, dtype=np.int64)
+    out_indices = np.empty(max(capacity, 1), dtype=np.int32)
+    out_data = np.empty(max(capacity, 1), dtype=np.float64)
+    _lib.check(lib.asp_sparsify_component(
+        ctypes.c_uint64(k), _lib.ptr(indptr), _lib.ptr(indices), _lib.ptr(data), _lib.ptr(frozen),
+        ctypes.c_double(float(reltol)), ctypes.c_uint64(int(anchor)), _lib.ptr(keep),
+        ctypes.byref(kept), ctypes.c_uint64(capacity), _lib.ptr(out_indptr), _lib.ptr(out_indices),
+        _lib.ptr(out_data), ctypes.byref(nnz)))
+    n, z = int(kept.value), int(nnz.value)
+    block = scipy.sparse.csr_matrix((out_data[:z].copy(), out_indices[:z].copy(),
+                                     out_indptr[:n + 1].astype(np.int32)), shape=(n, n))
+    return keep[:k].astype(bool), block
+
+
 def sparsify_using_global_cutoff(model: IsingModel, reltol: float, frozen_spins) -> IsingModel:
     """Drop couplings below ``reltol * max|J|`` (unless both ends are frozen) and keep
     the connected component that holds the frozen spins (common.py:634-692)."""
     frozen = binary_search(model.spins, frozen_spins)
     is_frozen = np.zeros(model.spins.shape[0], dtype=bool)
     is_frozen[frozen] = True
-
-    full = model.ising_hamiltonian.exchange.tocsr()
-    rows = np.repeat(np.arange(full.shape[0]), np.diff(full.indptr))
-    data = full.data.copy()
-    if data.size:
-        threshold = reltol * np.max(np.abs(data))
-        weak = (np.abs(data) < threshold) & ~(is_frozen[rows] & is_frozen[full.indices])
-        data[weak] = 0
-    pruned = scipy.sparse.csr_matrix((data, full.indices, full.indptr), shape=full.shape)
-    pruned = 0.5 * (pruned + pruned.transpose())
-    pruned.eliminate_zeros()
-
-    _, component = connected_components(pruned, directed=False)
-    wanted = component[frozen[0]]
-    assert np.all(component[frozen] == wanted)
-    keep = component == wanted
-
+    # NB: like the reference (common.py:674) the kept block comes from the UN-pruned matrix:
+    # the cutoff only decides which spins survive.
+    keep, exchange = sparsify_component(model.ising_hamiltonian.exchange, is_frozen, reltol,
+                                        int(frozen[0]))
     spins = model.spins[keep]
     signs = sa.bits_to_signs(model.initial_signs, model.size)[keep]
-    # NB: like the reference (common.py:674) the kept block comes from the
-    # UN-pruned matrix: the cutoff only decides which spins survive.
-    exchange = model.ising_hamiltonian.exchange[keep][:, keep]
     field = model.ising_hamiltonian.field[keep]
     return IsingModel(spins, model.quantum_hamiltonian, sa.Hamiltonian(exchange, field),
                       sa.signs_to_bits(signs))

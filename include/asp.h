@@ -194,6 +194,27 @@ int asp_operator_extend(asp_operator const *op, uint64_t n, uint64_t const *keys
 float asp_operator_last_ms(void);
 
 /* ------------------------------------------------------------------------- */
+/* (3c) Global-cutoff sparsification + component extraction                  */
+/* ------------------------------------------------------------------------- */
+
+/* sparsify_using_global_cutoff (annealing_sign_problem/common.py:634-692) on a CSR matrix
+ * (rows sorted by column, no duplicates):
+ *   M'_ij = 0 where |M_ij| < reltol * max|M| unless spins i and j are both frozen   (:634-643)
+ *   graph = non-zeros of 0.5 * (M' + M'^T)                                         (:660-662)
+ *   keep[i] = 1 iff i is connected to `anchor` in that graph                        (:664-668)
+ *   out_* = M[keep][:, keep], the UN-pruned block, as CSR with remapped columns    (:674)
+ * Fails with ASP_ERR_INVALID when a frozen spin is not in the anchor's component (the
+ * reference asserts it, :666).  *kept_spins and *out_nnz always receive the sizes; pass
+ * capacity 0 and NULL out_* to get the mask only.  out_indptr needs *kept_spins + 1 entries. */
+int asp_sparsify_component(uint64_t num_spins, int64_t const *indptr, int32_t const *indices,
+                           double const *data, uint8_t const *is_frozen, double reltol,
+                           uint64_t anchor, uint8_t *keep, uint64_t *kept_spins,
+                           uint64_t capacity, int64_t *out_indptr, int32_t *out_indices,
+                           double *out_data, uint64_t *out_nnz);
+/* Device time (ms) of this thread's last asp_sparsify_component call, copies excluded. */
+float asp_sparsify_last_ms(void);
+
+/* ------------------------------------------------------------------------- */
 /* (4) Annealer: replaces ising_glass_annealer.{Hamiltonian,anneal}          */
 /*     call sites: common.py:204,242-248; full_hilbert_space.py:212-218      */
 /* ------------------------------------------------------------------------- */

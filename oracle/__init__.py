@@ -287,3 +287,10 @@ def operator_extend(bond_table, keys):
     if count == 2 ** 64 - 1:
         raise MemoryError("oracle_operator_extend")
     return out[:count].copy()
+
+
+# ----------------------------------------------------------------------------
+# global-cutoff sparsification (sparsify_oracle.py)
+# ----------------------------------------------------------------------------
+
+from .sparsify_oracle import sparsify_component  # noqa: E402,F401

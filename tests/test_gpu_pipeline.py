@@ -75,3 +75,62 @@ def test_cluster_growth_on_gpu_action_equals_host_action(models):
         on_host = sampled_components.create_small_cluster_around_point(start, Foreign(),
                                                                        required_size=size)
         assert on_gpu == on_host and len(on_gpu) == size
+
+
+def test_sparsify_on_gpu_matches_reference_golden_and_oracle():
+    """asp_sparsify_component: cutoff + connected component + un-pruned block, against the
+    reference's own sparsify output and the scipy oracle on random non-symmetric matrices."""
+    import scipy.sparse
+
+    import oracle
+    from conftest import golden
+    from annealing_sign_problem_amd import _lib, common
+    from annealing_sign_problem_amd import annealer as sa
+
+    g = golden("make_ising_kagome16_cluster.npz")
+    n = g["ext_spins"].shape[0]
+    ext = scipy.sparse.coo_matrix((g["ext_data"], (g["ext_row"], g["ext_col"])), shape=(n, n))
+    idx = np.searchsorted(g["basis_states"], g["ext_spins"])
+    psi = g["ground_state"][idx]
+    model = common.IsingModel(g["ext_spins"], None, sa.Hamiltonian(ext, np.zeros(n)),
+                              sa.signs_to_bits(np.sign(psi)))
+    out = common.sparsify_using_global_cutoff(model, float(g["sp_reltol"]), g["spins"])
+    assert np.array_equal(out.spins, g["sp_spins"])
+    m = scipy.sparse.coo_matrix(out.ising_hamiltonian.exchange)
+    assert np.array_equal(m.row, g["sp_row"]) and np.array_equal(m.col, g["sp_col"])
+    assert m.data.tobytes() == g["sp_data"].tobytes()
+    assert np.array_equal(out.initial_signs, g["sp_x0"])
+
+    rng = np.random.default_rng(8)
+    for trial, (size, density, symmetric) in enumerate([(300, 0.02, True), (800, 0.006, False),
+                                                        (2000, 0.002, False), (50, 0.3, True)]):
+        a = scipy.sparse.random(size, size, density=density, random_state=trial, format="csr",
+                                data_rvs=lambda k: rng.normal(size=k) * np.exp(rng.normal(size=k) * 3))
+        a = (a + a.T).tocsr() if symmetric else a.tocsr()
+        a.sort_indices()
+        frozen = np.zeros(size, dtype=bool)
+        anchor = int(rng.integers(size))
+        frozen[anchor] = True
+        for reltol in (0.0, 1e-3, 0.3):
+            keep_o, block_o = oracle.sparsify_component(a, frozen, reltol, anchor)
+            keep, block = common.sparsify_component(a, frozen, reltol, anchor)
+            assert np.array_equal(keep, keep_o)
+            bo = scipy.sparse.csr_matrix(block_o)
+            bo.sort_indices()
+            assert np.array_equal(block.indptr, bo.indptr)
+            assert np.array_equal(block.indices, bo.indices)
+            assert block.data.tobytes() == bo.data.tobytes()
+        # freezing a second spin of the anchor's component keeps pairs of frozen spins coupled
+        keep_o, _ = oracle.sparsify_component(a, frozen, 0.0, anchor)
+        others = np.nonzero(keep_o)[0]
+        if others.size > 3:
+            frozen2 = frozen.copy()
+            frozen2[others[-1]] = True
+            k1, _ = common.sparsify_component(a, frozen2, 0.0, anchor)
+            assert np.array_equal(k1, keep_o)
+    # a frozen spin cut off by the cutoff: the reference asserts, the library reports
+    lonely = scipy.sparse.csr_matrix(np.array([[0, 1.0, 0], [1.0, 0, 1e-9], [0, 1e-9, 0]]))
+    with pytest.raises(_lib.AspError, match="frozen"):
+        common.sparsify_component(lonely, np.array([True, False, True]), 1e-3, 0)
+    keep, block = common.sparsify_component(lonely, np.array([True, False, False]), 1e-3, 0)
+    assert keep.tolist() == [True, True, False] and block.shape == (2, 2)

@@ -86,26 +86,26 @@ def test_accuracy_and_overlap_match_reference_golden():
         common.compute_accuracy_and_overlap(g["predicted"][0], g["exact"])
 
 
-def test_sparsify_matches_reference_golden():
-    """common.py:634-692 on the reference's own output (host numpy/scipy; the
-    Hamiltonian objects never touch the device here)."""
-    from annealing_sign_problem_amd import common
-    from annealing_sign_problem_amd import annealer as sa
+def test_sparsify_oracle_matches_reference_golden():
+    """oracle/sparsify_oracle.py (numpy/scipy restatement of common.py:634-692) on the
+    reference's own output: mask and kept block equal what the reference returned."""
+    import oracle
 
     g = golden("make_ising_kagome16_cluster.npz")
     n = g["ext_spins"].shape[0]
     ext = scipy.sparse.coo_matrix((g["ext_data"], (g["ext_row"], g["ext_col"])), shape=(n, n))
-    log_psi = np.log(np.abs(g["ground_state"]) + 0j)
-    idx = np.searchsorted(g["basis_states"], g["ext_spins"])
-    psi = g["ground_state"][idx]
-    model = common.IsingModel(g["ext_spins"], None, sa.Hamiltonian(ext, np.zeros(n)),
-                              sa.signs_to_bits(np.sign(psi)))
-    out = common.sparsify_using_global_cutoff(model, float(g["sp_reltol"]), g["spins"])
-    assert np.array_equal(out.spins, g["sp_spins"])
-    m = scipy.sparse.coo_matrix(out.ising_hamiltonian.exchange)
+    frozen = np.zeros(n, dtype=bool)
+    at = np.searchsorted(g["ext_spins"], g["spins"])
+    frozen[at] = True
+    keep, block = oracle.sparsify_component(ext, frozen, float(g["sp_reltol"]), int(at[0]))
+    assert np.array_equal(g["ext_spins"][keep], g["sp_spins"])
+    m = scipy.sparse.coo_matrix(block)
     assert np.array_equal(m.row, g["sp_row"]) and np.array_equal(m.col, g["sp_col"])
     assert m.data.tobytes() == g["sp_data"].tobytes()
-    assert np.array_equal(out.initial_signs, g["sp_x0"])
+    # a cutoff that cuts a frozen spin off trips the reference's assertion
+    lonely = scipy.sparse.csr_matrix(np.array([[0, 1.0, 0], [1.0, 0, 1e-9], [0, 1e-9, 0]]))
+    with pytest.raises(AssertionError):
+        oracle.sparsify_component(lonely, np.array([True, False, True]), 1e-3, 0)
 
 
 def test_strongest_off_diag_and_binary_search():
