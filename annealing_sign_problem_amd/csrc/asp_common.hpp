@@ -61,6 +61,23 @@ void pool_free(void *ptr);
 int stream_acquire(hipStream_t *out);
 void stream_release(hipStream_t stream);
 
+// A pooled stream for the duration of one synchronous entry point, so that calls from
+// different host threads (sampled_components --jobs) overlap on the GPU instead of queueing
+// on the null stream.  The entry point synchronises the stream before it returns.
+struct ScopedStream {
+  hipStream_t stream = nullptr;
+  ScopedStream() = default;
+  ScopedStream(const ScopedStream &) = delete;
+  ScopedStream &operator=(const ScopedStream &) = delete;
+  int acquire() { return stream_acquire(&stream); }
+  ~ScopedStream() {
+    if (stream) {
+      (void)hipStreamSynchronize(stream);
+      stream_release(stream);
+    }
+  }
+};
+
 // Compute units and opt-in LDS bytes per workgroup of the current device (queried once).
 int device_limits(int *num_cus, size_t *max_lds);
 

@@ -98,7 +98,9 @@ extern "C" int asp_ising_elements(uint64_t num_spins, uint64_t const *keys, doub
   for (uint64_t i = 1; i < K; ++i) {
     if (keys[i - 1] > keys[i]) return asp::set_error(ASP_ERR_INVALID, "keys are not sorted");
   }
-  hipStream_t stream = nullptr;  // default stream: this entry point is synchronous
+  asp::ScopedStream scoped;
+  ASP_TRY(scoped.acquire());
+  hipStream_t stream = scoped.stream;  // this entry point is synchronous
   DeviceBuffer<uint64_t> d_keys, d_other;
   DeviceBuffer<double> d_psi, d_coeffs, d_elements;
   DeviceBuffer<int64_t> d_counts, d_offsets, d_scratch, d_index;

@@ -474,7 +474,9 @@ int asp_operator_apply(asp_operator const *op, uint64_t n, uint64_t const *keys,
   asp_clear_error();
   ASP_TRY(check_operator(op));
   if (n && !keys) return asp::set_error(ASP_ERR_INVALID, "null keys");
-  hipStream_t stream = nullptr;
+  asp::ScopedStream scoped;
+  ASP_TRY(scoped.acquire());
+  hipStream_t stream = scoped.stream;
   Timer timer;
   ApplyBatch w;
   ASP_TRY(timer.start(stream));
@@ -525,7 +527,9 @@ int asp_operator_ising(asp_operator const *op, uint64_t num_spins, uint64_t cons
     }
   }
   if (K == 0) return ASP_OK;
-  hipStream_t stream = nullptr;
+  asp::ScopedStream scoped;
+  ASP_TRY(scoped.acquire());
+  hipStream_t stream = scoped.stream;
   uint64_t slots_n = 1024;
   while (slots_n < 2 * K) slots_n <<= 1;
   DeviceBuffer<uint64_t> d_keys;
@@ -615,7 +619,9 @@ int asp_operator_extend(asp_operator const *op, uint64_t n, uint64_t const *keys
   *count = 0;
   if (n && !keys) return asp::set_error(ASP_ERR_INVALID, "null keys");
   if (n == 0) return ASP_OK;
-  hipStream_t stream = nullptr;
+  asp::ScopedStream scoped;
+  ASP_TRY(scoped.acquire());
+  hipStream_t stream = scoped.stream;
   Timer timer;
   ApplyBatch w;
   ASP_TRY(timer.start(stream));

@@ -6,7 +6,7 @@
 // in one call, CSR in and CSR out.
 //
 // HBM layout: indptr i64[K+1], indices i32[nnz], data f64[nnz] (rows sorted by column), frozen
-// u8[K]; parent u32[K] (union-find forest); keep u8[K]; new_index i64[K+1] (scan of keep);
+// u8[K]; parent u32[K] (union-find forest), root u32[K]; keep u32[K]; new_index i64[K+1] (scan of keep);
 // row_kept u32[K] -> out_indptr (scan); out_indices i32[], out_data f64[].
 // Kernels (one stream): k_abs_max (exact: max is order-independent) -> k_hook_edges (one
 // wavefront per row; an edge (i, j) exists iff 0.5 * (M'_ij + M'_ji) != 0 with M' the pruned
@@ -131,12 +131,15 @@ __global__ __launch_bounds__(kThreads) void k_hook_edges(GraphArgs a) {
   }
 }
 
-__global__ __launch_bounds__(kThreads) void k_flatten(uint32_t *parent, uint64_t n) {
+// Roots into a SEPARATE array with a read-only walk: compressing in place here would let one
+// thread's path halving overwrite the root another thread has just stored.
+__global__ __launch_bounds__(kThreads) void k_flatten(const uint32_t *__restrict__ parent,
+                                                     uint32_t *__restrict__ root, uint64_t n) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x;
-  if (i < n) {
-    const uint32_t root = find_root(parent, static_cast<uint32_t>(i));
-    __hip_atomic_store(&parent[i], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (i >= n) return;
+  uint32_t x = static_cast<uint32_t>(i);
+  for (uint32_t p = parent[x]; p != x; p = parent[x]) x = p;
+  root[i] = x;
 }
 
 // keep[i] = same component as the anchor; stray[0] counts frozen spins outside it.
@@ -147,8 +150,7 @@ __global__ __launch_bounds__(kThreads) void k_mark_component(const uint32_t *__r
                                                             uint32_t *__restrict__ stray) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x;
   if (i >= n) return;
-  // k_flatten made every parent a root, and roots are final
-  const bool in = parent[i] == parent[anchor];
+  const bool in = parent[i] == parent[anchor];  // `parent` is k_flatten's root array here
   keep[i] = in ? 1u : 0u;
   if (frozen[i] && !in) atomicAdd(stray, 1u);
 }
@@ -235,18 +237,21 @@ extern "C" int asp_sparsify_component(uint64_t num_spins, int64_t const *indptr,
       }
     }
   }
-  hipStream_t stream = nullptr;
+  asp::ScopedStream scoped;
+  ASP_TRY(scoped.acquire());
+  hipStream_t stream = scoped.stream;
   DeviceBuffer<int64_t> d_indptr, d_new_index, d_out_indptr, d_scratch;
   DeviceBuffer<int32_t> d_indices, d_out_indices;
   DeviceBuffer<double> d_data, d_out_data;
   DeviceBuffer<uint8_t> d_frozen;
-  DeviceBuffer<uint32_t> d_parent, d_keep, d_row_kept, d_stray;
+  DeviceBuffer<uint32_t> d_parent, d_root, d_keep, d_row_kept, d_stray;
   DeviceBuffer<unsigned long long> d_max;
   ASP_TRY(d_indptr.alloc(K + 1));
   ASP_TRY(d_indices.alloc(nnz));
   ASP_TRY(d_data.alloc(nnz));
   ASP_TRY(d_frozen.alloc(K));
   ASP_TRY(d_parent.alloc(K));
+  ASP_TRY(d_root.alloc(K));
   ASP_TRY(d_keep.alloc(K));
   ASP_TRY(d_new_index.alloc(K + 1));
   ASP_TRY(d_scratch.alloc(asp::scan_scratch_elems(K)));
@@ -285,9 +290,9 @@ extern "C" int asp_sparsify_component(uint64_t num_spins, int64_t const *indptr,
                      d_parent.ptr, K);
   hipLaunchKernelGGL(k_hook_edges, dim3(grid_for(K, kWaves)), dim3(kThreads), 0, stream, g);
   hipLaunchKernelGGL(k_flatten, dim3(grid_for(K, kThreads)), dim3(kThreads), 0, stream,
-                     d_parent.ptr, K);
+                     d_parent.ptr, d_root.ptr, K);
   hipLaunchKernelGGL(k_mark_component, dim3(grid_for(K, kThreads)), dim3(kThreads), 0, stream,
-                     d_parent.ptr, d_frozen.ptr, K, anchor, d_keep.ptr, d_stray.ptr);
+                     d_root.ptr, d_frozen.ptr, K, anchor, d_keep.ptr, d_stray.ptr);
   ASP_HIP_TRY(hipGetLastError());
   ASP_TRY(asp::exclusive_scan_u32(d_keep.ptr, K, d_new_index.ptr, d_scratch.ptr, stream));
   int64_t kept = 0;

@@ -134,3 +134,35 @@ def test_sparsify_on_gpu_matches_reference_golden_and_oracle():
         common.sparsify_component(lonely, np.array([True, False, True]), 1e-3, 0)
     keep, block = common.sparsify_component(lonely, np.array([True, False, False]), 1e-3, 0)
     assert keep.tolist() == [True, True, False] and block.shape == (2, 2)
+
+
+def test_components_on_long_chains_match_scipy():
+    """Path-like graphs in random vertex order give the concurrent union-find long parent chains
+    (the case where an in-place flatten would race); every trial must equal scipy."""
+    import scipy.sparse
+
+    import oracle
+    from annealing_sign_problem_amd import common
+
+    rng = np.random.default_rng(1)
+    for trial in range(40):
+        n = int(rng.integers(50, 30000))
+        perm = rng.permutation(n)
+        cut = rng.random(n - 1) < 0.98
+        rows = np.concatenate([perm[:-1][cut], rng.integers(0, n, n // 20)])
+        cols = np.concatenate([perm[1:][cut], rng.integers(0, n, n // 20)])
+        vals = rng.normal(size=rows.size) * np.exp(rng.normal(size=rows.size) * 3)
+        a = scipy.sparse.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
+        a = (a + a.T).tocsr() if trial % 2 == 0 else a
+        a.sum_duplicates()
+        a.sort_indices()
+        frozen = np.zeros(n, dtype=bool)
+        anchor = int(rng.integers(n))
+        frozen[anchor] = True
+        reltol = [0.0, 1e-4, 1e-2][trial % 3]
+        keep_o, block_o = oracle.sparsify_component(a, frozen, reltol, anchor)
+        keep, block = common.sparsify_component(a, frozen, reltol, anchor)
+        bo = scipy.sparse.csr_matrix(block_o)
+        bo.sort_indices()
+        assert np.array_equal(keep, keep_o), trial
+        assert np.array_equal(block.indices, bo.indices) and block.data.tobytes() == bo.data.tobytes()
