@@ -213,7 +213,7 @@ def anneal(hamiltonian: Hamiltonian, x0=None, seed=None, number_sweeps: int = 51
         raise ValueError("'repetitions' must be positive")
     from . import distributed as _dist  # late import: torch is optional plumbing
 
-    sharded = distributed and _dist.world_size() > 1
+    sharded = distributed and _dist.shards_chains()
     seed = _dist.agree_on_seed(seed) if sharded else _resolve_seed(seed)
     if beta0 is None or beta1 is None:
         info = hamiltonian.info()

@@ -159,3 +159,46 @@ def anneal_sharded_best(hamiltonian, seed: int, betas: np.ndarray, repetitions: 
     dist.broadcast(box, src=src, group=group)
     x = box.cpu().numpy().view(np.uint64)[:words].copy()
     return x, float(lowest)
+
+
+_chains_local = 0
+
+
+class chains_local:
+    """Context manager: inside it ``annealer.anneal`` keeps all chains of a call on this rank
+    (no collectives) — needed when the ranks work on DIFFERENT problems, as in
+    :func:`map_sharded`."""
+
+    def __enter__(self):
+        global _chains_local
+        _chains_local += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _chains_local
+        _chains_local -= 1
+        return False
+
+
+def shards_chains() -> bool:
+    """True when ``annealer.anneal`` should split its repetitions over the ranks."""
+    return _chains_local == 0 and world_size() > 1
+
+
+def map_sharded(items, work, group=None):
+    """``[work(x) for x in items]`` with item ``c`` computed on rank ``c mod world`` (SURVEY §8e:
+    cluster instances are independent problems) and the picklable results gathered on every
+    rank, in item order.  Single process: a plain loop."""
+    d = _dist()
+    if d is None or d.get_world_size(group) == 1:
+        return [work(x) for x in items]
+    world, me = d.get_world_size(group), d.get_rank(group)
+    with chains_local():
+        mine = [(c, work(x)) for c, x in enumerate(items) if c % world == me]
+    parts = [None] * world
+    d.all_gather_object(parts, mine, group=group)
+    out = [None] * len(items)
+    for part in parts:
+        for c, result in part:
+            out[c] = result
+    return out

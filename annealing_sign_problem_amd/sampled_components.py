@@ -185,9 +185,12 @@ def parse_command_line(argv=None):
 
 
 def main(argv=None):
+    from . import distributed as asp_dist
+
     args = parse_command_line(argv)
     np.random.seed(args.seed)
-    if os.path.exists(args.output):
+    writer = asp_dist.rank() == 0  # under torch.distributed only rank 0 touches the file
+    if writer and os.path.exists(args.output):
         raise SystemExit("Output file '{}' already exists: refusing to overwrite".format(args.output))
     models = synthetic.load_models()
     hamiltonian = operators.Operator.from_config(models[args.model])
@@ -201,19 +204,33 @@ def main(argv=None):
     clusters = generate_clusters(hamiltonian, ground_state, args.number_samples,
                                  args.sampled_power, args.min_cluster_size,
                                  args.max_cluster_size, args.keep_probability)
-    with open(args.output, "w") as f:
-        f.write("# Generated by annealing_sign_problem_amd.sampled_components\n")
-        for key in ["seed", "order", "noise", "global_cutoff", "sampled_power", "min_cluster_size",
-                    "max_cluster_size", "keep_probability", "number_sweeps", "repetitions"]:
-            f.write("# {} = {}\n".format(key, getattr(args, key)))
-        f.write("# {}\n".format(OptimizationResult.csv_header()))
+    if writer:
+        with open(args.output, "w") as f:
+            f.write("# Generated by annealing_sign_problem_amd.sampled_components\n")
+            for key in ["seed", "order", "noise", "global_cutoff", "sampled_power",
+                        "min_cluster_size", "max_cluster_size", "keep_probability",
+                        "number_sweeps", "repetitions"]:
+                f.write("# {} = {}\n".format(key, getattr(args, key)))
+            f.write("# {}\n".format(OptimizationResult.csv_header()))
     def work(cluster):
         return process_cluster(cluster, hamiltonian, ground_state, noisy_ground_state,
                                noisy_log_coeff_fn, args.order, args.global_cutoff, args.annealing)
 
-    # Clusters are independent problems: with --jobs > 1 several are in flight on
-    # the GPU at once — the C calls release the GIL and every Hamiltonian owns its stream.  All
-    # randomness was consumed above, so the lines written are identical for any --jobs.
+    # Clusters are independent problems.  Under torch.distributed (one process per
+    # GPU) cluster c is solved by rank c mod world and rank 0 writes the gathered lines; every
+    # rank generated the same clusters above (same seed), so the file does not depend on the
+    # world size.
+    if asp_dist.world_size() > 1:
+        lines = asp_dist.map_sharded(
+            clusters, lambda c: ",".join(r.to_csv_str() for r in work(c)))
+        if writer:
+            with open(args.output, "a") as f:
+                for line in lines:
+                    f.write(line + "\n")
+        return
+    # With --jobs > 1 several clusters are in flight on one GPU at once — the C calls release
+    # the GIL and every Hamiltonian owns its stream.  All randomness was consumed above, so the
+    # lines written are identical for any --jobs.
     if args.jobs > 1:
         from concurrent.futures import ThreadPoolExecutor
 

@@ -77,3 +77,60 @@ def test_sharded_anneal_equals_single_process(tmp_path, repetitions):
         assert np.array_equal(best["x"], xs[k]) and float(best["e"]) == es[k]
     drawn = [np.load(tmp_path / ("drawn%d.npz" % rank)) for rank in range(world)]
     assert np.array_equal(drawn[0]["x"], drawn[1]["x"]) and float(drawn[0]["e"]) == float(drawn[1]["e"])
+
+
+def _cluster_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    import oracle
+    from annealing_sign_problem_amd import annealer, distributed, synthetic
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank,
+                            world_size=world)
+
+    def fake_anneal_raw(hamiltonian, seed, betas, count, offset=0, x0=None):
+        xs, es, _, _ = oracle.sa_anneal(hamiltonian.exchange, hamiltonian.field, seed, betas, count,
+                                        offset, x0, 40)
+        return xs, es
+
+    annealer.anneal_raw = fake_anneal_raw
+    info = type("I", (), {"beta0_auto": 0.5, "beta1_auto": 50.0})()
+
+    def solve(k):
+        # a different problem per item; anneal must not try to split its chains over the ranks
+        J, h, _ = synthetic.planted_cluster(100 + 10 * k, seed=k, mean_degree=6.0)
+        ham = annealer.Hamiltonian(J, h)
+        ham.info = lambda: info
+        x, e = annealer.anneal(ham, seed=7 + k, number_sweeps=10, repetitions=3)
+        return (k, float(e), x.tobytes())
+
+    results = distributed.map_sharded(list(range(7)), solve)   # 4 items on rank 0, 3 on rank 1
+    assert distributed.shards_chains()                          # back to normal outside
+    import pickle
+    with open(os.path.join(out_dir, "clusters%d.pkl" % rank), "wb") as f:
+        pickle.dump(results, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cluster_instances_shard_over_ranks(tmp_path):
+    """cluster c -> rank c mod world, results gathered in order on every rank, and
+    inside a sharded item the annealer keeps its chains on the rank (no collective)."""
+    import pickle
+
+    import torch.multiprocessing as mp
+
+    import oracle
+    from annealing_sign_problem_amd import synthetic
+
+    world = 2
+    mp.spawn(_cluster_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [pickle.load(open(tmp_path / ("clusters%d.pkl" % r), "rb")) for r in range(world)]
+    assert got[0] == got[1] and [g[0] for g in got[0]] == list(range(7))
+    for k, e, xbytes in got[0]:
+        J, h, _ = synthetic.planted_cluster(100 + 10 * k, seed=k, mean_degree=6.0)
+        betas = np.geomspace(0.5, 50.0, 10)
+        xs, es, _, _ = oracle.sa_anneal(J, h, 7 + k, betas, 3, 0, None, 40)
+        best = int(np.argmin(es))
+        assert e == es[best] and xbytes == xs[best].tobytes()
