@@ -60,7 +60,9 @@ def _fingerprint(sources: list[str]) -> str:
             if name.endswith((".h", ".hpp")):
                 deps.append(os.path.join(d, name))
     for path in deps:
-        h.update(path.encode())
+        # names relative to the repository: the same tree must give the same stamp wherever it
+        # is mounted (the GPU box runs a copy under a scratch path)
+        h.update(os.path.relpath(path, os.path.dirname(HERE)).encode())
         with open(path, "rb") as f:
             h.update(f.read())
     return h.hexdigest()
@@ -74,25 +76,43 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if _TAG and os.environ.get("ASP_NO_REBUILD") == "1" and os.path.exists(LIB_PATH):
         return LIB_PATH  # A/B against a variant built from an OLDER source tree
     fp = _fingerprint(sources)
-    if not force and os.path.exists(LIB_PATH) and os.path.exists(STAMP_PATH):
+
+    def current() -> bool:
+        if not (os.path.exists(LIB_PATH) and os.path.exists(STAMP_PATH)):
+            return False
         with open(STAMP_PATH) as f:
-            if f.read().strip() == fp:
-                return LIB_PATH
+            return f.read().strip() == fp
+
+    if not force and current():
+        return LIB_PATH
     if not os.access(HERE, os.W_OK):
         if os.path.exists(LIB_PATH):
             return LIB_PATH
         raise RuntimeError("cannot build: %s is not writable" % HERE)
-    cmd = [hipcc(), *HIPCC_FLAGS, *EXTRA_FLAGS, "-I", INCLUDE, "-I", CSRC, "-x", "hip", *sources, "-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    proc = subprocess.run(cmd, capture_output=True, text=True)
-    if proc.returncode != 0:
-        sys.stderr.write(proc.stdout + proc.stderr)
-        raise RuntimeError("hipcc failed building " + LIB_NAME)
-    if verbose and proc.stderr:
-        sys.stderr.write(proc.stderr)
-    with open(STAMP_PATH, "w") as f:
-        f.write(fp)
+    # one builder at a time (N ranks of a torch.distributed launch import this together); the
+    # library is written under a temporary name and renamed, so nobody loads half a file
+    import fcntl
+
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and current():  # somebody else built it while we waited
+            return LIB_PATH
+        tmp = "%s.%d.tmp" % (LIB_PATH, os.getpid())
+        cmd = [hipcc(), *HIPCC_FLAGS, *EXTRA_FLAGS, "-I", INCLUDE, "-I", CSRC, "-x", "hip",
+               *sources, "-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+        if proc.returncode != 0:
+            sys.stderr.write(proc.stdout + proc.stderr)
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            raise RuntimeError("hipcc failed building " + LIB_NAME)
+        if verbose and proc.stderr:
+            sys.stderr.write(proc.stderr)
+        os.replace(tmp, LIB_PATH)
+        with open(STAMP_PATH, "w") as f:
+            f.write(fp)
     return LIB_PATH
 
 
