@@ -307,6 +307,27 @@ def sparsify_using_global_cutoff(model: IsingModel, reltol: float, frozen_spins)
                       sa.signs_to_bits(signs))
 
 
+def invert_permutation(p) -> np.ndarray:
+    """``s`` with ``s[p[i]] = i`` (common.py:110-113)."""
+    p = np.asarray(p)
+    s = np.empty_like(p)
+    s[p] = np.arange(p.size)
+    return s
+
+
+def load_hamiltonian(filename: str):
+    """The operator of a ``physical_systems/*.yaml`` file (common.py:783-788) for bases without
+    lattice symmetries; the result runs its action on the GPU.  Symmetry-adapted bases raise
+    ``ValueError`` (they need lattice_symmetries)."""
+    import yaml
+
+    from . import operators
+
+    with open(filename, "r") as f:
+        config = yaml.safe_load(f)
+    return operators.Operator.from_config(config)
+
+
 @dataclass
 class SamplingResult:
     """common.py:264-267."""

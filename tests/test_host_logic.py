@@ -280,3 +280,35 @@ def test_cluster_growth_is_connected_and_sized(models):
     assert seen == members
     sizes = [sampled_components.random_cluster_size(50, 1000) for _ in range(200)]
     assert min(sizes) >= 50 and max(sizes) <= 1000 and np.median(sizes) < 400  # log-uniform
+
+
+def test_load_hamiltonian_from_yaml_and_invert_permutation(tmp_path, models):
+    from annealing_sign_problem_amd import common, operators
+
+    text = """basis:
+  number_spins: 4
+  hamming_weight: 2
+  symmetries: []
+hamiltonian:
+  name: "ring"
+  terms:
+    - matrix: [[1,  0,  0, 0],
+               [0, -1,  2, 0],
+               [0,  2, -1, 0],
+               [0,  0,  0, 1]]
+      sites: [[0, 1], [1, 2], [2, 3], [3, 0]]
+observables: []
+"""
+    path = tmp_path / "ring.yaml"
+    path.write_text(text)
+    op = common.load_hamiltonian(str(path))
+    assert isinstance(op, operators.Operator) and op.basis.number_spins == 4
+    op.basis.build()
+    e0, _ = op.ground_state()
+    assert abs(e0 + 8.0) < 1e-10          # 4-site Heisenberg ring in sigma.sigma units
+    symmetric = text.replace("symmetries: []", "symmetries: [{permutation: [1, 2, 3, 0], sector: 0}]")
+    path.write_text(symmetric)
+    with pytest.raises(ValueError):
+        common.load_hamiltonian(str(path))
+    p = np.array([2, 0, 3, 1])
+    assert common.invert_permutation(p).tolist() == [1, 3, 0, 2]
