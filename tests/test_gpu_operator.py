@@ -201,3 +201,52 @@ def test_device_operator_degenerate_and_errors():
     assert rc == -3 and "invalid bond" in _lib.last_error()
     rc = lib.asp_operator_create(65, 0, None, None, None, ctypes.byref(handle))
     assert rc == -3
+
+
+def test_raw_ctypes_binding_as_documented(models):
+    """The reference-side stub of INTEGRATION.md §2b, executed literally: plain ctypes on the
+    shared object, no wrapper from this package."""
+    import ctypes
+
+    from annealing_sign_problem_amd import build
+
+    lib = ctypes.CDLL(build.LIB_PATH)
+    lib.asp_last_error.restype = ctypes.c_char_p
+    config = models["heisenberg_kagome_16"]
+    a, b, m = [], [], []
+    for term in config["hamiltonian"]["terms"]:
+        for (i, j) in term["sites"]:
+            a.append(i)
+            b.append(j)
+            m.append(np.asarray(term["matrix"], dtype=np.float64).reshape(16))
+    a, b, m = np.asarray(a, np.uint8), np.asarray(b, np.uint8), np.ascontiguousarray(m)
+    op = ctypes.c_void_p()
+    rc = lib.asp_operator_create(ctypes.c_uint32(config["basis"]["number_spins"]),
+                                 ctypes.c_uint32(len(a)), a.ctypes, b.ctypes, m.ctypes,
+                                 ctypes.byref(op))
+    assert rc == 0, lib.asp_last_error()
+    g = golden("make_ising_kagome16_cluster.npz")
+    spins = np.ascontiguousarray(g["spins"], dtype=np.uint64)
+    psi = np.ascontiguousarray(np.exp(g["log_psi"]).real)
+    psi /= np.linalg.norm(psi)
+    capacity = g["data"].shape[0]
+    row = np.zeros(capacity, np.int32)
+    col = np.zeros(capacity, np.int32)
+    val = np.zeros(capacity, np.float64)
+    nnz = ctypes.c_uint64(0)
+    rc = lib.asp_operator_ising(op, ctypes.c_uint64(spins.shape[0]), spins.ctypes, psi.ctypes,
+                                ctypes.c_uint64(capacity), row.ctypes, col.ctypes, val.ctypes,
+                                ctypes.byref(nnz))
+    assert rc == 0, lib.asp_last_error()
+    assert nnz.value == capacity
+    _same(row, g["row"].astype(np.int32))
+    _same(col, g["col"].astype(np.int32))
+    _same(val, g["data"])
+    out = np.zeros(g["ext_spins"].shape[0], np.uint64)
+    count = ctypes.c_uint64(0)
+    rc = lib.asp_operator_extend(op, ctypes.c_uint64(spins.shape[0]), spins.ctypes,
+                                 ctypes.c_uint64(out.shape[0]), out.ctypes, ctypes.byref(count))
+    assert rc == 0 and count.value == out.shape[0]
+    _same(out, g["ext_spins"])
+    lib.asp_operator_destroy.argtypes = [ctypes.c_void_p]
+    lib.asp_operator_destroy(op)
