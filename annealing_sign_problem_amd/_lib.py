@@ -94,6 +94,8 @@ SIGNATURES = {
     "asp_sa_set_field_cache": (c_int, [c_void_p, c_int]),
     "asp_sa_anneal": (c_int, [c_void_p, c_u64, c_void_p, c_u32, c_u32, c_u32, c_void_p, c_void_p,
                               c_void_p]),
+    "asp_sa_anneal_trace": (c_int, [c_void_p, c_u64, c_void_p, c_u32, c_u32, c_u32, c_void_p,
+                                    c_void_p, c_void_p, c_void_p]),
     "asp_sa_greedy": (c_int, [c_void_p, c_u32, c_void_p, c_void_p, ctypes.POINTER(c_u32)]),
     "asp_sa_greedy_tree_host": (c_int, [c_u64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "asp_sa_last_sweep_ms": (c_float, [c_void_p]),

@@ -233,6 +233,51 @@ def anneal(hamiltonian: Hamiltonian, x0=None, seed=None, number_sweeps: int = 51
     return xs, es
 
 
+def anneal_trace_raw(hamiltonian: Hamiltonian, seed: int, betas: np.ndarray, repetitions: int,
+                     replica_offset: int = 0, x0=None):
+    """``anneal_raw`` plus ``trace int64[R, T+1]``: tracked energy of every chain after each
+    sweep in units of ``2**-energy_scale_exp``, relative to its initial configuration."""
+    lib = _lib.load()
+    plan = hamiltonian.plan()
+    words = (hamiltonian.size + 63) // 64
+    betas = np.ascontiguousarray(betas, dtype=np.float64)
+    xs = np.zeros((repetitions, max(words, 1)), dtype=np.uint64)
+    es = np.zeros(repetitions, dtype=np.float64)
+    trace = np.zeros((repetitions, betas.shape[0] + 1), dtype=np.int64)
+    if x0 is not None:
+        x0 = np.ascontiguousarray(x0, dtype=np.uint64).reshape(-1)
+        if x0.shape[0] != words:
+            raise ValueError("'x0' must have {} words".format(words))
+    _lib.check(lib.asp_sa_anneal_trace(plan, ctypes.c_uint64(seed), _lib.ptr(betas),
+                                       ctypes.c_uint32(betas.shape[0]),
+                                       ctypes.c_uint32(repetitions),
+                                       ctypes.c_uint32(replica_offset), _lib.ptr(x0),
+                                       _lib.ptr(xs), _lib.ptr(es), _lib.ptr(trace)))
+    return xs[:, :words], es, trace
+
+
+def anneal_with_traces(hamiltonian: Hamiltonian, x0=None, seed=None, number_sweeps: int = 5120,
+                       beta0: Optional[float] = None, beta1: Optional[float] = None):
+    """The older annealer API (annealing_sign_problem/train.py:238-245, square_deep.py:181-183):
+    one chain, ``(x, e_current, e_best)`` with the energy after every sweep and the best energy
+    so far (``e_best[0]`` before the first sweep, ``e_best[-1]`` the returned configuration's).
+
+    The traces come from the kernel's exact integer bookkeeping of the accepted ``dE`` and are
+    anchored at the returned configuration's energy, which is recomputed in full precision."""
+    if not isinstance(hamiltonian, Hamiltonian):
+        raise TypeError("'hamiltonian' must be a Hamiltonian")
+    info = hamiltonian.info()
+    beta0 = info.beta0_auto if beta0 is None else beta0
+    beta1 = info.beta1_auto if beta1 is None else beta1
+    betas = make_schedule(float(beta0), float(beta1), number_sweeps)
+    xs, es, trace = anneal_trace_raw(hamiltonian, _resolve_seed(seed), betas, 1, 0, x0)
+    unit = 2.0 ** -info.energy_scale_exp
+    best = np.minimum.accumulate(trace[0])
+    e_best = es[0] + (best - best[-1]).astype(np.float64) * unit
+    e_current = es[0] + (trace[0] - best[-1]).astype(np.float64) * unit
+    return xs[0].copy(), e_current, e_best
+
+
 def greedy_solve(hamiltonian: Hamiltonian):
     """Strongest-coupling-first greedy sign assignment (common.py:250)."""
     from .greedy import greedy_solve as _greedy

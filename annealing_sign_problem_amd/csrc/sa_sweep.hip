@@ -389,6 +389,7 @@ struct SweepArgs {
   double *field_cache;
   uint32_t cache_enter_flips;  // switch the cache on after a sweep with fewer flips than this
   uint64_t *spin_words;        // kGlobal: [groups][num_blocks] sign-bit words in HBM
+  long long *trace;            // nullptr or [groups * M][num_sweeps + 1] tracked energy per sweep
 };
 
 // One 64-spin word of the bit-packed layouts; device-scope accesses when it lives in HBM and
@@ -561,6 +562,9 @@ __global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep(SweepArgs a) {
   snapshot<M, LAYOUT>(spins, a, group, (1u << M) - 1u);
   __syncthreads();
 
+  if (a.trace != nullptr && tid < M) {
+    a.trace[(static_cast<uint64_t>(group) * M + tid) * (a.num_sweeps + 1ull)] = 0;
+  }
   uint32_t one_hi[4] = {0x3FF00000u, 0x3FF00000u, 0x3FF00000u, 0x3FF00000u};
   for (uint32_t t = 0; t < a.num_sweeps; ++t) {
     const double beta = a.betas[t];
@@ -799,6 +803,9 @@ __global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep(SweepArgs a) {
       const long long e = book[tid] + delta[tid];
       book[tid] = e;
       delta[tid] = 0;
+      if (a.trace != nullptr) {
+        a.trace[(static_cast<uint64_t>(group) * M + tid) * (a.num_sweeps + 1ull) + t + 1u] = e;
+      }
       if (e < book[8 + tid]) {
         book[8 + tid] = e;
         atomicOr(improved_flag, 1u << tid);
@@ -974,6 +981,7 @@ struct asp_sa_plan {
   DeviceBuffer<unsigned long long> w_accepted;
   DeviceBuffer<double> w_field_cache;  // [groups][blocks][M][64], see SweepArgs::field_cache
   DeviceBuffer<uint64_t> w_spins;      // [groups][blocks] sign words of the HBM-resident layout
+  DeviceBuffer<long long> w_trace;     // [groups * M][sweeps + 1] tracked energies (asp_sa_anneal_trace)
   bool use_field_cache = true;
 };
 
@@ -1189,7 +1197,7 @@ namespace {
 // All chains of one call; descent = strict-descent sweeps (greedy relaxation).
 int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_sweeps,
                uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0, bool descent,
-               uint64_t *out_x, double *out_e) {
+               uint64_t *out_x, double *out_e, int64_t *out_trace = nullptr) {
   if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
   ASP_TRY(asp::bind_device());
   if (repetitions == 0) return ASP_OK;
@@ -1283,6 +1291,12 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
   args.field_cache = nullptr;
   args.cache_enter_flips = 0;
   args.spin_words = global ? p->w_spins.ptr : nullptr;
+  args.trace = nullptr;
+  const uint64_t trace_elems = padded * (static_cast<uint64_t>(num_sweeps) + 1);
+  if (out_trace) {
+    ASP_TRY(p->w_trace.ensure(trace_elems));
+    args.trace = p->w_trace.ptr;
+  }
   if (p->use_field_cache && !packed) {  // (both the byte and the wide layout)
     // 512 B per block and replica; skipped when it would not fit comfortably in HBM
     const uint64_t cache_elems = padded * L.num_blocks * 64ull;
@@ -1328,6 +1342,12 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
                              hipMemcpyDeviceToHost, s));
   ASP_HIP_TRY(hipMemcpyAsync(p->last_accepted.data(), d_accepted.ptr,
                              repetitions * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  if (out_trace) {  // rows of the real replicas come first
+    ASP_HIP_TRY(hipMemcpyAsync(out_trace, p->w_trace.ptr,
+                               static_cast<uint64_t>(repetitions) * (num_sweeps + 1ull) *
+                                   sizeof(int64_t),
+                               hipMemcpyDeviceToHost, s));
+  }
   ASP_HIP_TRY(hipStreamSynchronize(s));
   p->last_m = m;
   p->last_layout = layout;
@@ -1348,6 +1368,15 @@ int asp_sa_anneal(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t n
   asp_clear_error();
   return run_chains(p, seed, betas, num_sweeps, repetitions, replica_offset, x0, false, out_x,
                     out_e);
+}
+
+int asp_sa_anneal_trace(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_sweeps,
+                        uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0,
+                        uint64_t *out_x, double *out_e, int64_t *out_trace) {
+  asp_clear_error();
+  if (!out_trace) return asp::set_error(ASP_ERR_INVALID, "null trace pointer");
+  return run_chains(p, seed, betas, num_sweeps, repetitions, replica_offset, x0, false, out_x,
+                    out_e, out_trace);
 }
 
 int asp_sa_greedy(asp_sa_plan *p, uint32_t max_sweeps, uint64_t *out_x, double *out_e,

@@ -289,6 +289,17 @@ int asp_sa_set_field_cache(asp_sa_plan *p, int enable);
 int asp_sa_anneal(asp_sa_plan *p, uint64_t seed, double const *betas,
                   uint32_t num_sweeps, uint32_t repetitions, uint32_t replica_offset,
                   uint64_t const *x0, uint64_t *out_x, double *out_e);
+/* asp_sa_anneal that also returns every chain's energy after each sweep — the per-sweep
+ * traces the older annealer API handed back as `(x, e_current[], e_best[]) = anneal(h, x0, seed,
+ * number_sweeps, beta0, beta1)` (annealing_sign_problem/train.py:238-245,297).
+ * out_trace[r * (num_sweeps + 1) + t] = tracked energy of chain r after t sweeps in units of
+ * 2^-energy_scale_exp, relative to its initial configuration (entry 0 is 0); exact integer
+ * bookkeeping of the accepted dE.  The best-so-far trace is its running
+ * minimum. */
+int asp_sa_anneal_trace(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_sweeps,
+                        uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0,
+                        uint64_t *out_x, double *out_e, int64_t *out_trace);
+
 /* Replaces ising_glass_annealer.greedy_solve (call site common.py:250; the only in-tree
  * description is the commented prototype at common.py:298-438): couplings are visited
  * strongest first and clusters of already-signed spins are merged so that the visited

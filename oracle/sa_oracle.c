@@ -315,7 +315,7 @@ static double sa_energy(sa_problem const *p, double const *field, int8_t const *
 static void sa_run_chain(sa_problem const *p, double const *field, uint64_t seed,
                          double const *betas, uint32_t num_sweeps, uint32_t replica,
                          uint64_t const *x0, double scale, int8_t *s, int8_t *best,
-                         int64_t *tracked_best, uint64_t *accepted_total) {
+                         int64_t *tracked_best, uint64_t *accepted_total, int64_t *trace) {
   uint64_t const n = p->n;
   for (uint64_t i = 0; i < n; ++i) {
     if (x0 != NULL) {
@@ -327,6 +327,7 @@ static void sa_run_chain(sa_problem const *p, double const *field, uint64_t seed
   memcpy(best, s, n);
   int64_t e_cur = 0, e_best = 0;
   uint64_t accepted = 0;
+  if (trace != NULL) trace[0] = 0;
   for (uint32_t t = 0; t < num_sweeps; ++t) {
     double const beta = betas[t];
     int64_t q_sweep = 0;
@@ -354,6 +355,7 @@ static void sa_run_chain(sa_problem const *p, double const *field, uint64_t seed
       }
     }
     e_cur += q_sweep;
+    if (trace != NULL) trace[t + 1] = e_cur;
     if (e_cur < e_best) {
       e_best = e_cur;
       memcpy(best, s, n);
@@ -366,12 +368,12 @@ static void sa_run_chain(sa_problem const *p, double const *field, uint64_t seed
 /* Returns 0 on success.  out_x: R * ceil(K/64) words; out_e: R doubles;
  * out_tracked (optional): R fixed-point best energies relative to the start;
  * out_accepted (optional): R counts of accepted flips. */
-int oracle_sa_anneal(uint64_t num_spins, int64_t const *indptr, int32_t const *indices,
-                     double const *data, double const *field, uint64_t seed,
-                     double const *betas, uint32_t num_sweeps, uint32_t repetitions,
-                     uint32_t replica_offset, uint64_t const *x0, int32_t energy_scale_exp,
-                     uint64_t *out_x, double *out_e, int64_t *out_tracked,
-                     uint64_t *out_accepted, int num_threads) {
+static int anneal_impl(uint64_t num_spins, int64_t const *indptr, int32_t const *indices,
+                       double const *data, double const *field, uint64_t seed,
+                       double const *betas, uint32_t num_sweeps, uint32_t repetitions,
+                       uint32_t replica_offset, uint64_t const *x0, int32_t energy_scale_exp,
+                       uint64_t *out_x, double *out_e, int64_t *out_tracked,
+                       uint64_t *out_accepted, int64_t *out_trace, int num_threads) {
   sa_problem p;
   if (sa_problem_init(&p, num_spins, indptr, indices, data) != 0) return -1;
   uint64_t const words = (num_spins + 63) / 64;
@@ -386,7 +388,8 @@ int oracle_sa_anneal(uint64_t num_spins, int64_t const *indptr, int32_t const *i
       int64_t tracked = 0;
       uint64_t accepted = 0;
       sa_run_chain(&p, field, seed, betas, num_sweeps, replica_offset + rr, x0, scale, s,
-                   best, &tracked, &accepted);
+                   best, &tracked, &accepted,
+                   out_trace ? out_trace + (uint64_t)rr * ((uint64_t)num_sweeps + 1) : NULL);
       uint64_t *x = out_x + (uint64_t)rr * words;
       for (uint64_t w = 0; w < words; ++w) x[w] = 0;
       for (uint64_t i = 0; i < num_spins; ++i) {
@@ -401,6 +404,29 @@ int oracle_sa_anneal(uint64_t num_spins, int64_t const *indptr, int32_t const *i
   }
   sa_problem_free(&p);
   return 0;
+}
+
+int oracle_sa_anneal(uint64_t num_spins, int64_t const *indptr, int32_t const *indices,
+                     double const *data, double const *field, uint64_t seed,
+                     double const *betas, uint32_t num_sweeps, uint32_t repetitions,
+                     uint32_t replica_offset, uint64_t const *x0, int32_t energy_scale_exp,
+                     uint64_t *out_x, double *out_e, int64_t *out_tracked,
+                     uint64_t *out_accepted, int num_threads) {
+  return anneal_impl(num_spins, indptr, indices, data, field, seed, betas, num_sweeps,
+                     repetitions, replica_offset, x0, energy_scale_exp, out_x, out_e, out_tracked,
+                     out_accepted, NULL, num_threads);
+}
+
+/* Same, and out_trace[r * (T + 1) + t] = tracked energy (fixed point, relative to the initial
+ * configuration) of chain r after t sweeps. */
+int oracle_sa_anneal_trace(uint64_t num_spins, int64_t const *indptr, int32_t const *indices,
+                           double const *data, double const *field, uint64_t seed,
+                           double const *betas, uint32_t num_sweeps, uint32_t repetitions,
+                           uint32_t replica_offset, uint64_t const *x0, int32_t energy_scale_exp,
+                           uint64_t *out_x, double *out_e, int64_t *out_trace, int num_threads) {
+  return anneal_impl(num_spins, indptr, indices, data, field, seed, betas, num_sweeps,
+                     repetitions, replica_offset, x0, energy_scale_exp, out_x, out_e, NULL, NULL,
+                     out_trace, num_threads);
 }
 
 /* E(x) for `count` packed configurations. */

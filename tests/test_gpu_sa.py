@@ -467,3 +467,32 @@ def test_full_size_properties_pyrochlore_sized_with_cutoff():
         s = sa.bits_to_signs(xs[r], small.size)
         ref = s @ (block @ s) + ham.field @ s
         assert abs(es[r] - ref) <= 1e-12 * abs(ref)
+
+
+@pytest.mark.parametrize("m,threads", [(1, 256), (4, 512), (8, 1024)])
+def test_energy_traces_match_oracle(m, threads):
+    """asp_sa_anneal_trace: the tracked energy after every sweep, as integers, equals the
+    oracle's; the legacy 3-tuple API built on it returns energies consistent with numpy."""
+    from annealing_sign_problem_amd import annealer as sa
+
+    J, h, _ = _planted(1200, 41)
+    field = np.random.default_rng(4).normal(size=1200) * 0.02
+    betas = np.geomspace(0.3, 5e3, 30)
+    ham = sa.Hamiltonian(J, field)
+    _set_launch(ham, m, threads)
+    xs, es, trace = sa.anneal_trace_raw(ham, 31337, betas, 11, 2)
+    S = ham.info().energy_scale_exp
+    oxs, oes, otrace = oracle.sa_anneal_trace(J, field, 31337, betas, 11, 2, None, S, num_threads=8)
+    assert np.array_equal(trace, otrace)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    assert np.all(trace[:, 0] == 0) and trace.min() < 0
+    _set_launch(ham, 0, 0)
+    x0 = sa.signs_to_bits(np.ones(1200))
+    x, e_current, e_best = sa.anneal_with_traces(ham, x0, seed=5, number_sweeps=40, beta0=0.3,
+                                                 beta1=5e3)
+    assert e_current.shape == (41,) and e_best.shape == (41,)
+    s0 = np.ones(1200)
+    e_start = s0 @ (J @ s0) + field @ s0
+    assert abs(e_current[0] - e_start) <= 1e-9 * abs(e_start)          # anchored consistently
+    assert abs(e_best[-1] - ham.energy(x)) == 0 and np.all(np.diff(e_best) <= 0)
+    assert np.all(e_best <= e_current + 1e-12)
