@@ -250,3 +250,38 @@ def test_raw_ctypes_binding_as_documented(models):
     _same(out, g["ext_spins"])
     lib.asp_operator_destroy.argtypes = [ctypes.c_void_p]
     lib.asp_operator_destroy(op)
+
+
+def test_device_operator_sixty_four_sites():
+    """The largest basis the reference allows (common.py:86): site 63 is the top key bit, so
+    flips, hashing, the radix sort of the extension and the sorted-key check all see keys above
+    2^63."""
+    from annealing_sign_problem_amd import operators
+
+    rng = np.random.default_rng(64)
+    pairs = set()
+    while len(pairs) < 90:
+        a, b = rng.choice(64, size=2, replace=False)
+        pairs.add((int(min(a, b)), int(max(a, b))))
+    pairs.update({(62, 63), (0, 63), (31, 63)})
+    terms = [operators.Term(rng.normal() * operators.SIGMA_DOT_SIGMA, [p]) for p in sorted(pairs)]
+    op = operators.Operator(operators.SpinBasis(64, 32), terms)
+    start = np.uint64(int("10" * 32, 2))          # bit 63 set
+    first, _, _ = op.batched_apply(np.array([start], dtype=np.uint64))
+    second, _, _ = op.batched_apply(first[:, 0])
+    keys = np.unique(np.concatenate([first[:, 0], second[:, 0]]))[:4000]
+    assert keys.max() >= np.uint64(1) << np.uint64(63) and keys.min() < np.uint64(1) << np.uint64(63)
+    psi = rng.normal(size=keys.size)
+    psi /= np.linalg.norm(psi)
+    dev, table = op.device(), op.bond_table()
+    row, col, val = dev.ising(keys, psi)
+    o_row, o_col, o_val = oracle.operator_ising(table, keys, psi)
+    _same(row, o_row)
+    _same(col, o_col)
+    _same(val, o_val)
+    other, coeffs, counts = dev.apply(keys[:300])
+    o = oracle.operator_apply(table, keys[:300])
+    _same(other, o[0])
+    _same(coeffs, o[1])
+    _same(counts, o[2])
+    _same(dev.extend(keys[:500]), oracle.operator_extend(table, keys[:500]))
