@@ -90,6 +90,7 @@ SIGNATURES = {
     "asp_sa_set_launch": (c_int, [c_void_p, c_int, c_int]),
     "asp_sa_set_packed": (c_int, [c_void_p, c_int]),
     "asp_sa_set_wide": (c_int, [c_void_p, c_int]),
+    "asp_sa_set_team": (c_int, [c_void_p, c_int]),
     "asp_sa_last_layout": (c_int, [c_void_p]),
     "asp_sa_set_field_cache": (c_int, [c_void_p, c_int]),
     "asp_sa_anneal": (c_int, [c_void_p, c_u64, c_void_p, c_u32, c_u32, c_u32, c_void_p, c_void_p,

@@ -832,6 +832,219 @@ __global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep(SweepArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// Team sweep: ONE chain spread over G workgroups (few chains on a large cluster)
+// ---------------------------------------------------------------------------
+// With fewer chains than compute units a chain bound to one workgroup leaves most of the chip
+// idle and pays ceil(blocks of a colour / 16) rounds per colour step.  Here the G workgroups of a
+// team each keep the whole configuration (bit-packed, LDS), visit every G-th slice of a colour's
+// blocks, publish the 64-bit flip word of each block they visited, meet at a device-scope
+// barrier and XOR the other members' flip words into their own copy.  Energy bookkeeping is
+// summed over the team through parity-buffered atomics.  Launched cooperatively (all workgroups
+// co-resident); the barrier carries a watchdog so that a bug cannot hang the GPU.  Chains are
+// bit-identical to k_sa_sweep's.
+
+struct TeamArgs {
+  SweepArgs s;
+  uint32_t team_size;            // G
+  uint32_t num_teams;            // = chains of the launch
+  unsigned long long *arrivals;  // [num_teams] barrier counters (monotone)
+  uint64_t *flips;               // [num_teams][num_blocks] flip words of the running colour step
+  long long *sums;               // [num_teams][2 parities][2] {dq, accepted} of a sweep
+  uint32_t *abort;               // set by the watchdog
+};
+
+constexpr uint32_t kTeamSpinLimit = 1u << 24;  // barrier polls before the watchdog gives up
+
+__device__ __forceinline__ void team_barrier(const TeamArgs &ta, unsigned long long *counter,
+                                             unsigned long long &target) {
+  // The exchange buffers are fine-grained (uncached, coherent across XCDs) and only touched with
+  // device-scope atomics, so no cache write-back/invalidate is needed — a release/acquire fence
+  // at agent scope flushes the whole L2 of the XCD on this chip and costs ~20 us.  Ordering:
+  // every wavefront first waits for the acknowledgement of its own outstanding stores and
+  // atomics (a workgroup-scope barrier alone does not: within a CU the vector L1 is shared, so
+  // hipcc emits no vmcnt wait for it), then the workgroup barrier, then thread 0 announces the
+  // arrival.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  target += ta.team_size;
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t polls = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (__hip_atomic_load(ta.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+      if (++polls > kTeamSpinLimit) {
+        __hip_atomic_store(ta.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+}
+
+// DESCENT as in k_sa_sweep: accept iff dE < 0, no random numbers, snapshot after every sweep.
+template <bool DESCENT>
+__global__ __launch_bounds__(1024) void k_sa_sweep_team(TeamArgs ta) {
+  const SweepArgs &a = ta.s;
+  extern __shared__ __align__(16) uint8_t lds[];
+  uint64_t *words = reinterpret_cast<uint64_t *>(lds);  // sign bits, one word per block
+  // book: [0] current tracked energy, [1] best, [2] this workgroup's dq, [3] its accepted flips,
+  // [4] accepted flips of the chain so far
+  long long *book = reinterpret_cast<long long *>(lds + static_cast<size_t>(a.num_blocks) * 8u);
+  uint32_t *improved = reinterpret_cast<uint32_t *>(book + 5);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, waves = blockDim.x >> 6;
+  const uint32_t G = ta.team_size;
+  // members of a team are num_teams apart: the same XCD when num_teams is a multiple of 8
+  const uint32_t team = blockIdx.x % ta.num_teams, member = blockIdx.x / ta.num_teams;
+  const uint32_t r = a.replica_first + team;
+  const uint32_t key0 = static_cast<uint32_t>(a.seed), key1 = static_cast<uint32_t>(a.seed >> 32);
+  uint64_t *flipbuf = ta.flips + static_cast<uint64_t>(team) * a.num_blocks;
+  unsigned long long *counter = ta.arrivals + team;
+  unsigned long long target = 0;
+
+  // every member builds the same initial configuration
+  for (uint32_t b0 = wave; b0 < a.num_blocks; b0 += waves) {
+    const uint32_t p = b0 * 64u + lane;
+    const uint32_t spin = a.spin_of_pos[p];
+    uint32_t negative = 0;
+    if (spin != kDummySpin) {
+      if (a.x0_perm != nullptr) {
+        negative = static_cast<uint32_t>((a.x0_perm[p >> 6] >> (p & 63u)) & 1ull);
+      } else {
+        const Philox4 rnd = philox4x32_10(spin, 0xFFFFFFFFu, r >> 2, 0u, key0, key1);
+        negative = (pick_word(rnd, r & 3u) & 1u) ^ 1u;
+      }
+    }
+    const uint64_t word = __ballot(negative);
+    if (lane == 0) words[b0] = word;
+  }
+  if (tid < 5) book[tid] = 0;
+  if (tid == 0) *improved = 0;
+  __syncthreads();
+  if (member == 0) {
+    for (uint32_t w = tid; w < a.num_blocks; w += blockDim.x) {
+      a.best_perm[static_cast<uint64_t>(team) * a.num_blocks + w] = words[w];
+    }
+  }
+
+  uint32_t one_hi[4] = {0x3FF00000u, 0x3FF00000u, 0x3FF00000u, 0x3FF00000u};
+  for (uint32_t t = 0; t < a.num_sweeps; ++t) {
+    const double beta = a.betas[t];
+    long long q_acc = 0;
+    uint32_t n_acc = 0;
+    for (uint32_t c = 0; c < a.num_colors; ++c) {
+      const uint32_t b_begin = a.color_block_start[c];
+      const uint32_t b_end = a.color_block_start[c + 1];
+      for (uint32_t b = b_begin + member * waves + wave; b < b_end; b += G * waves) {
+        const uint32_t p = b * 64u + lane;
+        const uint32_t quads = a.block_width[b] >> 2;
+        const uint64_t first_quad = a.ell_off[b] >> 2;
+        const uint4 *cptr = reinterpret_cast<const uint4 *>(a.ell_col) + first_quad * 64u + lane;
+        const double2 *vptr =
+            reinterpret_cast<const double2 *>(a.ell_val) + first_quad * 128u + lane;
+        const uint32_t spin = a.spin_of_pos[p];
+        const double h = a.field_pos[p];
+        double acc[1] = {0.0};
+        Quad qa, qb;
+        load_quad(qa, cptr, vptr, 0);
+        uint32_t i = 0;
+        for (; i + 2 <= quads; i += 2) {
+          load_quad(qb, cptr, vptr, i + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          accumulate_quad<1, kBits>(qa, lds, acc, one_hi);
+          __builtin_amdgcn_sched_barrier(0);
+          load_quad(qa, cptr, vptr, i + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          accumulate_quad<1, kBits>(qb, lds, acc, one_hi);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (i < quads) accumulate_quad<1, kBits>(qa, lds, acc, one_hi);
+        const bool valid = spin != kDummySpin;
+        const bool negative = (words[b] >> lane) & 1ull;
+        const double g = __dadd_rn(acc[0], h);
+        const double de = __dmul_rn(negative ? 2.0 : -2.0, g);
+        bool accept;
+        if constexpr (DESCENT) {
+          accept = valid && de < 0.0;
+        } else {
+          const Philox4 rnd = philox4x32_10(spin, t, r >> 2, 0u, key0, key1);
+          const uint32_t word = pick_word(rnd, r & 3u);
+          const double u = __dmul_rn(__dadd_rn(static_cast<double>(word), 0.5), 0x1p-32);
+          accept = valid && (de <= 0.0 || metropolis_accept(u, __dmul_rn(beta, de)));
+        }
+        if (accept) {
+          q_acc += __double_as_longlong(__dadd_rn(__dmul_rn(de, a.scale), 0x1.8p52)) -
+                   0x4338000000000000ll;
+          n_acc += 1;
+        }
+        const uint64_t flips = __ballot(accept);
+        if (lane == 0) {
+          if (flips != 0) words[b] ^= flips;
+          __hip_atomic_store(flipbuf + b, flips, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      team_barrier(ta, counter, target);
+      // the other members' flips of this colour step
+      for (uint32_t i = tid; i < b_end - b_begin; i += blockDim.x) {
+        if ((i / waves) % G != member) {
+          const uint64_t flips =
+              __hip_atomic_load(flipbuf + b_begin + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (flips != 0) words[b_begin + i] ^= flips;
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- the sweep's energy change, summed over the team (integers: order-free) ----
+    const long long v = wave_sum_i64(q_acc);
+    const long long n = wave_sum_i64(static_cast<long long>(n_acc));
+    if (lane == 0 && n != 0) {
+      atomicAdd(reinterpret_cast<unsigned long long *>(&book[2]), static_cast<unsigned long long>(v));
+      atomicAdd(reinterpret_cast<unsigned long long *>(&book[3]), static_cast<unsigned long long>(n));
+    }
+    __syncthreads();
+    long long *mine = ta.sums + (static_cast<uint64_t>(team) * 2u + (t & 1u)) * 2u;
+    long long *other = ta.sums + (static_cast<uint64_t>(team) * 2u + ((t + 1u) & 1u)) * 2u;
+    if (tid == 0) {
+      if (book[3] != 0) {
+        __hip_atomic_fetch_add(&mine[0], book[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&mine[1], book[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      book[2] = 0;
+      book[3] = 0;
+    }
+    team_barrier(ta, counter, target);
+    if (tid == 0) {
+      const long long dq = __hip_atomic_load(&mine[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long long dn = __hip_atomic_load(&mine[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long long e = book[0] + dq;
+      book[0] = e;
+      book[4] += dn;
+      const bool better = e < book[1];
+      if (better) book[1] = e;
+      *improved = (better || DESCENT) ? 1u : 0u;
+      // the other parity's slot was read a sweep ago and is next added to a sweep from now,
+      // with team barriers on either side: one member clears it
+      if (member == 0) {
+        __hip_atomic_store(&other[0], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&other[1], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+    if (*improved != 0u && member == 0) {
+      for (uint32_t w = tid; w < a.num_blocks; w += blockDim.x) {
+        a.best_perm[static_cast<uint64_t>(team) * a.num_blocks + w] = words[w];
+      }
+    }
+    __syncthreads();
+  }
+  if (member == 0 && tid == 0) {
+    a.tracked[team] = book[1];
+    a.accepted[team] = static_cast<unsigned long long>(book[4]);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Energy of packed configurations: E = D + T, T = radix-64
 // pairwise tree over the blocks of t_p = s_p (A_p . s / 2 + h_p).
 // ---------------------------------------------------------------------------
@@ -982,6 +1195,14 @@ struct asp_sa_plan {
   DeviceBuffer<double> w_field_cache;  // [groups][blocks][M][64], see SweepArgs::field_cache
   DeviceBuffer<uint64_t> w_spins;      // [groups][blocks] sign words of the HBM-resident layout
   DeviceBuffer<long long> w_trace;     // [groups * M][sweeps + 1] tracked energies (asp_sa_anneal_trace)
+  // team sweep exchange area, FINE-GRAINED device memory (coherent across XCDs without cache
+  // maintenance): arrivals u64[teams] | sums i64[teams][4] | abort u32 (+pad) | flips u64[teams][blocks]
+  void *team_area = nullptr;
+  size_t team_area_bytes = 0;
+  ~asp_sa_plan() {
+    if (team_area) (void)hipFree(team_area);
+  }
+  int team_mode = -1;  // asp_sa_set_team: -1 auto, 0 off, G >= 2 forced
   bool use_field_cache = true;
 };
 
@@ -1176,6 +1397,15 @@ int asp_sa_set_field_cache(asp_sa_plan *p, int enable) {
   return ASP_OK;
 }
 
+int asp_sa_set_team(asp_sa_plan *p, int team) {
+  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  if (team != -1 && team != 0 && team != 2 && team != 4 && team != 8) {
+    return asp::set_error(ASP_ERR_INVALID, "team must be -1 (auto), 0 (off), 2, 4 or 8");
+  }
+  p->team_mode = team;
+  return ASP_OK;
+}
+
 int asp_sa_set_wide(asp_sa_plan *p, int allow) {
   if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
   p->allow_wide = allow != 0;
@@ -1236,8 +1466,32 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
   // (measured: +2..12 % with four replicas per workgroup, nothing with two)
   const bool wide = !packed && !descent && p->allow_wide && m == 4 &&
                     p->ell_col4.ptr != nullptr && sweep_lds_bytes(L, kWide) <= p->max_lds;
-  const int layout = global ? kGlobal : (packed ? kBits : (wide ? kWide : kBytes));
-  const size_t lds = sweep_lds_bytes(L, layout);
+  // Few chains on a large cluster: spread each chain over a team of workgroups (k_sa_sweep_team).
+  uint32_t team = 0;
+  {
+    uint32_t widest = 1;
+    for (uint32_t c = 0; c < L.num_colors; ++c) {
+      widest = std::max(widest, L.color_block_start[c + 1] - L.color_block_start[c]);
+    }
+    const size_t team_lds = static_cast<size_t>(L.num_blocks) * 8 + 64;
+    const bool possible = !out_trace && !global && p->force_packed == 0 &&
+                          p->force_m == 0 && team_lds <= p->max_lds &&
+                          static_cast<uint64_t>(repetitions) * 2 <= static_cast<uint64_t>(p->num_cus);
+    if (possible && p->team_mode >= 2) {
+      team = static_cast<uint32_t>(p->team_mode);  // forced (tests, measurements)
+    } else if (possible && p->team_mode < 0 && widest >= 64) {
+      // auto: as many workgroups per chain as the chip has to spare, up to 8
+      const uint32_t spare = static_cast<uint32_t>(p->num_cus) / repetitions;
+      team = spare >= 8 ? 8u : (spare >= 4 ? 4u : 2u);
+      while (team > 2 && widest < 16u * team) team >>= 1;  // every member needs a full round
+    }
+    if (team * repetitions > static_cast<uint32_t>(p->num_cus)) team = 0;  // must be co-resident
+  }
+  if (team >= 2) m = 1;
+  const int layout = team >= 2 ? kBits
+                               : (global ? kGlobal : (packed ? kBits : (wide ? kWide : kBytes)));
+  const size_t lds = team >= 2 ? static_cast<size_t>(L.num_blocks) * 8 + 64
+                               : sweep_lds_bytes(L, layout);
   if (lds > p->max_lds) {
     return asp::set_error(ASP_ERR_TOO_LARGE, "%zu B of LDS needed, %zu B available", lds,
                           p->max_lds);
@@ -1297,7 +1551,7 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
     ASP_TRY(p->w_trace.ensure(trace_elems));
     args.trace = p->w_trace.ptr;
   }
-  if (p->use_field_cache && !packed) {  // (both the byte and the wide layout)
+  if (p->use_field_cache && !packed && team < 2) {  // (both the byte and the wide layout)
     // 512 B per block and replica; skipped when it would not fit comfortably in HBM
     const uint64_t cache_elems = padded * L.num_blocks * 64ull;
     if (cache_elems * sizeof(double) <= (32ull << 30) && p->w_field_cache.ensure(cache_elems) == ASP_OK) {
@@ -1313,17 +1567,60 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
     }
   }
 
-  SweepKernel kernel = sweep_kernel_for(m, descent, layout);
-  if (lds > 64 * 1024) {
-    ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    static_cast<int>(lds)));
+  uint32_t team_abort = 0;
+  if (team >= 2) {
+    // wavefronts per member: the widest colour class split over the team, at most 16
+    uint32_t widest = 1;
+    for (uint32_t c = 0; c < L.num_colors; ++c) {
+      widest = std::max(widest, L.color_block_start[c + 1] - L.color_block_start[c]);
+    }
+    threads = static_cast<int>(std::min<uint32_t>(16u, (widest + team - 1) / team)) * 64;
+    TeamArgs ta{};
+    ta.s = args;
+    ta.team_size = team;
+    ta.num_teams = repetitions;
+    const size_t head_bytes = static_cast<size_t>(repetitions) * 8 * 5 + 16;
+    const size_t need = head_bytes + static_cast<size_t>(repetitions) * L.num_blocks * 8;
+    if (need > p->team_area_bytes) {
+      if (p->team_area) (void)hipFree(p->team_area);
+      p->team_area = nullptr;
+      p->team_area_bytes = 0;
+      ASP_HIP_TRY(hipExtMallocWithFlags(&p->team_area, need, hipDeviceMallocFinegrained));
+      p->team_area_bytes = need;
+    }
+    ASP_HIP_TRY(hipMemsetAsync(p->team_area, 0, head_bytes, s));
+    uint8_t *area = static_cast<uint8_t *>(p->team_area);
+    ta.arrivals = reinterpret_cast<unsigned long long *>(area);
+    ta.sums = reinterpret_cast<long long *>(area + static_cast<size_t>(repetitions) * 8);
+    ta.abort = reinterpret_cast<uint32_t *>(area + static_cast<size_t>(repetitions) * 8 * 5);
+    ta.flips = reinterpret_cast<uint64_t *>(area + head_bytes);
+    const void *team_kernel = descent ? reinterpret_cast<const void *>(k_sa_sweep_team<true>)
+                                      : reinterpret_cast<const void *>(k_sa_sweep_team<false>);
+    if (lds > 64 * 1024) {
+      ASP_HIP_TRY(hipFuncSetAttribute(team_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(lds)));
+    }
+    ASP_HIP_TRY(hipEventRecord(p->ev[0], s));
+    ASP_HIP_TRY(hipEventRecord(p->ev[1], s));
+    void *kernel_args[] = {&ta};
+    // cooperative: every workgroup of every team must be resident, the barrier waits for them
+    ASP_HIP_TRY(hipLaunchCooperativeKernel(team_kernel, dim3(repetitions * team), dim3(threads),
+                                           kernel_args, static_cast<unsigned>(lds), s));
+    ASP_HIP_TRY(hipEventRecord(p->ev[2], s));
+    ASP_HIP_TRY(hipMemcpyAsync(&team_abort, ta.abort, sizeof team_abort, hipMemcpyDeviceToHost, s));
+  } else {
+    SweepKernel kernel = sweep_kernel_for(m, descent, layout);
+    if (lds > 64 * 1024) {
+      ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(lds)));
+    }
+    ASP_HIP_TRY(hipEventRecord(p->ev[0], s));
+    ASP_HIP_TRY(hipEventRecord(p->ev[1], s));
+    hipLaunchKernelGGL(kernel, dim3(groups), dim3(threads), lds, s, args);
+    ASP_HIP_TRY(hipGetLastError());
+    ASP_HIP_TRY(hipEventRecord(p->ev[2], s));
   }
-  ASP_HIP_TRY(hipEventRecord(p->ev[0], s));
-  ASP_HIP_TRY(hipEventRecord(p->ev[1], s));
-  hipLaunchKernelGGL(kernel, dim3(groups), dim3(threads), lds, s, args);
-  ASP_HIP_TRY(hipGetLastError());
-  ASP_HIP_TRY(hipEventRecord(p->ev[2], s));
   // the first `repetitions` rows of best_perm are the real replicas
   ASP_TRY(energies_of_perm(p, d_best.ptr, repetitions, d_partial.ptr, d_e.ptr));
   {
@@ -1349,8 +1646,12 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
                                hipMemcpyDeviceToHost, s));
   }
   ASP_HIP_TRY(hipStreamSynchronize(s));
+  if (team_abort != 0) {
+    return asp::set_error(ASP_ERR_HIP, "team barrier timed out (workgroups of a team were not "
+                                       "making progress together); results discarded");
+  }
   p->last_m = m;
-  p->last_layout = layout;
+  p->last_layout = team >= 2 ? 4 : layout;
   p->last_threads = threads;
   p->last_groups = static_cast<int>(groups);
   ASP_HIP_TRY(hipEventElapsedTime(&p->last_sweep_ms, p->ev[1], p->ev[2]));

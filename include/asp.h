@@ -273,6 +273,14 @@ int asp_sa_set_packed(asp_sa_plan *p, int packed);
 int asp_sa_set_wide(asp_sa_plan *p, int allow);
 int asp_sa_last_layout(asp_sa_plan const *p);
 
+/* Few chains on a large cluster (chains <= CUs / 2, e.g. the reference's default of 64
+ * repetitions): each chain is spread over a TEAM of 2, 4 or 8 workgroups that split every colour
+ * class, exchange one flip word per block and meet at a device-scope barrier per colour
+ * (cooperative launch).  team = -1 chooses automatically (default), 0 never, 2/4/8 forces that
+ * team size when the chains fit (tests, measurements).  Chains are bit-identical either way;
+ * asp_sa_last_layout reports 4 for a team launch. */
+int asp_sa_set_team(asp_sa_plan *p, int team);
+
 /* Field cache (default on): once a sweep flips few spins, a workgroup keeps the local fields
  * of every block in HBM and re-evaluates a block only after one of its neighbours flipped.
  * Pure optimisation of frozen sweeps; results are identical with it on or off. */

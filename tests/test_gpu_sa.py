@@ -496,3 +496,84 @@ def test_energy_traces_match_oracle(m, threads):
     assert abs(e_current[0] - e_start) <= 1e-9 * abs(e_start)          # anchored consistently
     assert abs(e_best[-1] - ham.energy(x)) == 0 and np.all(np.diff(e_best) <= 0)
     assert np.all(e_best <= e_current + 1e-12)
+
+
+def _set_team(h, team):
+    from annealing_sign_problem_amd import _lib
+
+    _lib.check(_lib.load().asp_sa_set_team(h.plan(), int(team)))
+
+
+@pytest.mark.parametrize("team", [2, 4, 8])
+def test_team_sweep_bit_exact(team):
+    """One chain spread over a team of workgroups (flip words exchanged per colour step behind a
+    device-scope barrier): same chains, tracked energies and flip counts as the oracle — with
+    random start, with x0 and a replica offset."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    lib = _lib.load()
+    J, h, _ = _planted(6000, 51)
+    field = np.random.default_rng(9).normal(size=6000) * 0.01
+    betas = np.geomspace(0.5, 5e4, 30)
+    ham = sa.Hamiltonian(J, field)
+    _set_team(ham, team)
+    xs, es = sa.anneal_raw(ham, 2718, betas, 5, 7)
+    assert lib.asp_sa_last_layout(ham.plan()) == 4
+    tracked, accepted = _stats(ham, 5)
+    S = ham.info().energy_scale_exp
+    oxs, oes, otr, oacc = oracle.sa_anneal(J, field, 2718, betas, 5, 7, None, S, num_threads=8)
+    assert np.array_equal(accepted, oacc) and np.array_equal(tracked, otr)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    x0 = sa.signs_to_bits(np.where(np.random.default_rng(1).random(6000) < 0.5, 1.0, -1.0))
+    xs, es = sa.anneal_raw(ham, 3, betas[:12], 3, 0, x0)
+    oxs, oes, _, _ = oracle.sa_anneal(J, field, 3, betas[:12], 3, 0, x0, S, num_threads=4)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    # switched off: the ordinary kernel, same answer
+    _set_team(ham, 0)
+    xs2, es2 = sa.anneal_raw(ham, 3, betas[:12], 3, 0, x0)
+    assert lib.asp_sa_last_layout(ham.plan()) != 4
+    assert np.array_equal(xs2, oxs) and es2.tobytes() == oes.tobytes()
+
+
+def test_greedy_relaxation_in_team_mode_matches_oracle():
+    """The greedy solver's descent sweeps on one chain also run as a team (forced here on a
+    mid-sized cluster, automatic on large ones): same result as the oracle and as team-off."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    J, h, _ = _planted(9000, 61, frustrated_fraction=0.2)
+    field = np.random.default_rng(2).normal(size=9000) * 1e-3
+    ham = sa.Hamiltonian(J, field)
+    ox, oe = oracle.greedy_solve(J, field)
+    for team in (4, 0):
+        _set_team(ham, team)
+        x, e = sa.greedy_solve(ham)
+        assert _lib.load().asp_sa_last_layout(ham.plan()) == (4 if team else 0)
+        assert np.array_equal(x, ox) and e == oe
+
+
+def test_team_sweep_chosen_automatically_for_few_chains_on_a_large_cluster():
+    """64 chains at K = 1e5 (the reference's default repetitions on a kagome_36-sized cluster):
+    the launcher forms teams by itself; energies check against numpy, chains against the
+    single-workgroup kernel."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    lib = _lib.load()
+    J, h, _ = _planted(100000, 17)
+    ham = sa.Hamiltonian(J, h)
+    info = ham.info()
+    betas = sa.make_schedule(info.beta0_auto, min(info.beta1_auto, 1e8), 20)
+    xs, es = sa.anneal_raw(ham, 42, betas, 64)
+    assert lib.asp_sa_last_layout(ham.plan()) == 4
+    team_ms = lib.asp_sa_last_sweep_ms(ham.plan())
+    _set_team(ham, 0)
+    xs1, es1 = sa.anneal_raw(ham, 42, betas, 64)
+    solo_ms = lib.asp_sa_last_sweep_ms(ham.plan())
+    assert np.array_equal(xs, xs1) and es.tobytes() == es1.tobytes()
+    for r in [0, 63]:
+        s = sa.bits_to_signs(xs[r], 100000)
+        ref = s @ (J @ s)
+        assert abs(es[r] - ref) <= 1e-12 * abs(ref)
+    print("team %.2f ms, single workgroup %.2f ms" % (team_ms, solo_ms))
