@@ -6,6 +6,7 @@
 // union-find that carries the sign of every spin relative to its cluster root.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <numeric>
 #include <vector>
 
@@ -64,10 +65,44 @@ int greedy_tree_signs(const SaHostLayout &L, uint64_t *x) {
       if (j > i) bonds.push_back(Bond{static_cast<uint32_t>(i), j, L.a_val[k]});
     }
   }
-  // strongest first; ties keep (i, j) ascending (the generation order)
-  std::stable_sort(bonds.begin(), bonds.end(), [](const Bond &a, const Bond &b) {
-    return std::fabs(a.weight) > std::fabs(b.weight);
-  });
+  // strongest first; ties keep (i, j) ascending (the generation order).  The bit pattern of
+  // |w| orders like |w|, so this is a stable LSD radix sort (four 16-bit digits) of the
+  // complemented patterns — the order std::stable_sort with `|a| > |b|` gives, several times
+  // faster on the ~1e6 bonds of a large cluster.
+  {
+    const size_t m = bonds.size();
+    std::vector<uint64_t> key(m), key_tmp(m);
+    std::vector<uint32_t> idx(m), idx_tmp(m);
+    for (size_t b = 0; b < m; ++b) {
+      uint64_t bits;
+      const double magnitude = std::fabs(bonds[b].weight);
+      std::memcpy(&bits, &magnitude, sizeof bits);
+      key[b] = ~bits;
+      idx[b] = static_cast<uint32_t>(b);
+    }
+    std::vector<size_t> count(65536);
+    for (int digit = 0; digit < 4; ++digit) {
+      const int shift = 16 * digit;
+      std::fill(count.begin(), count.end(), 0);
+      for (size_t b = 0; b < m; ++b) count[(key[b] >> shift) & 0xFFFFu]++;
+      size_t running = 0;
+      for (size_t d = 0; d < 65536; ++d) {
+        const size_t c = count[d];
+        count[d] = running;
+        running += c;
+      }
+      for (size_t b = 0; b < m; ++b) {
+        const size_t at = count[(key[b] >> shift) & 0xFFFFu]++;
+        key_tmp[at] = key[b];
+        idx_tmp[at] = idx[b];
+      }
+      key.swap(key_tmp);
+      idx.swap(idx_tmp);
+    }
+    std::vector<Bond> sorted(m);
+    for (size_t b = 0; b < m; ++b) sorted[b] = bonds[idx[b]];
+    bonds.swap(sorted);
+  }
 
   SignedForest forest(n);
   for (const Bond &bond : bonds) {
