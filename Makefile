@@ -1,0 +1,47 @@
+# Thin wrappers around the Python entry points, with the parameters of the reference's targets
+# (reference Makefile:17-35 `small`, :101-141 `kagome_36` / `pyrochlore_32` / `sk_32_1`).  The
+# reference's inputs are HDF5 ground states it downloads; here the symmetry-free 16-site models of
+# annealing_sign_problem_amd/models.json are diagonalised on the spot.
+PYTHON ?= python3
+SEED ?= 435834
+NOISE ?= 0
+CUTOFF ?= 1e-6
+ORDER ?= 2
+NUMBER_SAMPLES ?= 1000
+JOBS ?= 8
+MODEL ?= heisenberg_kagome_16
+SMALL_MODELS = heisenberg_kagome_16 j1j2_square_4x4 sk_16_1 sk_16_2 sk_16_3
+OUT ?= experiments
+
+.PHONY: all build test test-gpu bench small clusters
+all: build
+
+build:
+	$(PYTHON) __graft_entry__.py
+
+test:
+	$(PYTHON) -m pytest tests -x -q -m "not gpu"
+
+test-gpu:
+	$(PYTHON) -m pytest tests -x -q -m gpu
+
+bench:
+	$(PYTHON) bench.py
+
+# `make small`: P(exact signs) vs number of sweeps on the full 16-site Hilbert spaces
+small: $(SMALL_MODELS:%=$(OUT)/%.csv)
+
+$(OUT)/%.csv:
+	@mkdir -p $(OUT)
+	$(PYTHON) -m annealing_sign_problem_amd.full_hilbert_space --model $* --seed $(SEED) \
+		--output $@.wip --repetitions 1024 \
+		--number-sweeps 100,200,400,800,1600,3200,6400,12800,25600,51200,102400,204800 && \
+	mv $@.wip $@
+
+# `make kagome_36`-style run (greedy only, extension order $(ORDER), global cutoff) on $(MODEL)
+clusters:
+	@mkdir -p $(OUT)/$(MODEL)/noise_$(NOISE)/cutoff_$(CUTOFF)
+	$(PYTHON) -m annealing_sign_problem_amd.sampled_components --model $(MODEL) --seed $(SEED) \
+		--output $(OUT)/$(MODEL)/noise_$(NOISE)/cutoff_$(CUTOFF)/$(MODEL).csv$(JOBID) \
+		--order $(ORDER) --noise $(NOISE) --no-annealing --global-cutoff $(CUTOFF) \
+		--number-samples $(NUMBER_SAMPLES) --jobs $(JOBS)
