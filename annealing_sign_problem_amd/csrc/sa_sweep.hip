@@ -48,6 +48,9 @@
 #ifndef ASP_INERT_SKIP
 #define ASP_INERT_SKIP 1
 #endif
+#ifndef ASP_TEAM_SLEEP
+#define ASP_TEAM_SLEEP 4  // s_sleep argument between two polls of the team barrier (0/1/4/16/64 scanned)
+#endif
 #ifndef ASP_J_MAJOR
 #define ASP_J_MAJOR 1
 #endif
@@ -876,7 +879,7 @@ __device__ __forceinline__ void team_barrier(const TeamArgs &ta, unsigned long l
         __hip_atomic_store(ta.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
-      __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_s_sleep(ASP_TEAM_SLEEP);
     }
   }
   __syncthreads();
