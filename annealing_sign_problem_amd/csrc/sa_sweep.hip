@@ -30,6 +30,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <initializer_list>
+#include <mutex>
 #include <vector>
 
 #include "asp_common.hpp"
@@ -1571,7 +1572,12 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
   }
 
   uint32_t team_abort = 0;
+  // Two cooperative kernels resident at the same time could each hold CUs the other is waiting
+  // for: team launches of one process take turns (from launch to completion).
+  static std::mutex team_launches;
+  std::unique_lock<std::mutex> team_turn(team_launches, std::defer_lock);
   if (team >= 2) {
+    team_turn.lock();
     // wavefronts per member: the widest colour class split over the team, at most 16
     uint32_t widest = 1;
     for (uint32_t c = 0; c < L.num_colors; ++c) {
@@ -1607,8 +1613,18 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
     ASP_HIP_TRY(hipEventRecord(p->ev[1], s));
     void *kernel_args[] = {&ta};
     // cooperative: every workgroup of every team must be resident, the barrier waits for them
-    ASP_HIP_TRY(hipLaunchCooperativeKernel(team_kernel, dim3(repetitions * team), dim3(threads),
-                                           kernel_args, static_cast<unsigned>(lds), s));
+    const hipError_t launched = hipLaunchCooperativeKernel(
+        team_kernel, dim3(repetitions * team), dim3(threads), kernel_args,
+        static_cast<unsigned>(lds), s);
+    if (launched != hipSuccess) {
+      // no cooperative launch on this device/configuration: one workgroup per chain instead
+      (void)hipGetLastError();
+      ASP_HIP_TRY(hipStreamSynchronize(s));
+      team_turn.unlock();
+      p->team_mode = 0;
+      return run_chains(p, seed, betas, num_sweeps, repetitions, replica_offset, x0, descent, out_x,
+                        out_e, out_trace);
+    }
     ASP_HIP_TRY(hipEventRecord(p->ev[2], s));
     ASP_HIP_TRY(hipMemcpyAsync(&team_abort, ta.abort, sizeof team_abort, hipMemcpyDeviceToHost, s));
   } else {

@@ -577,3 +577,28 @@ def test_team_sweep_chosen_automatically_for_few_chains_on_a_large_cluster():
         ref = s @ (J @ s)
         assert abs(es[r] - ref) <= 1e-12 * abs(ref)
     print("team %.2f ms, single workgroup %.2f ms" % (team_ms, solo_ms))
+
+
+def test_team_sweeps_from_concurrent_host_threads():
+    """sampled_components --jobs runs several Hamiltonians at once from host threads: their
+    cooperative team launches must take turns (two resident at once could starve each other)
+    and still return the single-threaded results."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from annealing_sign_problem_amd import annealer as sa
+
+    problems = []
+    for k in range(6):
+        J, h, _ = _planted(40000 + 5000 * k, 70 + k, mean_degree=8.0)
+        problems.append(sa.Hamiltonian(J, h))
+
+    def solve(ham):
+        info = ham.info()
+        betas = sa.make_schedule(info.beta0_auto, min(info.beta1_auto, 1e7), 40)
+        return sa.anneal_raw(ham, 5, betas, 8)
+
+    serial = [solve(h) for h in problems]
+    with ThreadPoolExecutor(max_workers=6) as pool:
+        threaded = list(pool.map(solve, problems))
+    for (xs, es), (xt, et) in zip(serial, threaded):
+        assert np.array_equal(xs, xt) and es.tobytes() == et.tobytes()
