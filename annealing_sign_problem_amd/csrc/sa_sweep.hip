@@ -896,6 +896,14 @@ __global__ __launch_bounds__(1024) void k_sa_sweep_team(TeamArgs ta) {
   // [4] accepted flips of the chain so far
   long long *book = reinterpret_cast<long long *>(lds + static_cast<size_t>(a.num_blocks) * 8u);
   uint32_t *improved = reinterpret_cast<uint32_t *>(book + 5);
+  // ctl[0]: 1 while the team tracks which blocks are untouched ("tracking": few flips per
+  // sweep), ctl[1]: 1 in the sweep tracking was switched on.  Then per block a dirty byte (a
+  // neighbour flipped since the block's last evaluation) and an inert byte (its last evaluation
+  // was all certain rejections) — the bookkeeping of k_sa_sweep's cached mode without the cached
+  // fields: a clean inert block is skipped, everything else is evaluated in full.
+  uint32_t *ctl = improved + 1;
+  uint8_t *dirty = reinterpret_cast<uint8_t *>(ctl + 3);
+  uint8_t *inert = dirty + ((a.num_blocks + 15u) & ~15u);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, waves = blockDim.x >> 6;
   const uint32_t G = ta.team_size;
   // members of a team are num_teams apart: the same XCD when num_teams is a multiple of 8
@@ -923,7 +931,11 @@ __global__ __launch_bounds__(1024) void k_sa_sweep_team(TeamArgs ta) {
     if (lane == 0) words[b0] = word;
   }
   if (tid < 5) book[tid] = 0;
-  if (tid == 0) *improved = 0;
+  if (tid == 0) {
+    *improved = 0;
+    ctl[0] = 0;
+    ctl[1] = 0;
+  }
   __syncthreads();
   if (member == 0) {
     for (uint32_t w = tid; w < a.num_blocks; w += blockDim.x) {
@@ -934,12 +946,26 @@ __global__ __launch_bounds__(1024) void k_sa_sweep_team(TeamArgs ta) {
   uint32_t one_hi[4] = {0x3FF00000u, 0x3FF00000u, 0x3FF00000u, 0x3FF00000u};
   for (uint32_t t = 0; t < a.num_sweeps; ++t) {
     const double beta = a.betas[t];
+    const bool tracking = __builtin_amdgcn_readfirstlane(ctl[0]) != 0;
+    if (tracking && t > 0 && beta < a.betas[t - 1]) {
+      // certain rejections are only certain for non-decreasing beta (team-uniform branch)
+      for (uint32_t b = tid; b < a.num_blocks; b += blockDim.x) inert[b] = 0;
+      __syncthreads();
+    }
     long long q_acc = 0;
     uint32_t n_acc = 0;
     for (uint32_t c = 0; c < a.num_colors; ++c) {
       const uint32_t b_begin = a.color_block_start[c];
       const uint32_t b_end = a.color_block_start[c + 1];
       for (uint32_t b = b_begin + member * waves + wave; b < b_end; b += G * waves) {
+        if (tracking && __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(dirty[b])) == 0u &&
+            __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(inert[b])) != 0u) {
+          // nothing around this block moved and every proposal was a certain rejection
+          if (lane == 0) {
+            __hip_atomic_store(flipbuf + b, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          continue;
+        }
         const uint32_t p = b * 64u + lane;
         const uint32_t quads = a.block_width[b] >> 2;
         const uint64_t first_quad = a.ell_off[b] >> 2;
@@ -968,6 +994,9 @@ __global__ __launch_bounds__(1024) void k_sa_sweep_team(TeamArgs ta) {
         const double g = __dadd_rn(acc[0], h);
         const double de = __dmul_rn(negative ? 2.0 : -2.0, g);
         bool accept;
+        // this lane's proposal is not a certain rejection
+        const bool open = DESCENT ? (valid && de < 0.0)
+                                  : (valid && !(__dmul_rn(beta, de) >= 23.0));
         if constexpr (DESCENT) {
           accept = valid && de < 0.0;
         } else {
@@ -986,14 +1015,59 @@ __global__ __launch_bounds__(1024) void k_sa_sweep_team(TeamArgs ta) {
           if (flips != 0) words[b] ^= flips;
           __hip_atomic_store(flipbuf + b, flips, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (tracking) {
+          const bool none_open = __ballot(open) == 0ull;
+          if (lane == 0) {
+            dirty[b] = 0;  // nobody marks a block during its own colour step
+            inert[b] = none_open ? 1 : 0;
+          }
+          if (flips != 0) {
+            // the neighbours of a flipped spin sit in blocks of other colours: stale now
+            for (uint32_t q = 0; q < quads; ++q) {
+              const uint4 c4 = cptr[q * 64u];
+              if (accept) {  // (padding entries point at the lane's own position)
+                if (c4.x != p) dirty[c4.x >> 6] = 1;
+                if (c4.y != p) dirty[c4.y >> 6] = 1;
+                if (c4.z != p) dirty[c4.z >> 6] = 1;
+                if (c4.w != p) dirty[c4.w >> 6] = 1;
+              }
+            }
+          }
+        }
       }
       team_barrier(ta, counter, target);
-      // the other members' flips of this colour step
-      for (uint32_t i = tid; i < b_end - b_begin; i += blockDim.x) {
-        if ((i / waves) % G != member) {
+      // the other members' flips of this colour step: XOR them in and, when tracking, mark the
+      // blocks of the flipped spins' neighbours (a wavefront per flipped block, lane = row)
+      if (tracking) {
+        for (uint32_t i = wave; i < b_end - b_begin; i += waves) {
+          if ((i / waves) % G == member) continue;
+          const uint32_t b = b_begin + i;
           const uint64_t flips =
-              __hip_atomic_load(flipbuf + b_begin + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (flips != 0) words[b_begin + i] ^= flips;
+              __hip_atomic_load(flipbuf + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (flips == 0) continue;  // wave-uniform
+          if (lane == 0) words[b] ^= flips;
+          const uint32_t quads = a.block_width[b] >> 2;
+          const uint4 *cptr =
+              reinterpret_cast<const uint4 *>(a.ell_col) + (a.ell_off[b] >> 2) * 64u + lane;
+          const bool flipped = (flips >> lane) & 1ull;
+          for (uint32_t q = 0; q < quads; ++q) {
+            const uint4 c4 = cptr[q * 64u];
+            if (flipped) {
+              const uint32_t p = b * 64u + lane;
+              if (c4.x != p) dirty[c4.x >> 6] = 1;
+              if (c4.y != p) dirty[c4.y >> 6] = 1;
+              if (c4.z != p) dirty[c4.z >> 6] = 1;
+              if (c4.w != p) dirty[c4.w >> 6] = 1;
+            }
+          }
+        }
+      } else {
+        for (uint32_t i = tid; i < b_end - b_begin; i += blockDim.x) {
+          if ((i / waves) % G != member) {
+            const uint64_t flips = __hip_atomic_load(flipbuf + b_begin + i, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+            if (flips != 0) words[b_begin + i] ^= flips;
+          }
         }
       }
       __syncthreads();
@@ -1027,6 +1101,12 @@ __global__ __launch_bounds__(1024) void k_sa_sweep_team(TeamArgs ta) {
       const bool better = e < book[1];
       if (better) book[1] = e;
       *improved = (better || DESCENT) ? 1u : 0u;
+      // tracking pays while the flips of a sweep touch a fraction of the blocks (the same
+      // hysteresis as the field cache; dn is the team-wide count, so all members agree)
+      const bool was = ctl[0] != 0;
+      const bool now = was ? dn < 2ll * a.cache_enter_flips : dn < static_cast<long long>(a.cache_enter_flips);
+      ctl[0] = now ? 1u : 0u;
+      ctl[1] = (now && !was) ? 1u : 0u;
       // the other parity's slot was read a sweep ago and is next added to a sweep from now,
       // with team barriers on either side: one member clears it
       if (member == 0) {
@@ -1038,6 +1118,12 @@ __global__ __launch_bounds__(1024) void k_sa_sweep_team(TeamArgs ta) {
     if (*improved != 0u && member == 0) {
       for (uint32_t w = tid; w < a.num_blocks; w += blockDim.x) {
         a.best_perm[static_cast<uint64_t>(team) * a.num_blocks + w] = words[w];
+      }
+    }
+    if (ctl[1] != 0u) {  // tracking starts with the next sweep: every block is stale
+      for (uint32_t b = tid; b < a.num_blocks; b += blockDim.x) {
+        dirty[b] = 1;
+        inert[b] = 0;
       }
     }
     __syncthreads();
@@ -1244,6 +1330,12 @@ size_t sweep_lds_bytes(const asp::SaHostLayout &L, int layout) {
   const size_t per_block = layout == kWide ? 256 : 64;
   return static_cast<size_t>(L.num_blocks) * per_block + 34 * sizeof(long long) +
          static_cast<size_t>(L.num_blocks) * sizeof(uint2) + 16 +
+         2 * (((static_cast<size_t>(L.num_blocks) + 15) / 16) * 16);
+}
+
+// k_sa_sweep_team: sign words | book, flags (64 B) | dirty[num_blocks] | inert[num_blocks]
+size_t team_lds_bytes(const asp::SaHostLayout &L) {
+  return static_cast<size_t>(L.num_blocks) * 8 + 64 +
          2 * (((static_cast<size_t>(L.num_blocks) + 15) / 16) * 16);
 }
 
@@ -1477,7 +1569,7 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
     for (uint32_t c = 0; c < L.num_colors; ++c) {
       widest = std::max(widest, L.color_block_start[c + 1] - L.color_block_start[c]);
     }
-    const size_t team_lds = static_cast<size_t>(L.num_blocks) * 8 + 64;
+    const size_t team_lds = team_lds_bytes(L);
     const bool possible = !out_trace && !global && p->force_packed == 0 &&
                           p->force_m == 0 && team_lds <= p->max_lds &&
                           static_cast<uint64_t>(repetitions) * 2 <= static_cast<uint64_t>(p->num_cus);
@@ -1494,8 +1586,7 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
   if (team >= 2) m = 1;
   const int layout = team >= 2 ? kBits
                                : (global ? kGlobal : (packed ? kBits : (wide ? kWide : kBytes)));
-  const size_t lds = team >= 2 ? static_cast<size_t>(L.num_blocks) * 8 + 64
-                               : sweep_lds_bytes(L, layout);
+  const size_t lds = team >= 2 ? team_lds_bytes(L) : sweep_lds_bytes(L, layout);
   if (lds > p->max_lds) {
     return asp::set_error(ASP_ERR_TOO_LARGE, "%zu B of LDS needed, %zu B available", lds,
                           p->max_lds);
@@ -1584,6 +1675,12 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
       widest = std::max(widest, L.color_block_start[c + 1] - L.color_block_start[c]);
     }
     threads = static_cast<int>(std::min<uint32_t>(16u, (widest + team - 1) / team)) * 64;
+    if (p->use_field_cache) {
+      // the team's "tracking" of untouched blocks uses the field cache's switch-over threshold
+      const double degree = std::max(1.0, static_cast<double>(L.a_col.size()) / static_cast<double>(K));
+      args.cache_enter_flips =
+          static_cast<uint32_t>(std::max(1.0, 0.7 * static_cast<double>(L.num_blocks) / degree));
+    }
     TeamArgs ta{};
     ta.s = args;
     ta.team_size = team;

@@ -602,3 +602,32 @@ def test_team_sweeps_from_concurrent_host_threads():
         threaded = list(pool.map(solve, problems))
     for (xs, es), (xt, et) in zip(serial, threaded):
         assert np.array_equal(xs, xt) and es.tobytes() == et.tobytes()
+
+
+@pytest.mark.parametrize("team", [2, 8])
+def test_team_sweep_tracks_untouched_blocks_in_the_frozen_tail(team):
+    """In the frozen tail a team skips blocks whose neighbourhood has not moved and whose
+    proposals were all certain rejections (tracking switches on when a sweep flips few spins,
+    also learning about the other members' flips).  A ladder that freezes, reheats and freezes
+    again must follow the oracle bit for bit, with and without the tracking."""
+    from annealing_sign_problem_amd import annealer as sa
+
+    J, h, _ = _planted(5000, 81)
+    field = np.random.default_rng(12).normal(size=5000) * 1e-4
+    betas = np.concatenate([np.geomspace(1.0, 1e12, 70), np.full(10, 1e12), np.geomspace(1e12, 3e2, 5),
+                            np.geomspace(3e2, 1e12, 50), [1e3, 1e12, 1e12, 1e5, 1e12]])
+    ham = sa.Hamiltonian(J, field)
+    _set_team(ham, team)
+    xs, es = sa.anneal_raw(ham, 123, betas, 4, 1)
+    tracked, accepted = _stats(ham, 4)
+    S = ham.info().energy_scale_exp
+    oxs, oes, otr, oacc = oracle.sa_anneal(J, field, 123, betas, 4, 1, None, S, num_threads=4)
+    assert np.array_equal(accepted, oacc) and np.array_equal(tracked, otr)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    _set_cache(ham, False)   # the same switch turns the tracking off
+    xs2, es2 = sa.anneal_raw(ham, 123, betas, 4, 1)
+    assert np.array_equal(xs2, oxs) and es2.tobytes() == oes.tobytes()
+    # the chains really freeze and thaw: flips during the reheating, none in sweeps 70..79
+    _, _, _, acc80 = oracle.sa_anneal(J, field, 123, betas[:80], 4, 1, None, S, num_threads=4)
+    _, _, _, acc70 = oracle.sa_anneal(J, field, 123, betas[:70], 4, 1, None, S, num_threads=4)
+    assert np.array_equal(acc80, acc70) and (oacc.astype(np.int64) - acc80.astype(np.int64)).min() > 100
