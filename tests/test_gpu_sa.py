@@ -631,3 +631,61 @@ def test_team_sweep_tracks_untouched_blocks_in_the_frozen_tail(team):
     _, _, _, acc80 = oracle.sa_anneal(J, field, 123, betas[:80], 4, 1, None, S, num_threads=4)
     _, _, _, acc70 = oracle.sa_anneal(J, field, 123, betas[:70], 4, 1, None, S, num_threads=4)
     assert np.array_equal(acc80, acc70) and (oacc.astype(np.int64) - acc80.astype(np.int64)).min() > 100
+
+
+def test_randomised_configurations_match_oracle():
+    """Two hundred random small problems x launch shapes x spin layouts x team sizes x start modes:
+    every combination must reproduce the oracle's chains, tracked energies and flip counts."""
+    from annealing_sign_problem_amd import _lib, synthetic
+    from annealing_sign_problem_amd import annealer as sa
+
+    lib = _lib.load()
+    rng = np.random.default_rng(20261004)
+    for case in range(200):
+        n = int(rng.choice([1, 2, 63, 64, 65, 128, 500, 1024, 1500, 2500]))
+        degree = float(rng.choice([0.0, 1.0, 3.0, 9.0, 24.0]))
+        if degree == 0.0 or n < 4:
+            J = scipy.sparse.diags(rng.normal(size=n)).tocsr()
+            h = rng.normal(size=n)
+        else:
+            J, h, _ = synthetic.planted_cluster(n, seed=int(rng.integers(1 << 30)),
+                                                mean_degree=min(degree, n / 3),
+                                                frustrated_fraction=float(rng.random() * 0.5))
+            h = h + rng.normal(size=n) * float(rng.choice([0.0, 1e-3, 1.0]))
+        sweeps = int(rng.choice([0, 1, 7, 30]))
+        betas = np.geomspace(0.2, float(rng.choice([5.0, 1e4, 1e12])), sweeps) if sweeps else np.zeros(0)
+        if sweeps > 3 and rng.random() < 0.3:
+            betas[sweeps // 2] = 0.0          # an infinite-temperature sweep in the middle
+        reps = int(rng.choice([1, 3, 8, 17]))
+        offset = int(rng.choice([0, 1, 5, 1000]))
+        x0 = None
+        if rng.random() < 0.4:
+            x0 = sa.signs_to_bits(np.where(rng.random(n) < 0.5, 1.0, -1.0))
+        ham = sa.Hamiltonian(J, h)
+        mode = int(rng.integers(5))
+        m = int(rng.choice([0, 1, 2, 4, 8]))
+        threads = int(rng.choice([0, 64, 256, 1024]))
+        label = "case %d: n=%d degree=%s sweeps=%d reps=%d mode=%d m=%d threads=%d" % (
+            case, n, degree, sweeps, reps, mode, m, threads)
+        if mode == 0:
+            _set_launch(ham, m, threads)                    # bytes / words, any group size
+        elif mode == 1:
+            _set_packed(ham, 1)
+            _set_launch(ham, 0, threads)
+        elif mode == 2:
+            _set_packed(ham, 2)
+            _set_launch(ham, 0, threads)
+        elif mode == 3:
+            _set_team(ham, int(rng.choice([2, 4, 8])))
+        else:
+            _set_launch(ham, m, threads)
+            _lib.check(lib.asp_sa_set_wide(ham.plan(), 0))
+            _set_cache(ham, False)
+        xs, es = sa.anneal_raw(ham, 77 + case, betas, reps, offset, x0)
+        tracked, accepted = _stats(ham, reps)
+        S = ham.info().energy_scale_exp
+        oxs, oes, otr, oacc = oracle.sa_anneal(J, h, 77 + case, betas, reps, offset, x0, S,
+                                               num_threads=4)
+        assert np.array_equal(xs, oxs), label
+        assert es.tobytes() == oes.tobytes(), label
+        assert np.array_equal(tracked, otr) and np.array_equal(accepted, oacc), label
