@@ -20,7 +20,9 @@ The JSON line also carries
   cpu_baseline  the oracle's OpenMP port of the same sweep on the host cores,
                 timed on a bounded sample (rank 0, N = 1 only);
   build         the coupling build (build_matrix) on the K = 1e5 cluster, device
-                resident, next to the reference's own C timed on a sample.
+                resident, next to the reference's own C timed on a sample;
+  reference_default_call  the reference's default solve (5120 sweeps x 64 chains)
+                on one 1e5-spin cluster, team sweep vs one workgroup per chain.
 """
 from __future__ import annotations
 
@@ -253,6 +255,32 @@ def bench_build(J, cores_unused, seconds=6.0):
     }
 
 
+def bench_default_call():
+    """The reference's default solve (common.py:236-239: 5120 sweeps, 64 repetitions) on one
+    kagome_36-sized cluster: 64 chains cannot fill 256 CUs one workgroup each, so the launcher
+    spreads every chain over a team of workgroups; timed next to the
+    one-workgroup-per-chain kernel, same energies required."""
+    from annealing_sign_problem_amd import _lib, synthetic
+    from annealing_sign_problem_amd import annealer as sa
+
+    lib = _lib.load()
+    J, h, _ = synthetic.planted_cluster(100000, seed=1, mean_degree=8.0)
+    ham = sa.Hamiltonian(J, h)
+    sa.anneal(ham, seed=1, number_sweeps=16, repetitions=64)  # warm-up
+    out = {"workload": "anneal(number_sweeps=5120, repetitions=64), K=100000, dbar=8"}
+    energies = []
+    for name, team in (("team", -1), ("one_workgroup_per_chain", 0)):
+        _lib.check(lib.asp_sa_set_team(ham.plan(), team))
+        t0 = time.perf_counter()
+        x, e = sa.anneal(ham, seed=12345, number_sweeps=5120, repetitions=64)
+        out[name + "_s"] = time.perf_counter() - t0
+        out[name + "_flips_per_s"] = 100000 * 64 * 5120 / (lib.asp_sa_last_sweep_ms(ham.plan()) * 1e-3)
+        energies.append(e)
+    if energies[0] != energies[1]:
+        raise RuntimeError("team sweep and single-workgroup sweep disagree")
+    return out
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -391,6 +419,7 @@ def main():
                                                args.cpu_seconds)
         if world == 1 and not args.no_build:
             out["build"] = bench_build(clusters[-1]["J"], 1)
+            out["reference_default_call"] = bench_default_call()
         print(json.dumps(out))
 
     if world > 1:
