@@ -7,9 +7,17 @@
 //   * one workgroup = one GROUP of M replicas (M in {1,2,4,8}); the whole anneal
 //     (all sweeps) is ONE launch, the spins never leave LDS;
 //   * LDS: one byte per (padded) spin position, bit m = sign bit of replica m
-//     (1 means s = -1), so one ds_read_u8 serves all M replicas of a neighbour;
-//     beyond the capacity of that layout, one BIT per position and one replica
-//     per workgroup (PACKED), flips applied by a wavefront ballot;
+//     (1 means s = -1), so one ds_read_u8 serves all M replicas of a neighbour
+//     (kBytes); a 32-bit word per position for M = 4 on small clusters, where
+//     the sign of a term is one SDWA instruction (kWide); beyond the capacity of
+//     bytes one BIT per position and one replica per workgroup, flips applied
+//     by a wavefront ballot (kBits), and beyond 1.3e6 spins the same bit words
+//     in HBM (kGlobal);
+//   * frozen sweeps: row sums cached in HBM and re-used while no neighbour of a
+//     block flipped (dirty bytes), blocks whose proposals are all certain
+//     rejections skipped outright (inert bytes);
+//   * few chains on a large cluster: k_sa_sweep_team spreads ONE chain over 2-8
+//     workgroups that exchange 64-bit flip words behind a device-scope barrier;
 //   * a wavefront owns a 64-row block of one colour class: lane = spin.  Same
 //     colour means no couplings inside the block, so the 64 x M proposals of a
 //     block are independent and are decided at once;
