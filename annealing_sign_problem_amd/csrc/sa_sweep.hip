@@ -861,7 +861,7 @@ struct TeamArgs {
   uint32_t num_teams;            // = chains of the launch
   unsigned long long *arrivals;  // [num_teams] barrier counters (monotone)
   uint64_t *flips;               // [num_teams][num_blocks] flip words of the running colour step
-  long long *sums;               // [num_teams][2 parities][2] {dq, accepted} of a sweep
+  long long *sums;               // [num_teams][3 rotating slots][2] {dq, accepted} of a sweep
   uint32_t *abort;               // set by the watchdog
 };
 
@@ -1043,6 +1043,25 @@ __global__ __launch_bounds__(1024) void k_sa_sweep_team(TeamArgs ta) {
           }
         }
       }
+      if (c + 1u == a.num_colors) {
+        // the sweep's energy change rides on the last colour's barrier (integers: order-free)
+        const long long v = wave_sum_i64(q_acc);
+        const long long n = wave_sum_i64(static_cast<long long>(n_acc));
+        if (lane == 0 && n != 0) {
+          atomicAdd(reinterpret_cast<unsigned long long *>(&book[2]), static_cast<unsigned long long>(v));
+          atomicAdd(reinterpret_cast<unsigned long long *>(&book[3]), static_cast<unsigned long long>(n));
+        }
+        __syncthreads();
+        if (tid == 0) {
+          long long *mine = ta.sums + (static_cast<uint64_t>(team) * 3u + t % 3u) * 2u;
+          if (book[3] != 0) {
+            __hip_atomic_fetch_add(&mine[0], book[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&mine[1], book[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          book[2] = 0;
+          book[3] = 0;
+        }
+      }
       team_barrier(ta, counter, target);
       // the other members' flips of this colour step: XOR them in and, when tracking, mark the
       // blocks of the flipped spins' neighbours (a wavefront per flipped block, lane = row)
@@ -1081,25 +1100,9 @@ __global__ __launch_bounds__(1024) void k_sa_sweep_team(TeamArgs ta) {
       __syncthreads();
     }
 
-    // ---- the sweep's energy change, summed over the team (integers: order-free) ----
-    const long long v = wave_sum_i64(q_acc);
-    const long long n = wave_sum_i64(static_cast<long long>(n_acc));
-    if (lane == 0 && n != 0) {
-      atomicAdd(reinterpret_cast<unsigned long long *>(&book[2]), static_cast<unsigned long long>(v));
-      atomicAdd(reinterpret_cast<unsigned long long *>(&book[3]), static_cast<unsigned long long>(n));
-    }
-    __syncthreads();
-    long long *mine = ta.sums + (static_cast<uint64_t>(team) * 2u + (t & 1u)) * 2u;
-    long long *other = ta.sums + (static_cast<uint64_t>(team) * 2u + ((t + 1u) & 1u)) * 2u;
-    if (tid == 0) {
-      if (book[3] != 0) {
-        __hip_atomic_fetch_add(&mine[0], book[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&mine[1], book[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      book[2] = 0;
-      book[3] = 0;
-    }
-    team_barrier(ta, counter, target);
+    // ---- bookkeeping of the sweep: the team sums were exchanged with the last colour ----
+    long long *mine = ta.sums + (static_cast<uint64_t>(team) * 3u + t % 3u) * 2u;
+    long long *other = ta.sums + (static_cast<uint64_t>(team) * 3u + (t + 2u) % 3u) * 2u;
     if (tid == 0) {
       const long long dq = __hip_atomic_load(&mine[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const long long dn = __hip_atomic_load(&mine[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1115,8 +1118,8 @@ __global__ __launch_bounds__(1024) void k_sa_sweep_team(TeamArgs ta) {
       const bool now = was ? dn < 2ll * a.cache_enter_flips : dn < static_cast<long long>(a.cache_enter_flips);
       ctl[0] = now ? 1u : 0u;
       ctl[1] = (now && !was) ? 1u : 0u;
-      // the other parity's slot was read a sweep ago and is next added to a sweep from now,
-      // with team barriers on either side: one member clears it
+      // three rotating slots: the one cleared here was read a sweep ago and is next added to
+      // two sweeps from now, with team barriers on either side; one member clears it
       if (member == 0) {
         __hip_atomic_store(&other[0], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&other[1], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1294,7 +1297,7 @@ struct asp_sa_plan {
   DeviceBuffer<uint64_t> w_spins;      // [groups][blocks] sign words of the HBM-resident layout
   DeviceBuffer<long long> w_trace;     // [groups * M][sweeps + 1] tracked energies (asp_sa_anneal_trace)
   // team sweep exchange area, FINE-GRAINED device memory (coherent across XCDs without cache
-  // maintenance): arrivals u64[teams] | sums i64[teams][4] | abort u32 (+pad) | flips u64[teams][blocks]
+  // maintenance): arrivals u64[teams] | sums i64[teams][6] | abort u32 (+pad) | flips u64[teams][blocks]
   void *team_area = nullptr;
   size_t team_area_bytes = 0;
   ~asp_sa_plan() {
@@ -1693,7 +1696,7 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
     ta.s = args;
     ta.team_size = team;
     ta.num_teams = repetitions;
-    const size_t head_bytes = static_cast<size_t>(repetitions) * 8 * 5 + 16;
+    const size_t head_bytes = static_cast<size_t>(repetitions) * 8 * 7 + 16;
     const size_t need = head_bytes + static_cast<size_t>(repetitions) * L.num_blocks * 8;
     if (need > p->team_area_bytes) {
       if (p->team_area) (void)hipFree(p->team_area);
@@ -1706,7 +1709,7 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
     uint8_t *area = static_cast<uint8_t *>(p->team_area);
     ta.arrivals = reinterpret_cast<unsigned long long *>(area);
     ta.sums = reinterpret_cast<long long *>(area + static_cast<size_t>(repetitions) * 8);
-    ta.abort = reinterpret_cast<uint32_t *>(area + static_cast<size_t>(repetitions) * 8 * 5);
+    ta.abort = reinterpret_cast<uint32_t *>(area + static_cast<size_t>(repetitions) * 8 * 7);
     ta.flips = reinterpret_cast<uint64_t *>(area + head_bytes);
     const void *team_kernel = descent ? reinterpret_cast<const void *>(k_sa_sweep_team<true>)
                                       : reinterpret_cast<const void *>(k_sa_sweep_team<false>);
