@@ -52,7 +52,7 @@
 #define ASP_MAGIC_RINT 1
 #endif
 #ifndef ASP_EXP_FILTER
-#define ASP_EXP_FILTER 1
+#define ASP_EXP_FILTER 2  // 0 exact rule only, 1 f64 filter on u, 2 integer filter on the word
 #endif
 #ifndef ASP_INERT_SKIP
 #define ASP_INERT_SKIP 1
@@ -191,6 +191,24 @@ __device__ __forceinline__ bool metropolis_accept(double u, double x) {
   const double p = static_cast<double>(estimate);
   if (u < p * (1.0 - 1e-5)) return true;
   if (u > p * (1.0 + 1e-5)) return false;
+  return u < expneg(x);
+}
+
+// The same decision taken on the random WORD: u = (word + 0.5) * 2^-32 < p  <=>  word + 0.5 <
+// p * 2^32.  With est = v_exp_f32 estimate of p (|est / p - 1| <= 2.63e-6, measured) and the two
+// f32 products lo = est * 2^32 (1 - 2e-5), hi = est * 2^32 (1 + 2e-5) (constant and product
+// rounding <= 1.3e-7 together): word < trunc(lo) implies word + 0.5 < lo < p * 2^32 (accept),
+// word > trunc(hi) implies word + 0.5 > hi > p * 2^32 (reject); in between (~4e-5 of the
+// proposals) the exact rule decides.  Integer compares and f32 products replace the f64
+// conversions, products and compares of metropolis_accept.
+__device__ __forceinline__ bool metropolis_accept_word(uint32_t word, double x) {
+  if (!(x < 23.0)) return false;  // expneg(x) = 0 < u; also NaN
+  const float estimate = __builtin_amdgcn_exp2f(static_cast<float>(x) * -1.44269504f);
+  const float lo = estimate * (4294967296.0f * (1.0f - 2e-5f));  // < 2^32: conversion in range
+  if (word < static_cast<uint32_t>(lo)) return true;
+  const float hi = estimate * (4294967296.0f * (1.0f + 2e-5f));
+  if (hi < 4294967040.0f && word > static_cast<uint32_t>(hi)) return false;
+  const double u = __dmul_rn(__dadd_rn(static_cast<double>(word), 0.5), 0x1p-32);
   return u < expneg(x);
 }
 
@@ -724,6 +742,8 @@ __global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep(SweepArgs a) {
 #else
 #if ASP_ABL_NO_EXP
             accept = valid && (de <= 0.0 || u < __dmul_rn(beta, de) * 1e-3);
+#elif ASP_EXP_FILTER == 2
+            accept = valid && (de <= 0.0 || metropolis_accept_word(word, __dmul_rn(beta, de)));
 #elif ASP_EXP_FILTER
             accept = valid && (de <= 0.0 || metropolis_accept(u, __dmul_rn(beta, de)));
 #else
@@ -1010,8 +1030,7 @@ __global__ __launch_bounds__(1024) void k_sa_sweep_team(TeamArgs ta) {
         } else {
           const Philox4 rnd = philox4x32_10(spin, t, r >> 2, 0u, key0, key1);
           const uint32_t word = pick_word(rnd, r & 3u);
-          const double u = __dmul_rn(__dadd_rn(static_cast<double>(word), 0.5), 0x1p-32);
-          accept = valid && (de <= 0.0 || metropolis_accept(u, __dmul_rn(beta, de)));
+          accept = valid && (de <= 0.0 || metropolis_accept_word(word, __dmul_rn(beta, de)));
         }
         if (accept) {
           q_acc += __double_as_longlong(__dadd_rn(__dmul_rn(de, a.scale), 0x1.8p52)) -
