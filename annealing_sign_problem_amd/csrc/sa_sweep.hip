@@ -1372,7 +1372,12 @@ size_t team_lds_bytes(const asp::SaHostLayout &L) {
 // Launch geometry: as many replicas per group as still leaves one group per CU,
 // as many wavefronts as a colour class has blocks.
 void choose_launch(const asp_sa_plan *p, uint32_t repetitions, int *m_out, int *threads_out) {
+  uint32_t widest = 1;  // blocks of the largest colour class
+  for (uint32_t c = 0; c < p->host.num_colors; ++c) {
+    widest = std::max(widest, p->host.color_block_start[c + 1] - p->host.color_block_start[c]);
+  }
   int m = 1;
+  bool two_per_cu = false;
   if (p->force_m) {
     m = p->force_m;
   } else {
@@ -1382,15 +1387,19 @@ void choose_launch(const asp_sa_plan *p, uint32_t repetitions, int *m_out, int *
         break;
       }
     }
+    // Small clusters with chains to spare: two workgroups of four replicas per CU, eight
+    // wavefronts each, fill the thin rounds of one another (K = 1e4, 2048 chains: 209 -> 228
+    // G flips/s against eight replicas in one workgroup; the reverse from ~50 blocks per colour)
+    if (m == 8 && widest <= 32 && !p->force_threads) {
+      m = 4;
+      two_per_cu = true;
+    }
   }
   int threads = p->force_threads;
+  if (two_per_cu) threads = 512;
   if (!threads) {
-    // one wavefront per block of the LARGEST colour class (first-fit classes are skewed, the
+    // one wavefront per block of the LARGEST colour class (DSATUR classes are skewed, the
     // first is the biggest), at most 16
-    uint32_t widest = 1;
-    for (uint32_t c = 0; c < p->host.num_colors; ++c) {
-      widest = std::max(widest, p->host.color_block_start[c + 1] - p->host.color_block_start[c]);
-    }
     // 16 wavefronts pay once a colour step is many rounds long; below ~80 blocks per colour
     // 12 (three per SIMD) finish the same rounds sooner (measured: +7 % at K = 1e4, +5 % at
     // 3e4, -4 % at 5e4; tools/tune_sweep.py --threads)
