@@ -6,8 +6,11 @@ called, an :class:`AspError` is raised.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes
 import os
+import sys
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -55,7 +58,9 @@ SIGNATURES = {
     "asp_clear_error": (None, []),
     "asp_device_count": (c_int, []),
     "asp_set_device": (c_int, [c_int]),
+    "asp_get_device": (c_int, []),
     "asp_version": (ctypes.c_char_p, []),
+    "asp_shutdown": (c_int, []),
     "build_matrix": (c_u64, [c_u64] + [c_void_p] * 11),
     "extract_signs": (None, [c_u64, c_void_p, c_void_p]),
     "asp_build_create": (c_void_p, [c_u64, c_u64]),
@@ -108,6 +113,39 @@ SIGNATURES = {
 }
 
 _lib: Optional[ctypes.CDLL] = None
+_closed = False  # shutdown() ran: device handles are gone, destructors must not touch HIP
+_live = weakref.WeakSet()  # objects owning device handles; each has release()
+
+
+def track(owner) -> None:
+    """Register an object that owns a libasp_hip handle: :func:`shutdown` calls its
+    ``release()`` before the interpreter starts tearing modules down."""
+    _live.add(owner)
+
+
+def closed() -> bool:
+    return _closed or sys.is_finalizing()
+
+
+def shutdown() -> None:
+    """Destroy every live handle, then ``asp_shutdown``.  Registered with ``atexit`` (which runs
+    before module globals are cleared and long before the C runtime's exit handlers), so that no
+    ``__del__`` reaches into HIP during interpreter teardown — where the HIP runtime or a
+    profiler attached to it may already be finalised — and nothing of this library is left for
+    the runtime's own exit handler to clean up."""
+    global _closed
+    if _lib is None or _closed:
+        return
+    for owner in list(_live):
+        try:
+            owner.release()
+        except Exception:
+            pass
+    _closed = True
+    try:
+        _lib.asp_shutdown()
+    except Exception:
+        pass
 
 
 def library_path() -> str:
@@ -133,6 +171,7 @@ def load() -> ctypes.CDLL:
         fn.restype = restype
         fn.argtypes = argtypes
     _lib = lib
+    atexit.register(shutdown)
     return lib
 
 

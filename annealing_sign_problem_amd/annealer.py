@@ -128,6 +128,7 @@ class Hamiltonian:
             raise _lib.AspError(lib.asp_last_error_code(), _lib.last_error())
         self._plan = ctypes.c_void_p(handle)
         self._plan_key = key
+        _lib.track(self)
         return self._plan
 
     def info(self) -> _lib.SaInfo:
@@ -136,6 +137,7 @@ class Hamiltonian:
         return info
 
     def release(self) -> None:
+        """Destroy the device plan now (it is rebuilt on the next use)."""
         if self._plan is not None:
             try:
                 _lib.load().asp_sa_plan_destroy(self._plan)
@@ -144,6 +146,10 @@ class Hamiltonian:
                 self._plan_key = None
 
     def __del__(self):
+        # never reach into HIP from interpreter teardown: _lib.shutdown (atexit) has released
+        # every live plan before that point
+        if getattr(self, "_plan", None) is None or _lib.closed():
+            return
         try:
             self.release()
         except Exception:

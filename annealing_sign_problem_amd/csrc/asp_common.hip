@@ -32,6 +32,7 @@ std::atomic<int> g_device{-1};  // process-wide choice of asp_set_device; -1 = H
 }
 
 void remember_device(int device) { g_device.store(device); }
+int chosen_device() { return g_device.load(); }
 
 int bind_device() {
   const int device = g_device.load();
@@ -165,6 +166,7 @@ struct StreamPool {
     size_t max_lds;
   };
   std::map<int, Limits> limits;
+  bool closed = false;  // after asp_shutdown: released streams are destroyed, not kept
 };
 
 StreamPool &stream_pool() {
@@ -205,12 +207,51 @@ void stream_release(hipStream_t stream) {
     return;
   }
   auto &idle = p.idle[it->second];
-  if (idle.size() < 64) {
+  if (!p.closed && idle.size() < 64) {
     idle.push_back(stream);
   } else {
     p.device_of.erase(it);
     (void)hipStreamDestroy(stream);
   }
+}
+
+int shutdown_pools() {
+  // wait for everything this process queued on the devices it used, then give back what the
+  // library keeps between calls; blocks and streams still handed out stay with their owners
+  std::vector<void *> blocks;
+  std::vector<std::pair<int, hipStream_t>> streams;
+  {
+    Pool &p = pool();
+    std::lock_guard<std::mutex> lock(p.mutex);
+    for (auto &kv : p.idle) {
+      blocks.insert(blocks.end(), kv.second.begin(), kv.second.end());
+      kv.second.clear();
+    }
+    p.idle_bytes = 0;
+    p.cap = 0;  // blocks released after the shutdown are freed directly
+  }
+  {
+    StreamPool &sp = stream_pool();
+    std::lock_guard<std::mutex> lock(sp.mutex);
+    sp.closed = true;
+    for (auto &kv : sp.idle) {
+      for (hipStream_t s : kv.second) {
+        streams.emplace_back(kv.first, s);
+        sp.device_of.erase(s);
+      }
+      kv.second.clear();
+    }
+  }
+  int current = 0;
+  const bool have_device = hipGetDevice(&current) == hipSuccess;
+  for (auto &ds : streams) {
+    if (hipSetDevice(ds.first) != hipSuccess) continue;
+    (void)hipStreamSynchronize(ds.second);
+    (void)hipStreamDestroy(ds.second);
+  }
+  if (have_device) (void)hipSetDevice(current);
+  for (void *b : blocks) (void)hipFree(b);
+  return ASP_OK;
 }
 
 int device_limits(int *num_cus, size_t *max_lds) {
@@ -409,6 +450,20 @@ int asp_set_device(int device) {
   return ASP_OK;
 }
 
-const char *asp_version(void) { return "0.1.0"; }
+int asp_get_device(void) {
+  const int chosen = asp::chosen_device();
+  if (chosen >= 0) return chosen;
+  int device = 0;
+  ASP_HIP_TRY(hipGetDevice(&device));
+  return device;
+}
+
+int asp_shutdown(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ASP_OK;  // nothing was ever used
+  return asp::shutdown_pools();
+}
+
+const char *asp_version(void) { return "0.2.0"; }
 
 }  // extern "C"

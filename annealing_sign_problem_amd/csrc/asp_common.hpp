@@ -46,6 +46,7 @@ int require_device();
 // Only the binding (for entry points that receive an existing handle).
 int bind_device();
 void remember_device(int device);
+int chosen_device();  // -1: asp_set_device was never called
 
 // ---- pooled device memory ---------------------------------------------------
 // hipMalloc/hipFree cost ~0.1-0.5 ms each and hipFree synchronises the device; a sampled-
@@ -77,6 +78,23 @@ struct ScopedStream {
     }
   }
 };
+
+// Declared AFTER the DeviceBuffers of an entry point (objects die in reverse order of
+// declaration): waits for the stream first, so that on an early error return no buffer goes
+// back to the shared pool while a kernel or an asynchronous copy still uses it.
+struct StreamFence {
+  hipStream_t stream = nullptr;
+  explicit StreamFence(hipStream_t s) : stream(s) {}
+  StreamFence(const StreamFence &) = delete;
+  StreamFence &operator=(const StreamFence &) = delete;
+  ~StreamFence() {
+    if (stream) (void)hipStreamSynchronize(stream);
+  }
+};
+
+// Releases what the library keeps alive between calls (idle pool blocks, pooled streams) after
+// waiting for the device; see asp_shutdown in asp.h.
+int shutdown_pools();
 
 // Compute units and opt-in LDS bytes per workgroup of the current device (queried once).
 int device_limits(int *num_cus, size_t *max_lds);

@@ -105,6 +105,7 @@ extern "C" int asp_ising_elements(uint64_t num_spins, uint64_t const *keys, doub
   DeviceBuffer<double> d_psi, d_coeffs, d_elements;
   DeviceBuffer<int64_t> d_counts, d_offsets, d_scratch, d_index;
   DeviceBuffer<uint8_t> d_member;
+  asp::StreamFence fence(stream);  // error exits wait for the stream before the buffers go
   ASP_TRY(d_keys.alloc(K));
   ASP_TRY(d_other.alloc(N));
   ASP_TRY(d_psi.alloc(K));

@@ -479,6 +479,7 @@ int asp_operator_apply(asp_operator const *op, uint64_t n, uint64_t const *keys,
   hipStream_t stream = scoped.stream;
   Timer timer;
   ApplyBatch w;
+  asp::StreamFence fence_w(stream);  // (and the later buffers have a fence of their own)
   ASP_TRY(timer.start(stream));
   ASP_TRY(count_connections(op, n, keys, &w, stream));
   if (total) *total = w.total;
@@ -491,6 +492,7 @@ int asp_operator_apply(asp_operator const *op, uint64_t n, uint64_t const *keys,
   }
   DeviceBuffer<uint64_t> d_other;
   DeviceBuffer<double> d_coeffs;
+  asp::StreamFence fence(stream);  // error exits wait for the stream before the buffers go
   ASP_TRY(d_other.alloc(w.total));
   ASP_TRY(d_coeffs.alloc(w.total));
   if (n > 0) {
@@ -538,6 +540,7 @@ int asp_operator_ising(asp_operator const *op, uint64_t num_spins, uint64_t cons
   DeviceBuffer<uint32_t> d_row_nnz;
   DeviceBuffer<int64_t> d_row_start, d_scratch;
   DeviceBuffer<int32_t> d_row, d_col;
+  asp::StreamFence fence(stream);  // error exits wait for the stream before the buffers go
   ASP_TRY(d_keys.alloc(K));
   ASP_TRY(d_psi.alloc(K));
   ASP_TRY(d_slots.alloc(slots_n));
@@ -624,6 +627,7 @@ int asp_operator_extend(asp_operator const *op, uint64_t n, uint64_t const *keys
   hipStream_t stream = scoped.stream;
   Timer timer;
   ApplyBatch w;
+  asp::StreamFence fence_w(stream);  // (and the later buffers have a fence of their own)
   ASP_TRY(timer.start(stream));
   ASP_TRY(count_connections(op, n, keys, &w, stream));
   const uint64_t N = w.total;
@@ -632,6 +636,8 @@ int asp_operator_extend(asp_operator const *op, uint64_t n, uint64_t const *keys
   DeviceBuffer<double> d_coeffs;  // written by k_apply<true>, not used here
   DeviceBuffer<uint32_t> d_flag;
   DeviceBuffer<int64_t> d_pos, d_scratch;
+  DeviceBuffer<uint8_t> d_temp;
+  asp::StreamFence fence(stream);  // error exits wait for the stream before the buffers go
   ASP_TRY(d_targets.alloc(N));
   ASP_TRY(d_sorted.alloc(N));
   ASP_TRY(d_coeffs.alloc(N));
@@ -645,7 +651,6 @@ int asp_operator_extend(asp_operator const *op, uint64_t n, uint64_t const *keys
   size_t temp_bytes = 0;
   ASP_HIP_TRY(rocprim::radix_sort_keys(nullptr, temp_bytes, d_targets.ptr, d_sorted.ptr, N, 0,
                                        op->number_spins, stream));
-  DeviceBuffer<uint8_t> d_temp;
   ASP_TRY(d_temp.alloc(temp_bytes ? temp_bytes : 1));
   ASP_HIP_TRY(rocprim::radix_sort_keys(d_temp.ptr, temp_bytes, d_targets.ptr, d_sorted.ptr, N, 0,
                                        op->number_spins, stream));

@@ -1324,6 +1324,7 @@ struct asp_sa_plan {
   }
   int team_mode = -1;  // asp_sa_set_team: -1 auto, 0 off, G >= 2 forced
   bool use_field_cache = true;
+  uint32_t team_abort_host = 0;  // landing place of the watchdog flag's asynchronous read-back
 };
 
 namespace {
@@ -1609,7 +1610,9 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
       widest = std::max(widest, L.color_block_start[c + 1] - L.color_block_start[c]);
     }
     const size_t team_lds = team_lds_bytes(L);
-    const bool possible = !out_trace && !global && p->force_packed == 0 &&
+    // (one colour class only — a diagonal or field-only J —: the single barrier per sweep would
+    // not separate a fast member's next publication from a slow member's read of this one)
+    const bool possible = !out_trace && !global && p->force_packed == 0 && L.num_colors >= 2 &&
                           p->force_m == 0 && team_lds <= p->max_lds &&
                           static_cast<uint64_t>(repetitions) * 2 <= static_cast<uint64_t>(p->num_cus);
     if (possible && p->team_mode >= 2) {
@@ -1633,6 +1636,9 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
   const uint32_t groups = (repetitions + m - 1) / m;
   const uint64_t padded = static_cast<uint64_t>(groups) * m;
   hipStream_t s = p->stream;
+  // every exit below, error or not, first waits for what was queued on the stream: copies into
+  // the caller's buffers and kernels using the plan's work buffers never outlive the call
+  asp::StreamFence fence(s);
   if (global) ASP_TRY(p->w_spins.ensure(static_cast<uint64_t>(groups) * L.num_blocks));
 
   DeviceBuffer<double> &d_betas = p->w_betas, &d_partial = p->w_partial, &d_e = p->w_e;
@@ -1701,7 +1707,7 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
     }
   }
 
-  uint32_t team_abort = 0;
+  p->team_abort_host = 0;
   // Two cooperative kernels resident at the same time could each hold CUs the other is waiting
   // for: team launches of one process take turns (from launch to completion).
   static std::mutex team_launches;
@@ -1762,7 +1768,8 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
                         out_e, out_trace);
     }
     ASP_HIP_TRY(hipEventRecord(p->ev[2], s));
-    ASP_HIP_TRY(hipMemcpyAsync(&team_abort, ta.abort, sizeof team_abort, hipMemcpyDeviceToHost, s));
+    ASP_HIP_TRY(hipMemcpyAsync(&p->team_abort_host, ta.abort, sizeof p->team_abort_host,
+                               hipMemcpyDeviceToHost, s));
   } else {
     SweepKernel kernel = sweep_kernel_for(m, descent, layout);
     if (lds > 64 * 1024) {
@@ -1801,9 +1808,15 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
                                hipMemcpyDeviceToHost, s));
   }
   ASP_HIP_TRY(hipStreamSynchronize(s));
-  if (team_abort != 0) {
-    return asp::set_error(ASP_ERR_HIP, "team barrier timed out (workgroups of a team were not "
-                                       "making progress together); results discarded");
+  if (p->team_abort_host != 0) {
+    // The members of a team were not resident together (another process or a long kernel holding
+    // compute units — the launch mutex only orders this process's team launches): the partial
+    // results are discarded and the call is repeated with one workgroup per chain, the fallback
+    // of a refused cooperative launch.  Teams stay off for this plan.
+    if (team_turn.owns_lock()) team_turn.unlock();
+    p->team_mode = 0;
+    return run_chains(p, seed, betas, num_sweeps, repetitions, replica_offset, x0, descent, out_x,
+                      out_e, out_trace);
   }
   p->last_m = m;
   p->last_layout = team >= 2 ? 4 : layout;

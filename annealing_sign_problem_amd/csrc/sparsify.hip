@@ -246,6 +246,7 @@ extern "C" int asp_sparsify_component(uint64_t num_spins, int64_t const *indptr,
   DeviceBuffer<uint8_t> d_frozen;
   DeviceBuffer<uint32_t> d_parent, d_root, d_keep, d_row_kept, d_stray;
   DeviceBuffer<unsigned long long> d_max;
+  asp::StreamFence fence(stream);  // error exits wait for the stream before the buffers go
   ASP_TRY(d_indptr.alloc(K + 1));
   ASP_TRY(d_indices.alloc(nnz));
   ASP_TRY(d_data.alloc(nnz));

@@ -30,6 +30,63 @@ def _dist():
     return dist
 
 
+def init_from_env(backend: Optional[str] = None) -> bool:
+    """One process per GPU under ``python -m torch.distributed.run``: when RANK / WORLD_SIZE are
+    in the environment and no process group exists yet, bind this process to GPU LOCAL_RANK —
+    for torch (RCCL follows ``torch.cuda.current_device()``) AND for libasp_hip
+    (``asp_set_device``; the library otherwise computes on HIP device 0 in every rank) — and
+    create the process group, before any other GPU call.  Returns True when a group was created.
+
+    ``backend`` defaults to ``$ASP_DIST_BACKEND``, else ``nccl`` (= RCCL) when GPUs are visible
+    and ``gloo`` otherwise.  ``ASP_SINGLE_DEVICE=1`` puts every rank on device 0 (rehearsal on a
+    one-GPU box; only meaningful with gloo)."""
+    import os
+
+    if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
+        return False
+    import torch
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        return False
+    from . import _lib
+
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("ASP_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    gpus = _lib.device_count()
+    backend = backend or os.environ.get("ASP_DIST_BACKEND") or ("nccl" if gpus > 0 else "gloo")
+    if gpus > 0:
+        if local_rank >= gpus:
+            raise _lib.AspError(-1, "LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, gpus))
+        torch.cuda.set_device(local_rank)
+        _lib.check(_lib.load().asp_set_device(local_rank))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend)
+    return True
+
+
+def check_device_binding(group=None) -> None:
+    """With RCCL the gathered tensors live on ``torch.cuda.current_device()``; the chains must
+    have run on the same GPU, and no two ranks of a node may share one (RCCL refuses duplicate
+    devices).  Raises when libasp_hip is bound elsewhere — the mistake :func:`init_from_env`
+    exists to prevent."""
+    import torch
+    import torch.distributed as dist
+
+    if dist.get_backend(group) != "nccl":
+        return
+    from . import _lib
+
+    mine = int(_lib.load().asp_get_device())
+    theirs = int(torch.cuda.current_device())
+    if mine != theirs:
+        raise _lib.AspError(-3, "libasp_hip computes on device %d but torch.distributed/RCCL uses "
+                                "device %d: call distributed.init_from_env() (or asp_set_device and "
+                                "torch.cuda.set_device with LOCAL_RANK) before the first GPU call"
+                                % (mine, theirs))
+
+
 def world_size() -> int:
     d = _dist()
     return d.get_world_size() if d is not None else 1
@@ -38,6 +95,16 @@ def world_size() -> int:
 def rank() -> int:
     d = _dist()
     return d.get_rank() if d is not None else 0
+
+
+def broadcast_object(value, src: int = 0, group=None):
+    """``value`` of rank ``src`` on every rank (picklable control data; single process: as is)."""
+    d = _dist()
+    if d is None or d.get_world_size(group) == 1:
+        return value
+    box = [value]
+    d.broadcast_object_list(box, src=src, group=group)
+    return box[0]
 
 
 def shard_range(total: int, world: int, index: int) -> Tuple[int, int]:
@@ -74,6 +141,7 @@ def anneal_sharded(hamiltonian, seed: int, betas: np.ndarray, repetitions: int, 
 
     import torch.distributed as dist
 
+    check_device_binding(group)
     world = dist.get_world_size(group)
     me = dist.get_rank(group)
     offset, count = shard_range(repetitions, world, me)
@@ -131,6 +199,7 @@ def anneal_sharded_best(hamiltonian, seed: int, betas: np.ndarray, repetitions: 
 
     from .annealer import anneal_raw
 
+    check_device_binding(group)
     world = dist.get_world_size(group)
     me = dist.get_rank(group)
     offset, count = shard_range(repetitions, world, me)

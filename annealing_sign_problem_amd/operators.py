@@ -237,12 +237,17 @@ class DeviceOperator:
         self.number_spins = int(number_spins)
         self.unique_targets = bool(self._lib.asp_operator_unique_targets(handle))
         self.max_connections = int(self._lib.asp_operator_max_connections(handle))
+        _lib.track(self)
 
-    def __del__(self):
+    def release(self) -> None:
         handle, self._handle = getattr(self, "_handle", None), None
         if handle:
+            self._lib.asp_operator_destroy(handle)
+
+    def __del__(self):
+        if getattr(self, "_handle", None) and not self._lib_module.closed():
             try:
-                self._lib.asp_operator_destroy(handle)
+                self.release()
             except Exception:
                 pass
 

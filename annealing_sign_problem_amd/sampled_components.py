@@ -188,9 +188,14 @@ def main(argv=None):
     from . import distributed as asp_dist
 
     args = parse_command_line(argv)
+    # under `python -m torch.distributed.run -m ...sampled_components`: bind this rank's GPU for
+    # torch and for libasp_hip and join the process group before anything touches a device
+    created_group = asp_dist.init_from_env()
     np.random.seed(args.seed)
     writer = asp_dist.rank() == 0  # under torch.distributed only rank 0 touches the file
-    if writer and os.path.exists(args.output):
+    # rank 0 looks at the file and tells the others, so that all ranks stop together
+    refuse = asp_dist.broadcast_object(writer and os.path.exists(args.output))
+    if refuse:
         raise SystemExit("Output file '{}' already exists: refusing to overwrite".format(args.output))
     models = synthetic.load_models()
     hamiltonian = operators.Operator.from_config(models[args.model])
@@ -227,6 +232,11 @@ def main(argv=None):
             with open(args.output, "a") as f:
                 for line in lines:
                     f.write(line + "\n")
+        if created_group:
+            import torch.distributed as dist
+
+            dist.barrier()
+            dist.destroy_process_group()
         return
     # With --jobs > 1 several clusters are in flight on one GPU at once — the C calls release
     # the GIL and every Hamiltonian owns its stream.  All randomness was consumed above, so the

@@ -44,6 +44,16 @@ int asp_device_count(void);
 /* Select the device used by this library in the whole process (every entry point binds
  * its calling thread to it). */
 int asp_set_device(int device);
+/* The device this library computes on: the asp_set_device choice, else HIP's current device
+ * of the calling thread; negative asp_status on failure. */
+int asp_get_device(void);
+/* Waits for the device(s) and releases what the library keeps alive BETWEEN calls: pooled
+ * device memory and pooled streams.  Meant to be called once, after every handle (plans,
+ * operators, builds) has been destroyed and before the process starts to exit, so that no HIP
+ * call is left to static destructors or interpreter teardown, where the runtime or a profiler
+ * attached to it may already be gone (the Python binding registers it with atexit and
+ * destroys its live handles first).  The library stays usable afterwards, without pooling. */
+int asp_shutdown(void);
 /* Library version, "major.minor.patch". */
 const char *asp_version(void);
 

@@ -134,3 +134,50 @@ def test_cluster_instances_shard_over_ranks(tmp_path):
         xs, es, _, _ = oracle.sa_anneal(J, h, 7 + k, betas, 3, 0, None, 40)
         best = int(np.argmin(es))
         assert e == es[best] and xbytes == xs[best].tobytes()
+
+
+def _main_worker(rank, world, port, out_path, expect_refusal):
+    """sampled_components.main() as `python -m torch.distributed.run` would start it: nothing
+    but RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* in the environment.  The device stages are
+    replaced by a deterministic stand-in (no GPU here); what is under test is the rank
+    discovery, the single writer and the gathered output."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from annealing_sign_problem_amd import distributed, sampled_components as sc
+
+    def fake_clusters(hamiltonian, ground_state, number_samples, *args):
+        states = hamiltonian.basis.states
+        return [states[7 * c: 7 * c + 5 + c].copy() for c in range(number_samples)]
+
+    def fake_process(cluster, hamiltonian, ground_state, noisy, fn, order, cutoff, annealing):
+        assert not distributed.shards_chains()  # inside a sharded item chains stay on the rank
+        return [sc.OptimizationResult(int(cluster.size) + i, float(cluster[0] % 97) / 97.0, 0.5, 0.25,
+                                      0.125, float(distributed.world_size())) for i in range(order + 1)]
+
+    sc.generate_clusters = fake_clusters
+    sc.process_cluster = fake_process
+    argv = ["--model", "heisenberg_kagome_16", "--output", out_path, "--order", "1",
+            "--number-samples", "5", "--seed", "3"]
+    if expect_refusal:
+        with pytest.raises(SystemExit):
+            sc.main(argv)
+        return
+    sc.main(argv)
+    assert distributed.world_size() == 1  # main() tore its own group down
+
+
+def test_pipeline_main_initialises_ranks_from_env(tmp_path):
+    """under torch.distributed.run every rank used to see world_size 1 and raced on
+    the output file.  Two ranks, env-var rendezvous: one header, each cluster's line once, in
+    cluster order; a second launch onto the same file stops on EVERY rank."""
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "clusters.csv")
+    mp.spawn(_main_worker, args=(2, _free_port(), out, False), nprocs=2, join=True)
+    lines = [l for l in open(out).read().splitlines() if not l.startswith("#")]
+    assert len(lines) == 5
+    sizes = [int(l.split(",")[0]) for l in lines]
+    assert sizes == [5 + c for c in range(5)]
+    assert all(l.split(",")[5] == "2.00000000e+00" for l in lines)  # computed under world size 2
+    mp.spawn(_main_worker, args=(2, _free_port(), out, True), nprocs=2, join=True)

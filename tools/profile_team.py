@@ -18,3 +18,5 @@ for team in (-1, 0):
     x, e = sa.anneal(ham, seed=12345, number_sweeps=5120, repetitions=64)
     print("team=%2d: %.3f s wall, sweep kernel %.1f ms, E = %.12g" % (
         team, time.time() - t0, lib.asp_sa_last_sweep_ms(ham.plan()), e), flush=True)
+ham.release()  # handles are destroyed before the interpreter (and the profiler) wind down
+_lib.shutdown()
