@@ -1,0 +1,108 @@
+"""GPU parity at BASELINE.json's configurations 1 and 2 — the full 16-site Hilbert spaces
+(K = C(16,8) = 12 870) the reference's `make small` anneals (Makefile:27-35):
+
+  config 1  j1j2_square_4x4 (physical_systems/j1j2_square_4x4.yaml:18-41, incl. the (3,3) = 1
+            entry of the J2 matrix): coupling build, energy identity, 1 and few replicas
+  config 2  heisenberg_kagome_16: 256 replicas, fixed seed, chains vs the oracle
+
+Each test goes model YAML -> exact ground state -> make_ising_model (GPU) -> sa.anneal (GPU)
+through the package's reference-named entry points and compares with the CPU oracle bit for
+bit."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import reference_route_ising
+
+pytestmark = pytest.mark.gpu
+
+_cache = {}
+
+
+def _full_space(models, name):
+    """(operator, ground state, exact IsingModel) of the whole basis."""
+    from annealing_sign_problem_amd import common, operators
+
+    if name not in _cache:
+        op = operators.Operator.from_config(models[name])
+        op.basis.build()
+        energy, psi = op.ground_state()
+        fn = common.ground_state_to_log_coeff_fn(psi, op.basis)
+        model = common.make_ising_model(op.basis.states, op, log_psi_fn=fn)
+        _cache[name] = (op, energy, psi, model)
+    return _cache[name]
+
+
+@pytest.mark.parametrize("name", ["j1j2_square_4x4", "heisenberg_kagome_16"])
+def test_full_space_coupling_build_and_energy_identity(models, name):
+    """J of the WHOLE basis equals the reference route (common.py:71-82,116-128,190-196 in
+    numpy/scipy) bit for bit, and E(sign psi) = <psi|H|psi> to 1e-12 (common.py:757-760,
+    experiments/full_hilbert_space.py:142-145)."""
+    import scipy.sparse
+
+    op, energy, psi, model = _full_space(models, name)
+    assert model.size == 12870
+    if name == "j1j2_square_4x4":
+        j2 = np.asarray(models[name]["hamiltonian"]["terms"][1]["matrix"], dtype=float)
+        assert j2[3, 3] == 1.0 and j2[0, 0] == 0.55  # the YAML's quirk is part of the config
+    amp = psi / np.linalg.norm(psi)
+    want = reference_route_ising(op, op.basis.states, amp)
+    got = scipy.sparse.coo_matrix(model.ising_hamiltonian.exchange)
+    assert np.array_equal(got.row, want.row) and np.array_equal(got.col, want.col)
+    assert got.data.tobytes() == want.data.tobytes()
+    h = model.ising_hamiltonian
+    rayleigh = float(amp @ (op.to_sparse().real @ amp))
+    e_signs = h.energy(model.initial_signs)
+    assert abs(e_signs - rayleigh) <= 1e-12 * abs(rayleigh)
+    assert abs(e_signs - energy) <= 1e-9 * abs(energy)  # eigensolver tolerance
+    e_oracle = oracle.sa_energy(h.exchange, h.field, model.initial_signs)[0]
+    assert abs(e_signs - e_oracle) <= 1e-12 * abs(e_signs)
+
+
+def _chains_vs_oracle(h, seed, sweeps, reps, threads):
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    info = h.info()
+    betas = sa.make_schedule(info.beta0_auto, info.beta1_auto, sweeps)
+    xs, es = sa.anneal_raw(h, seed, betas, reps)
+    tracked = np.zeros(reps, np.int64)
+    accepted = np.zeros(reps, np.uint64)
+    _lib.check(_lib.load().asp_sa_last_stats(h.plan(), reps, _lib.ptr(tracked), _lib.ptr(accepted)))
+    oxs, oes, otracked, oaccepted = oracle.sa_anneal(h.exchange, h.field, seed, betas, reps, 0, None,
+                                                    info.energy_scale_exp, num_threads=threads)
+    assert np.array_equal(accepted, oaccepted) and np.array_equal(tracked, otracked)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    return xs, es
+
+
+def test_config1_j1j2_full_space_one_and_few_replicas(models):
+    """BASELINE config 1: `make small` on j1j2_square_4x4, seed 435834 (Makefile:14): one
+    replica (the CPU reference path's shape) and a few, automatic beta ladder."""
+    _, _, _, model = _full_space(models, "j1j2_square_4x4")
+    h = model.ising_hamiltonian
+    xs, es = _chains_vs_oracle(h, 435834, 400, 1, 1)
+    assert es[0] <= 0.5 * h.energy(model.initial_signs)  # (negative) well on the way to E0
+    _chains_vs_oracle(h, 435834, 150, 5, 5)
+    # the public entry point with only_best: the first minimum of the chains
+    from annealing_sign_problem_amd import annealer as sa
+
+    x, e = sa.anneal(h, seed=435834, number_sweeps=150, repetitions=5)
+    xs5, es5 = sa.anneal(h, seed=435834, number_sweeps=150, repetitions=5, only_best=False)
+    k = int(np.argmin(es5))
+    assert np.array_equal(x, xs5[k]) and e == es5[k]
+
+
+def test_config2_kagome16_full_space_256_replicas(models):
+    """BASELINE config 2: heisenberg_kagome_16 full space, 256 replicas on one GPU, fixed seed,
+    every chain's signs and energy equal to the oracle's."""
+    from annealing_sign_problem_amd import common
+
+    _, _, _, model = _full_space(models, "heisenberg_kagome_16")
+    xs, es = _chains_vs_oracle(model.ising_hamiltonian, 435834, 60, 256, 16)
+    # the chains are 256 different Markov chains, and the sign metric works on them
+    assert np.unique(xs, axis=0).shape[0] == 256
+    weights = np.ones(model.size) / model.size
+    acc, overlap = common.compute_accuracy_and_overlap(xs[int(np.argmin(es))], model.initial_signs,
+                                                       weights)
+    assert 0.5 <= acc <= 1.0 and 0.0 <= overlap <= 1.0

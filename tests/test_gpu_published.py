@@ -1,0 +1,56 @@
+"""The only pin of the annealer the reference holds: its PUBLISHED success probabilities on the
+full 16-site Hilbert spaces (experiments/*.csv, `make small`, Makefile:27-35: 1024 repetitions
+x 10 trials per number of sweeps).  The annealer library itself (ising_glass_annealer) is
+absent, so bit parity is out of reach; this test turns the statistical comparison
+into an assertion that goes red when the schedule, the random-number use or the acceptance rule
+drift.
+
+For each point (model, number of sweeps) it repeats the experiment with 8 x 1024 chains, fixed
+seeds, and requires P(accuracy > 0.995)
+  * within [published - 0.03, published + 0.07]: specification ASP-SA-1 is a different Markov
+    chain from the library's — it reaches the exact sign structure as often or MORE often (round 1:
+    up to +0.045 on these models at these sweep counts, up to 10 standard errors, DESIGN.md
+    §6.1) — so the band is one-sided wide;
+  * within +-0.03 of this repository's own round-1 measurement (10 x 1024 chains; 4 standard
+    errors of the difference are 0.03), the regression pin proper;
+and, as in every row of the published CSVs, P(residual <= 1e-12) == P(accuracy > 0.995).
+Numbers: tests/golden/published_sa_curves.json (+ generate_published_curves.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+POINTS = [("heisenberg_kagome_16", 100), ("heisenberg_kagome_16", 1600),
+          ("heisenberg_kagome_16", 25600), ("sk_16_1", 100), ("sk_16_1", 1600), ("sk_16_1", 25600)]
+TRIALS = 8
+_sims = {}
+
+
+def _simulation(name):
+    from annealing_sign_problem_amd import full_hilbert_space
+
+    if name not in _sims:
+        _sims[name] = full_hilbert_space.Simulation(name)
+    return _sims[name]
+
+
+@pytest.mark.parametrize("name,sweeps", POINTS)
+def test_success_probability_matches_published_curve(name, sweeps):
+    with open(os.path.join(GOLDEN, "published_sa_curves.json")) as f:
+        row = json.load(f)["models"][name][str(sweeps)]
+    sim = _simulation(name)
+    results = np.array([sim.run(sweeps, 1024, seed=435834 + 1000003 * trial + sweeps)
+                        for trial in range(TRIALS)])
+    acc, residual = results[:, 0].mean(), results[:, 2].mean()
+    assert residual == acc, "P(residual <= 1e-12) and P(accuracy > 0.995) differ"
+    published, own = row["acc_prob_mean"], row["mi355x_r01_acc_prob_mean"]
+    assert published - 0.03 <= acc <= published + 0.07, \
+        "%s @ %d sweeps: %.4f vs published %.4f (%s)" % (name, sweeps, acc, published,
+                                                        row["reference_line"])
+    assert abs(acc - own) <= 0.03, \
+        "%s @ %d sweeps: %.4f vs this repository's round-1 %.4f" % (name, sweeps, acc, own)
