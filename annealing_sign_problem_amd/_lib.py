@@ -51,6 +51,22 @@ class SaInfo(ctypes.Structure):
     ]
 
 
+class SaBatchItem(ctypes.Structure):
+    """Mirror of ``asp_sa_batch_item`` (include/asp.h)."""
+
+    _fields_ = [
+        ("plan", c_void_p),
+        ("seed", c_u64),
+        ("betas", c_void_p),
+        ("num_sweeps", c_u32),
+        ("repetitions", c_u32),
+        ("replica_offset", c_u32),
+        ("reserved", c_u32),
+        ("out_x", c_void_p),
+        ("out_e", c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/asp.h declares
 SIGNATURES = {
     "asp_last_error": (ctypes.c_char_p, []),
@@ -102,6 +118,8 @@ SIGNATURES = {
                               c_void_p]),
     "asp_sa_anneal_trace": (c_int, [c_void_p, c_u64, c_void_p, c_u32, c_u32, c_u32, c_void_p,
                                     c_void_p, c_void_p, c_void_p]),
+    "asp_sa_anneal_batch": (c_int, [ctypes.POINTER(SaBatchItem), c_u32]),
+    "asp_sa_batch_last_ms": (c_float, []),
     "asp_sa_greedy": (c_int, [c_void_p, c_u32, c_void_p, c_void_p, ctypes.POINTER(c_u32)]),
     "asp_sa_greedy_tree_host": (c_int, [c_u64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "asp_sa_last_sweep_ms": (c_float, [c_void_p]),

@@ -33,6 +33,7 @@ from . import _lib
 __all__ = [
     "Hamiltonian",
     "anneal",
+    "anneal_batch",
     "greedy_solve",
     "signs_to_bits",
     "bits_to_signs",
@@ -237,6 +238,79 @@ def anneal(hamiltonian: Hamiltonian, x0=None, seed=None, number_sweeps: int = 51
         best = int(np.argmin(es))  # first minimum: deterministic tie-break
         return xs[best].copy(), float(es[best])
     return xs, es
+
+
+def anneal_batch_raw(hamiltonians, seeds, schedules, repetitions, replica_offsets=None):
+    """Many independent problems in ONE device call (``asp_sa_anneal_batch``): problem ``i`` is
+    ``anneal_raw(hamiltonians[i], seeds[i], schedules[i], repetitions[i], replica_offsets[i])``,
+    chain for chain, but the groups of all problems share a few launches, so a batch of small
+    clusters fills the chip.  Returns ``[(xs, es), ...]`` in order."""
+    lib = _lib.load()
+    n = len(hamiltonians)
+    repetitions = [int(r) for r in (repetitions if np.ndim(repetitions) else [repetitions] * n)]
+    offsets = [0] * n if replica_offsets is None else [int(o) for o in replica_offsets]
+    if not (len(seeds) == len(schedules) == len(repetitions) == len(offsets) == n):
+        raise ValueError("anneal_batch_raw: argument lengths differ")
+    if len({id(h) for h in hamiltonians}) != n:
+        raise ValueError("anneal_batch_raw: every problem needs its own Hamiltonian object")
+    items = (_lib.SaBatchItem * max(n, 1))()
+    keep, out = [], []
+    for i, h in enumerate(hamiltonians):
+        words = (h.size + 63) // 64
+        betas = np.ascontiguousarray(schedules[i], dtype=np.float64)
+        xs = np.zeros((repetitions[i], max(words, 1)), dtype=np.uint64)
+        es = np.zeros(repetitions[i], dtype=np.float64)
+        keep.append(betas)
+        out.append((xs, es, words))
+        items[i].plan = h.plan()
+        items[i].seed = int(seeds[i]) & (2**64 - 1)
+        items[i].betas = betas.ctypes.data
+        items[i].num_sweeps = betas.shape[0]
+        items[i].repetitions = repetitions[i]
+        items[i].replica_offset = offsets[i]
+        items[i].reserved = 0
+        items[i].out_x = xs.ctypes.data
+        items[i].out_e = es.ctypes.data
+    _lib.check(lib.asp_sa_anneal_batch(items, ctypes.c_uint32(n)))
+    return [(xs[:, :words], es) for xs, es, words in out]
+
+
+def anneal_batch(hamiltonians, seed=None, number_sweeps: int = 5120, repetitions: int = 64,
+                 only_best: bool = True, beta0: Optional[float] = None,
+                 beta1: Optional[float] = None):
+    """``[anneal(h, seed=seed, number_sweeps=..., repetitions=..., only_best=...) for h in
+    hamiltonians]`` in one device call — identical results (each problem keeps its own automatic
+    ladder and the same chains), a fraction of the time for many small problems.  ``seed`` may be
+    one value for all problems (what the reference's per-cluster loop passes, common.py:236) or
+    a sequence.  Chains stay on this rank (cluster instances are what shards over ranks)."""
+    hamiltonians = list(hamiltonians)
+    n = len(hamiltonians)
+    for h in hamiltonians:
+        if not isinstance(h, Hamiltonian):
+            raise TypeError("'hamiltonians' must hold Hamiltonian objects")
+    repetitions = int(repetitions)
+    if repetitions < 1:
+        raise ValueError("'repetitions' must be positive")
+    if seed is None or np.ndim(seed) == 0:
+        seeds = [_resolve_seed(seed) for _ in range(n)] if seed is None else [_resolve_seed(seed)] * n
+    else:
+        seeds = [_resolve_seed(x) for x in seed]
+    schedules = []
+    for h in hamiltonians:
+        b0, b1 = beta0, beta1
+        if b0 is None or b1 is None:
+            info = h.info()
+            b0 = info.beta0_auto if b0 is None else b0
+            b1 = info.beta1_auto if b1 is None else b1
+        schedules.append(make_schedule(float(b0), float(b1), number_sweeps))
+    results = anneal_batch_raw(hamiltonians, seeds, schedules, [repetitions] * n)
+    if not only_best:
+        return results
+    best = []
+    for xs, es in results:
+        k = int(np.argmin(es))  # first minimum, as anneal()
+        best.append((xs[k].copy(), float(es[k])))
+    return best
 
 
 def anneal_trace_raw(hamiltonian: Hamiltonian, seed: int, betas: np.ndarray, repetitions: int,

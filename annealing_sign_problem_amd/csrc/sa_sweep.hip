@@ -495,8 +495,10 @@ __device__ __forceinline__ void snapshot(const uint8_t *spins, const SweepArgs &
 
 // DESCENT = true: strict-descent sweeps (accept iff dE < 0, no random numbers), used by the
 // greedy solver's relaxation; the final configuration is snapshotted after every sweep.
+// The whole anneal of one group of M replicas by one workgroup; `group` = index of the group
+// inside its problem (k_sa_sweep: the workgroup id; k_sa_sweep_batch: looked up in a table).
 template <int M, bool DESCENT, int LAYOUT>
-__global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep(SweepArgs a) {
+__device__ __forceinline__ void sa_sweep_body(const SweepArgs &a, const uint32_t group) {
   constexpr bool GLOBAL = LAYOUT == kGlobal;
   constexpr bool PACKED = LAYOUT == kBits || GLOBAL;  // one bit per position
   constexpr bool WIDE = LAYOUT == kWide;
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep(SweepArgs a) {
   extern __shared__ __align__(16) uint8_t lds[];
   // kGlobal: this workgroup's bit words live in HBM, the LDS holds the bookkeeping only
   uint8_t *spins = GLOBAL ? reinterpret_cast<uint8_t *>(a.spin_words +
-                                                       static_cast<uint64_t>(blockIdx.x) * a.num_blocks)
+                                                       static_cast<uint64_t>(group) * a.num_blocks)
                           : lds;
   // bytes of the spin area per block: 64 (a byte per position), 8 (a bit) or 256 (a word)
   const uint32_t P = GLOBAL ? 0u : a.num_blocks * (PACKED ? 8u : (WIDE ? 256u : 64u));
@@ -539,7 +541,6 @@ __global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep(SweepArgs a) {
   const uint32_t lane = tid & 63u;
   const uint32_t wave = tid >> 6;
   const uint32_t waves = blockDim.x >> 6;
-  const uint32_t group = blockIdx.x;
   const uint32_t r0 = a.replica_first + group * M;
   const uint32_t key0 = static_cast<uint32_t>(a.seed);
   const uint32_t key1 = static_cast<uint32_t>(a.seed >> 32);
@@ -863,6 +864,37 @@ __global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep(SweepArgs a) {
   }
 }
 
+template <int M, bool DESCENT, int LAYOUT>
+__global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep(SweepArgs a) {
+  sa_sweep_body<M, DESCENT, LAYOUT>(a, blockIdx.x);
+}
+
+// Many PROBLEMS in one launch (asp_sa_anneal_batch): workgroup -> (problem, group of M replicas)
+// through a slot table, the problem's SweepArgs through a descriptor table in HBM (scalar
+// loads: the slot is workgroup-uniform).  Slots are laid out per XCD — workgroup i runs on XCD
+// i mod 8 — so that the groups of one problem share that XCD's L2 copy of its couplings, and in
+// descending order of work inside an XCD (longest first, the tail stays short).  Every chain is
+// bit-identical to the one its own single-problem launch produces: the body is the same and
+// results never depend on the launch geometry.
+struct BatchSlot {
+  uint32_t problem;  // 0xFFFFFFFF: padding slot
+  uint32_t group;
+};
+struct BatchArgs {
+  const SweepArgs *problems;
+  const BatchSlot *slots;  // [8][slots_per_xcd]
+  uint32_t slots_per_xcd;
+};
+
+template <int M, int LAYOUT>
+__global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep_batch(BatchArgs b) {
+  const BatchSlot slot = b.slots[(blockIdx.x & 7u) * b.slots_per_xcd + (blockIdx.x >> 3)];
+  const uint32_t problem = __builtin_amdgcn_readfirstlane(slot.problem);
+  if (problem == 0xFFFFFFFFu) return;
+  const SweepArgs a = b.problems[problem];
+  sa_sweep_body<M, false, LAYOUT>(a, __builtin_amdgcn_readfirstlane(slot.group));
+}
+
 // ---------------------------------------------------------------------------
 // Team sweep: ONE chain spread over G workgroups (few chains on a large cluster)
 // ---------------------------------------------------------------------------
@@ -871,9 +903,10 @@ __global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep(SweepArgs a) {
 // team each keep the whole configuration (bit-packed, LDS), visit every G-th slice of a colour's
 // blocks, publish the 64-bit flip word of each block they visited, meet at a device-scope
 // barrier and XOR the other members' flip words into their own copy.  Energy bookkeeping is
-// summed over the team through parity-buffered atomics.  Launched cooperatively (all workgroups
-// co-resident); the barrier carries a watchdog so that a bug cannot hang the GPU.  Chains are
-// bit-identical to k_sa_sweep's.
+// summed over the team through parity-buffered atomics.  All workgroups must be resident together
+// (the launcher keeps the grid within the CU count and serialises team launches); the barrier
+// carries a watchdog so that neither a bug nor a busy device can hang the GPU — on a timeout
+// the call is repeated without teams.  Chains are bit-identical to k_sa_sweep's.
 
 struct TeamArgs {
   SweepArgs s;
@@ -1183,9 +1216,8 @@ struct EnergyArgs {
 // STAGED: the configuration's sign words are copied to LDS first; otherwise (more blocks than the
 // LDS holds) they are gathered from HBM/L2 directly.
 template <bool STAGED>
-__global__ __launch_bounds__(512) void k_sa_energy_blocks(EnergyArgs a) {
+__device__ __forceinline__ void energy_blocks_body(const EnergyArgs &a, const uint32_t r) {
   extern __shared__ __align__(16) uint8_t lds[];
-  const uint32_t r = blockIdx.x;
   const uint64_t *mine = a.perm_words + static_cast<uint64_t>(r) * a.num_blocks;
   const uint64_t *bits = mine;
   if constexpr (STAGED) {
@@ -1221,10 +1253,14 @@ __global__ __launch_bounds__(512) void k_sa_energy_blocks(EnergyArgs a) {
   }
 }
 
+template <bool STAGED>
+__global__ __launch_bounds__(512) void k_sa_energy_blocks(EnergyArgs a) {
+  energy_blocks_body<STAGED>(a, blockIdx.x);
+}
+
 // One wavefront per configuration folds its block sums 64 at a time, in place.
-__global__ __launch_bounds__(64) void k_sa_energy_fold(double *partial, uint32_t num_blocks,
-                                                      double diag_sum, double *out_e) {
-  const uint32_t r = blockIdx.x;
+__device__ __forceinline__ void energy_fold_body(double *partial, uint32_t num_blocks,
+                                                 double diag_sum, double *out_e, const uint32_t r) {
   const uint32_t lane = threadIdx.x;
   double *level = partial + static_cast<uint64_t>(r) * num_blocks;
   uint32_t n = num_blocks;
@@ -1239,6 +1275,38 @@ __global__ __launch_bounds__(64) void k_sa_energy_fold(double *partial, uint32_t
     n = groups;
   }
   if (lane == 0) out_e[r] = __dadd_rn(diag_sum, num_blocks ? level[0] : 0.0);
+}
+
+__global__ __launch_bounds__(64) void k_sa_energy_fold(double *partial, uint32_t num_blocks,
+                                                      double diag_sum, double *out_e) {
+  energy_fold_body(partial, num_blocks, diag_sum, out_e, blockIdx.x);
+}
+
+// The same three steps for the chains of MANY problems in one launch each (asp_sa_anneal_batch):
+// workgroup -> (problem, chain) through a table, the problem's pointers through a descriptor.
+struct PostProblem {
+  EnergyArgs e;  // perm_words / partial: this problem's rows
+  const uint32_t *pos_of_spin;
+  uint64_t num_spins;
+  uint32_t words;
+  double diag_sum;
+  double *out_e;    // [repetitions]
+  uint64_t *out_x;  // [repetitions][words]
+};
+
+template <bool STAGED>
+__global__ __launch_bounds__(512) void k_sa_energy_blocks_batch(const PostProblem *problems,
+                                                               const BatchSlot *chains) {
+  const BatchSlot c = chains[blockIdx.x];
+  const EnergyArgs a = problems[__builtin_amdgcn_readfirstlane(c.problem)].e;
+  energy_blocks_body<STAGED>(a, __builtin_amdgcn_readfirstlane(c.group));
+}
+
+__global__ __launch_bounds__(64) void k_sa_energy_fold_batch(const PostProblem *problems,
+                                                            const BatchSlot *chains) {
+  const BatchSlot c = chains[blockIdx.x];
+  const PostProblem &pp = problems[c.problem];
+  energy_fold_body(pp.e.partial, pp.e.num_blocks, pp.diag_sum, pp.out_e, c.group);
 }
 
 // Packed original-order configurations (bit = +1) -> permuted sign-bit words.
@@ -1281,6 +1349,24 @@ __global__ __launch_bounds__(256) void k_unpermute_bits(const uint64_t *__restri
     word |= (neg ^ 1ull) << j;
   }
   x[idx] = word;
+}
+
+__global__ __launch_bounds__(256) void k_unpermute_bits_batch(const PostProblem *problems,
+                                                             const BatchSlot *chains) {
+  const BatchSlot c = chains[blockIdx.x];
+  const PostProblem &pp = problems[c.problem];
+  const uint64_t *perm = pp.e.perm_words + static_cast<uint64_t>(c.group) * pp.e.num_blocks;
+  for (uint32_t w = threadIdx.x; w < pp.words; w += blockDim.x) {
+    uint64_t word = 0;
+    for (uint32_t j = 0; j < 64; ++j) {
+      const uint64_t spin = static_cast<uint64_t>(w) * 64u + j;
+      if (spin >= pp.num_spins) break;
+      const uint32_t pos = pp.pos_of_spin[spin];
+      const uint64_t neg = (perm[pos >> 6] >> (pos & 63u)) & 1ull;
+      word |= (neg ^ 1ull) << j;
+    }
+    pp.out_x[static_cast<uint64_t>(c.group) * pp.words + w] = word;
+  }
 }
 
 }  // namespace
@@ -1708,8 +1794,8 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
   }
 
   p->team_abort_host = 0;
-  // Two cooperative kernels resident at the same time could each hold CUs the other is waiting
-  // for: team launches of one process take turns (from launch to completion).
+  // Two team kernels resident at the same time could each hold CUs the other is waiting for:
+  // team launches of one process take turns (from launch to completion).
   static std::mutex team_launches;
   std::unique_lock<std::mutex> team_turn(team_launches, std::defer_lock);
   if (team >= 2) {
@@ -1753,14 +1839,20 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
     }
     ASP_HIP_TRY(hipEventRecord(p->ev[0], s));
     ASP_HIP_TRY(hipEventRecord(p->ev[1], s));
-    void *kernel_args[] = {&ta};
-    // cooperative: every workgroup of every team must be resident, the barrier waits for them
-    const hipError_t launched = hipLaunchCooperativeKernel(
-        team_kernel, dim3(repetitions * team), dim3(threads), kernel_args,
-        static_cast<unsigned>(lds), s);
+    // An ORDINARY launch: team * repetitions <= CUs workgroups, each fitting a CU by itself,
+    // are all resident on an otherwise idle device, and the watchdog (with the rerun below)
+    // covers a device that is not idle.  hipLaunchCooperativeKernel would check the same
+    // occupancy bound, but a process that has used it once dies in the HIP runtime's exit
+    // handler when rocprofv3 is attached (tools/exit_probe.hip: a 40-line program does;
+    // profiles/r02_exit_probe.txt).
+    if (descent) {
+      hipLaunchKernelGGL(k_sa_sweep_team<true>, dim3(repetitions * team), dim3(threads), lds, s, ta);
+    } else {
+      hipLaunchKernelGGL(k_sa_sweep_team<false>, dim3(repetitions * team), dim3(threads), lds, s, ta);
+    }
+    const hipError_t launched = hipGetLastError();
     if (launched != hipSuccess) {
-      // no cooperative launch on this device/configuration: one workgroup per chain instead
-      (void)hipGetLastError();
+      // the configuration cannot be launched: one workgroup per chain instead
       ASP_HIP_TRY(hipStreamSynchronize(s));
       team_turn.unlock();
       p->team_mode = 0;
@@ -1812,7 +1904,7 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
     // The members of a team were not resident together (another process or a long kernel holding
     // compute units — the launch mutex only orders this process's team launches): the partial
     // results are discarded and the call is repeated with one workgroup per chain, the fallback
-    // of a refused cooperative launch.  Teams stay off for this plan.
+    // of a refused launch.  Teams stay off for this plan.
     if (team_turn.owns_lock()) team_turn.unlock();
     p->team_mode = 0;
     return run_chains(p, seed, betas, num_sweeps, repetitions, replica_offset, x0, descent, out_x,
@@ -1935,6 +2027,395 @@ int asp_sa_energy(asp_sa_plan *p, uint32_t count, uint64_t const *x, double *out
   ASP_TRY(energies_of_perm(p, d_perm.ptr, count, d_partial.ptr, d_e.ptr));
   ASP_TRY(d_e.download(out_e, count, s));
   ASP_HIP_TRY(hipStreamSynchronize(s));
+  return ASP_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Batched anneal: many problems, one launch per size class
+// ---------------------------------------------------------------------------
+// The reference's production job is 50 000 sampled clusters of 50-1000 states, extended twice,
+// each solved with 64 chains x 5120 sweeps (Makefile:9,115-127,
+// experiments/sampled_connected_components.py:764-767, common.py:236-239).  One such problem
+// is 64 workgroups of one or two wavefronts that wait on L2 latency at every colour step: a
+// launch per problem leaves > 90 % of the chip idle.  Here the groups of ALL problems of a batch
+// are the workgroups of a few launches (one per wavefront count), so the chip holds hundreds
+// of problems at once and the latency of one hides behind the others.
+
+namespace {
+
+thread_local float g_batch_sweep_ms = 0.0f;
+
+uint32_t widest_color(const asp::SaHostLayout &L) {
+  uint32_t widest = 1;
+  for (uint32_t c = 0; c < L.num_colors; ++c) {
+    widest = std::max(widest, L.color_block_start[c + 1] - L.color_block_start[c]);
+  }
+  return widest;
+}
+
+struct BatchEntry {
+  uint32_t item;     // index into the caller's array
+  uint32_t waves;    // wavefronts per workgroup this problem wants
+  double work;       // ~ time of one group: sweeps * ELL slabs
+  uint64_t beta_at;  // offset of its ladder in the concatenated betas
+};
+
+}  // namespace
+
+extern "C" {
+
+float asp_sa_batch_last_ms(void) { return g_batch_sweep_ms; }
+
+int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
+  asp_clear_error();
+  g_batch_sweep_ms = 0.0f;
+  if (count == 0) return ASP_OK;
+  if (!items) return asp::set_error(ASP_ERR_INVALID, "null items");
+  ASP_TRY(asp::bind_device());
+  // ---- validation (the checks of asp_sa_anneal, for every item before anything runs) ----
+  for (uint32_t i = 0; i < count; ++i) {
+    const asp_sa_batch_item &it = items[i];
+    if (!it.plan) return asp::set_error(ASP_ERR_INVALID, "item %u: null plan", i);
+    if (it.repetitions == 0) continue;
+    if (!it.out_x || !it.out_e || (it.num_sweeps && !it.betas)) {
+      return asp::set_error(ASP_ERR_INVALID, "item %u: null argument", i);
+    }
+    if (it.num_sweeps == 0xFFFFFFFFu) {
+      return asp::set_error(ASP_ERR_INVALID, "item %u: num_sweeps 2^32-1 is reserved", i);
+    }
+    if (static_cast<uint64_t>(it.replica_offset) + it.repetitions + 8 > 0xFFFFFFFFull) {
+      return asp::set_error(ASP_ERR_INVALID, "item %u: replica ids exceed 32 bits", i);
+    }
+    for (uint32_t t = 0; t < it.num_sweeps; ++t) {
+      if (!(it.betas[t] >= 0.0)) {
+        return asp::set_error(ASP_ERR_INVALID, "item %u: betas[%u] is not >= 0", i, t);
+      }
+    }
+    for (uint32_t j = 0; j < i; ++j) {
+      if (items[j].plan == it.plan && items[j].repetitions) {
+        return asp::set_error(ASP_ERR_INVALID, "items %u and %u share a plan", j, i);
+      }
+    }
+  }
+  // ---- which items go into the shared launches ----
+  // Problems whose spins need the bit-packed layouts, plans with a forced launch geometry
+  // (tests, measurements) and a batch of one keep the single-problem path (team sweep included).
+  std::vector<BatchEntry> entries;
+  std::vector<uint32_t> alone;
+  for (uint32_t i = 0; i < count; ++i) {
+    const asp_sa_batch_item &it = items[i];
+    if (it.repetitions == 0) continue;
+    const asp_sa_plan *p = it.plan;
+    const asp::SaHostLayout &L = p->host;
+    const bool fits = L.num_spins > 0 && sweep_lds_bytes(L, kBytes) <= p->max_lds;
+    if (!fits || p->force_m || p->force_threads || p->force_packed) {
+      alone.push_back(i);
+      continue;
+    }
+    const uint32_t widest = widest_color(L);
+    BatchEntry e{};
+    e.item = i;
+    e.waves = std::min<uint32_t>(widest, widest >= 80 ? 16u : 12u);
+    e.work = static_cast<double>(it.num_sweeps) * static_cast<double>(L.ell_off.back() + L.num_blocks);
+    entries.push_back(e);
+  }
+  if (entries.size() == 1) {
+    alone.push_back(entries[0].item);
+    entries.clear();
+  }
+  for (uint32_t i : alone) {
+    const asp_sa_batch_item &it = items[i];
+    ASP_TRY(run_chains(it.plan, it.seed, it.betas, it.num_sweeps, it.repetitions, it.replica_offset,
+                       nullptr, false, it.out_x, it.out_e));
+    g_batch_sweep_ms += it.plan->last_sweep_ms;
+  }
+  if (entries.empty()) return ASP_OK;
+
+  const asp_sa_plan *first = items[entries[0].item].plan;
+  const int num_cus = first->num_cus;
+  const size_t max_lds = first->max_lds;
+  // ---- size classes: workgroups of one launch have one thread count ----
+  static const uint32_t kClasses[] = {1, 2, 3, 4, 6, 8, 12, 16};
+  constexpr int kNumClasses = sizeof kClasses / sizeof kClasses[0];
+  auto class_of = [&](uint32_t waves) {
+    for (int c = 0; c < kNumClasses; ++c) {
+      if (waves <= kClasses[c]) return c;
+    }
+    return kNumClasses - 1;
+  };
+  // ---- replicas per workgroup: as many as still fill the chip (rows are then shared by more
+  // replicas); 16 wavefronts per CU are resident at this kernel's register budget ----
+  int m = 1;
+  if (const char *env = std::getenv("ASP_BATCH_M")) {  // tuning aid
+    const int forced = std::atoi(env);
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) m = forced;
+  } else {
+    for (int cand : {8, 4, 2}) {
+      uint64_t waves = 0;
+      for (const BatchEntry &e : entries) {
+        const uint32_t reps = items[e.item].repetitions;
+        waves += static_cast<uint64_t>((reps + cand - 1) / cand) * kClasses[class_of(e.waves)];
+      }
+      if (waves >= static_cast<uint64_t>(num_cus) * 16u) {
+        m = cand;
+        break;
+      }
+    }
+  }
+  // ---- per-problem buffer offsets ----
+  struct Offsets {
+    uint64_t best, stat, cache, partial, e, x, groups, padded;
+  };
+  std::vector<Offsets> off(entries.size());
+  uint64_t n_best = 0, n_stat = 0, n_cache = 0, n_partial = 0, n_e = 0, n_x = 0, n_betas = 0;
+  bool use_cache = true;
+  for (size_t k = 0; k < entries.size(); ++k) {
+    const asp_sa_batch_item &it = items[entries[k].item];
+    const asp::SaHostLayout &L = it.plan->host;
+    const uint64_t groups = (it.repetitions + m - 1) / m, padded = groups * m;
+    const uint64_t words = (L.num_spins + 63) / 64;
+    off[k] = Offsets{n_best, n_stat, n_cache, n_partial, n_e, n_x, groups, padded};
+    n_best += padded * L.num_blocks;
+    n_stat += padded;
+    n_cache += padded * L.num_blocks * 64ull;
+    n_partial += static_cast<uint64_t>(it.repetitions) * L.num_blocks;
+    n_e += it.repetitions;
+    n_x += static_cast<uint64_t>(it.repetitions) * words;
+    entries[k].beta_at = n_betas;
+    n_betas += it.num_sweeps;
+    use_cache = use_cache && it.plan->use_field_cache;
+  }
+  if (n_cache * sizeof(double) > (32ull << 30)) use_cache = false;
+
+  asp::ScopedStream main_stream;
+  ASP_TRY(main_stream.acquire());
+  hipStream_t s = main_stream.stream;
+  asp::ScopedStream class_stream[kNumClasses];
+  DeviceBuffer<double> d_betas, d_partial, d_e, d_cache;
+  DeviceBuffer<uint64_t> d_best, d_x;
+  DeviceBuffer<long long> d_tracked;
+  DeviceBuffer<unsigned long long> d_accepted;
+  DeviceBuffer<SweepArgs> d_problems;
+  DeviceBuffer<PostProblem> d_post;
+  DeviceBuffer<BatchSlot> d_slots, d_chains;
+  asp::StreamFence fence(s);
+  ASP_TRY(d_betas.alloc(n_betas));
+  ASP_TRY(d_best.alloc(n_best));
+  ASP_TRY(d_tracked.alloc(n_stat));
+  ASP_TRY(d_accepted.alloc(n_stat));
+  ASP_TRY(d_partial.alloc(n_partial));
+  ASP_TRY(d_e.alloc(n_e));
+  ASP_TRY(d_x.alloc(n_x));
+  if (use_cache && d_cache.alloc(n_cache) != ASP_OK) {
+    asp_clear_error();  // the cache is an optimisation: run without it
+    use_cache = false;
+  }
+  // ---- descriptors ----
+  std::vector<double> h_betas(n_betas);
+  std::vector<SweepArgs> h_problems(entries.size());
+  std::vector<PostProblem> h_post(entries.size());
+  std::vector<BatchSlot> h_chains;
+  h_chains.reserve(n_e);
+  size_t energy_lds = 0;
+  std::vector<bool> wide_ok(kNumClasses, m == 4);
+  for (size_t k = 0; k < entries.size(); ++k) {
+    const asp_sa_plan *p = items[entries[k].item].plan;
+    if (!(p->allow_wide && p->ell_col4.ptr && sweep_lds_bytes(p->host, kWide) <= max_lds)) {
+      wide_ok[class_of(entries[k].waves)] = false;
+    }
+  }
+  for (size_t k = 0; k < entries.size(); ++k) {
+    const asp_sa_batch_item &it = items[entries[k].item];
+    const asp_sa_plan *p = it.plan;
+    const asp::SaHostLayout &L = p->host;
+    const bool wide = wide_ok[class_of(entries[k].waves)];
+    std::copy(it.betas, it.betas + it.num_sweeps, h_betas.begin() + entries[k].beta_at);
+    SweepArgs a{};
+    a.color_block_start = p->color_block_start.ptr;
+    a.block_width = p->block_width.ptr;
+    a.ell_off = p->ell_off.ptr;
+    a.ell_col = wide ? p->ell_col4.ptr : p->ell_col.ptr;
+    a.ell_val = p->ell_val.ptr;
+    a.spin_of_pos = p->spin_of_pos.ptr;
+    a.field_pos = p->field_pos.ptr;
+    a.betas = d_betas.ptr + entries[k].beta_at;
+    a.x0_perm = nullptr;
+    a.best_perm = d_best.ptr + off[k].best;
+    a.tracked = d_tracked.ptr + off[k].stat;
+    a.accepted = d_accepted.ptr + off[k].stat;
+    a.seed = it.seed;
+    a.scale = std::ldexp(1.0, L.energy_scale_exp);
+    a.num_colors = L.num_colors;
+    a.num_blocks = L.num_blocks;
+    a.num_sweeps = it.num_sweeps;
+    a.replica_first = it.replica_offset;
+    a.field_cache = use_cache ? d_cache.ptr + off[k].cache : nullptr;
+    const double degree =
+        std::max(1.0, static_cast<double>(L.a_col.size()) / static_cast<double>(L.num_spins));
+    a.cache_enter_flips =
+        static_cast<uint32_t>(std::max(1.0, 0.7 * static_cast<double>(L.num_blocks) / degree));
+    a.spin_words = nullptr;
+    a.trace = nullptr;
+    h_problems[k] = a;
+    PostProblem pp{};
+    pp.e = EnergyArgs{p->block_width.ptr, p->ell_off.ptr, p->ell_col.ptr, p->ell_val.ptr,
+                      p->field_pos.ptr, d_best.ptr + off[k].best, d_partial.ptr + off[k].partial,
+                      L.num_blocks};
+    pp.pos_of_spin = p->pos_of_spin.ptr;
+    pp.num_spins = L.num_spins;
+    pp.words = static_cast<uint32_t>((L.num_spins + 63) / 64);
+    pp.diag_sum = L.diag_sum;
+    pp.out_e = d_e.ptr + off[k].e;
+    pp.out_x = d_x.ptr + off[k].x;
+    h_post[k] = pp;
+    for (uint32_t r = 0; r < it.repetitions; ++r) {
+      h_chains.push_back(BatchSlot{static_cast<uint32_t>(k), r});
+    }
+    energy_lds = std::max(energy_lds, static_cast<size_t>(L.num_blocks) * sizeof(uint64_t));
+  }
+  // ---- slot tables: per class, problems longest first, dealt round-robin to the 8 XCDs ----
+  struct ClassLaunch {
+    uint64_t slot_at = 0;
+    uint32_t slots_per_xcd = 0;
+    size_t lds = 0;
+    bool used = false;
+  };
+  ClassLaunch launches[kNumClasses];
+  std::vector<BatchSlot> h_slots;
+  for (int c = 0; c < kNumClasses; ++c) {
+    std::vector<size_t> members;
+    for (size_t k = 0; k < entries.size(); ++k) {
+      if (class_of(entries[k].waves) == c) members.push_back(k);
+    }
+    if (members.empty()) continue;
+    std::stable_sort(members.begin(), members.end(),
+                     [&](size_t a, size_t b) { return entries[a].work > entries[b].work; });
+    std::vector<BatchSlot> per_xcd[8];
+    uint64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t k : members) {
+      // the XCD with the fewest groups so far (ties: lowest index): balanced and deterministic
+      int x = 0;
+      for (int j = 1; j < 8; ++j) {
+        if (load[j] < load[x]) x = j;
+      }
+      for (uint32_t g = 0; g < off[k].groups; ++g) {
+        per_xcd[x].push_back(BatchSlot{static_cast<uint32_t>(k), g});
+      }
+      load[x] += off[k].groups;
+      launches[c].lds = std::max(
+          launches[c].lds, sweep_lds_bytes(items[entries[k].item].plan->host, wide_ok[c] ? kWide : kBytes));
+    }
+    uint32_t most = 0;
+    for (int x = 0; x < 8; ++x) most = std::max<uint32_t>(most, static_cast<uint32_t>(per_xcd[x].size()));
+    launches[c].used = true;
+    launches[c].slot_at = h_slots.size();
+    launches[c].slots_per_xcd = most;
+    for (int x = 0; x < 8; ++x) {
+      per_xcd[x].resize(most, BatchSlot{0xFFFFFFFFu, 0});
+      h_slots.insert(h_slots.end(), per_xcd[x].begin(), per_xcd[x].end());
+    }
+  }
+  ASP_TRY(d_problems.alloc(h_problems.size()));
+  ASP_TRY(d_post.alloc(h_post.size()));
+  ASP_TRY(d_slots.alloc(h_slots.size()));
+  ASP_TRY(d_chains.alloc(h_chains.size()));
+  ASP_TRY(d_betas.upload(h_betas.data(), h_betas.size(), s));
+  ASP_TRY(d_problems.upload(h_problems.data(), h_problems.size(), s));
+  ASP_TRY(d_post.upload(h_post.data(), h_post.size(), s));
+  ASP_TRY(d_slots.upload(h_slots.data(), h_slots.size(), s));
+  ASP_TRY(d_chains.upload(h_chains.data(), h_chains.size(), s));
+  ASP_HIP_TRY(hipMemsetAsync(d_accepted.ptr, 0, n_stat * sizeof(unsigned long long), s));
+  hipEvent_t ev[2 + kNumClasses] = {};
+  struct EventGuard {
+    hipEvent_t *ev;
+    int n;
+    ~EventGuard() {
+      for (int i = 0; i < n; ++i) {
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+      }
+    }
+  } event_guard{ev, 2 + kNumClasses};
+  for (auto &e : ev) ASP_HIP_TRY(hipEventCreate(&e));
+  ASP_HIP_TRY(hipEventRecord(ev[0], s));
+  // ---- one sweep launch per class, each on its own stream so that they share the chip ----
+  for (int c = 0; c < kNumClasses; ++c) {
+    if (!launches[c].used) continue;
+    ASP_TRY(class_stream[c].acquire());
+    hipStream_t cs = class_stream[c].stream;
+    ASP_HIP_TRY(hipStreamWaitEvent(cs, ev[0], 0));
+    BatchArgs b{d_problems.ptr, d_slots.ptr + launches[c].slot_at, launches[c].slots_per_xcd};
+    using BatchKernel = void (*)(BatchArgs);
+    BatchKernel kernel = nullptr;
+    if (wide_ok[c]) {
+      kernel = k_sa_sweep_batch<4, kWide>;
+    } else {
+      switch (m) {
+        case 1: kernel = k_sa_sweep_batch<1, kBytes>; break;
+        case 2: kernel = k_sa_sweep_batch<2, kBytes>; break;
+        case 4: kernel = k_sa_sweep_batch<4, kBytes>; break;
+        default: kernel = k_sa_sweep_batch<8, kBytes>; break;
+      }
+    }
+    if (launches[c].lds > 64 * 1024) {
+      ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(launches[c].lds)));
+    }
+    hipLaunchKernelGGL(kernel, dim3(8u * launches[c].slots_per_xcd), dim3(64u * kClasses[c]),
+                       launches[c].lds, cs, b);
+    ASP_HIP_TRY(hipGetLastError());
+    ASP_HIP_TRY(hipEventRecord(ev[2 + c], cs));
+    ASP_HIP_TRY(hipStreamWaitEvent(s, ev[2 + c], 0));
+  }
+  ASP_HIP_TRY(hipEventRecord(ev[1], s));
+  // ---- energies and original-order bits of every chain's best configuration ----
+  const unsigned chains = static_cast<unsigned>(h_chains.size());
+  if (energy_lds > max_lds) {
+    hipLaunchKernelGGL(k_sa_energy_blocks_batch<false>, dim3(chains), dim3(512), 0, s, d_post.ptr,
+                       d_chains.ptr);
+  } else {
+    if (energy_lds > 64 * 1024) {
+      ASP_HIP_TRY(hipFuncSetAttribute(
+          reinterpret_cast<const void *>(k_sa_energy_blocks_batch<true>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(energy_lds)));
+    }
+    hipLaunchKernelGGL(k_sa_energy_blocks_batch<true>, dim3(chains), dim3(512), energy_lds, s,
+                       d_post.ptr, d_chains.ptr);
+  }
+  hipLaunchKernelGGL(k_sa_energy_fold_batch, dim3(chains), dim3(64), 0, s, d_post.ptr, d_chains.ptr);
+  hipLaunchKernelGGL(k_unpermute_bits_batch, dim3(chains), dim3(256), 0, s, d_post.ptr, d_chains.ptr);
+  ASP_HIP_TRY(hipGetLastError());
+  std::vector<uint64_t> h_x(n_x);
+  std::vector<double> h_e(n_e);
+  std::vector<long long> h_tracked(n_stat);
+  std::vector<unsigned long long> h_accepted(n_stat);
+  ASP_TRY(d_x.download(h_x.data(), n_x, s));
+  ASP_TRY(d_e.download(h_e.data(), n_e, s));
+  ASP_TRY(d_tracked.download(h_tracked.data(), n_stat, s));
+  ASP_TRY(d_accepted.download(h_accepted.data(), n_stat, s));
+  ASP_HIP_TRY(hipStreamSynchronize(s));
+  float ms = 0.0f;
+  ASP_HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
+  g_batch_sweep_ms += ms;
+  for (size_t k = 0; k < entries.size(); ++k) {
+    const asp_sa_batch_item &it = items[entries[k].item];
+    asp_sa_plan *p = it.plan;
+    const uint64_t words = (p->host.num_spins + 63) / 64;
+    std::copy(h_x.begin() + off[k].x, h_x.begin() + off[k].x + it.repetitions * words, it.out_x);
+    std::copy(h_e.begin() + off[k].e, h_e.begin() + off[k].e + it.repetitions, it.out_e);
+    p->last_tracked.assign(h_tracked.begin() + off[k].stat,
+                           h_tracked.begin() + off[k].stat + it.repetitions);
+    p->last_accepted.assign(h_accepted.begin() + off[k].stat,
+                            h_accepted.begin() + off[k].stat + it.repetitions);
+    const int c = class_of(entries[k].waves);
+    p->last_m = wide_ok[c] ? 4 : m;
+    p->last_layout = wide_ok[c] ? kWide : kBytes;
+    p->last_threads = static_cast<int>(64u * kClasses[c]);
+    p->last_groups = static_cast<int>(off[k].groups);
+    p->last_sweep_ms = p->last_total_ms = 0.0f;  // shared launches: see asp_sa_batch_last_ms
+  }
   return ASP_OK;
 }
 

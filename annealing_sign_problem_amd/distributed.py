@@ -271,3 +271,25 @@ def map_sharded(items, work, group=None):
         for c, result in part:
             out[c] = result
     return out
+
+
+def map_sharded_many(items, work_many, group=None):
+    """:func:`map_sharded` for a worker that takes a LIST of items and returns one result per
+    item (so that a rank can batch its share of the problems on its GPU): rank k gets the items
+    ``c`` with ``c mod world == k``, in order; results come back in item order on every rank."""
+    d = _dist()
+    if d is None or d.get_world_size(group) == 1:
+        return list(work_many(list(items)))
+    world, me = d.get_world_size(group), d.get_rank(group)
+    share = [c for c in range(len(items)) if c % world == me]
+    with chains_local():
+        done = list(work_many([items[c] for c in share]))
+    if len(done) != len(share):
+        raise ValueError("work_many returned %d results for %d items" % (len(done), len(share)))
+    parts = [None] * world
+    d.all_gather_object(parts, list(zip(share, done)), group=group)
+    out = [None] * len(items)
+    for part in parts:
+        for c, result in part:
+            out[c] = result
+    return out

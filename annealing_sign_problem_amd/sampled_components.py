@@ -161,6 +161,42 @@ def process_cluster(cluster, hamiltonian, ground_state, noisy_ground_state, nois
     return results
 
 
+def process_clusters_batched(clusters: Sequence[np.ndarray], hamiltonian, ground_state,
+                             noisy_ground_state, noisy_log_coeff_fn, order: int,
+                             global_cutoff: float, annealing: bool) -> List[List[OptimizationResult]]:
+    """``[process_cluster(c, ...) for c in clusters]`` with the annealing of ALL models — every
+    cluster at every order — in one batched device call.  The models of a cluster do not depend
+    on its solutions (the extension of order i grows from the model of order i-1, common.py:516),
+    so they can all be built first; the results are identical to the per-cluster loop."""
+    basis = hamiltonian.basis
+    staged = []  # (cluster index, model, exact_signs, weights, result so far)
+    for index, cluster in enumerate(clusters):
+        exact_psi = ground_state[np.asarray(basis.batched_index(cluster), dtype=np.int64)]
+        exact_signs = sa.signs_to_bits(np.sign(exact_psi))
+        weights = exact_psi ** 2
+        weights /= np.sum(weights)
+        h = None
+        for i in range(order + 1):
+            if i == 0:
+                h = common.make_ising_model(cluster, hamiltonian, log_psi_fn=noisy_log_coeff_fn)
+            else:
+                h = common.make_hamiltonian_extension(h, noisy_log_coeff_fn)
+                h = common.sparsify_using_global_cutoff(h, global_cutoff, cluster)
+            r = solve_and_test_model(h, cluster, exact_signs, weights, annealing=False)
+            r.amplitude_overlap = amplitude_overlap(h.spins, ground_state, noisy_ground_state, basis)
+            staged.append((index, h, exact_signs, weights, r))
+    if annealing and staged:
+        solutions = common.solve_ising_models([m for _, m, _, _, _ in staged],
+                                              [clusters[c] for c, _, _, _, _ in staged])
+        for (_, _, exact_signs, weights, r), x in zip(staged, solutions):
+            r.sa_accuracy, r.sa_overlap = common.compute_accuracy_and_overlap(x, exact_signs, weights)
+    results: List[List[OptimizationResult]] = [[] for _ in clusters]
+    for index, h, _, _, r in staged:
+        results[index].append(r)
+        h.ising_hamiltonian.release()  # the device plan of a finished model
+    return results
+
+
 def parse_command_line(argv=None):
     parser = argparse.ArgumentParser(description="Test Simulated Annealing on sampled clusters.")
     parser.add_argument("--model", type=str, required=True,
@@ -178,6 +214,10 @@ def parse_command_line(argv=None):
     parser.add_argument("--sampled-power", type=float, default=0.1)
     parser.add_argument("--keep-probability", type=float, default=0.5)
     parser.add_argument("--seed", type=int, default=12345)
+    parser.add_argument("--batch", type=int, default=64,
+                        help="clusters whose annealing chains share one batched device call "
+                             "(asp_sa_anneal_batch); 1 = one call per model, as the reference's "
+                             "loop.  The output does not depend on it")
     parser.add_argument("--jobs", type=int, default=1,
                         help="clusters optimised concurrently (independent plans and HIP streams "
                              "on one GPU; the output does not depend on it)")
@@ -221,17 +261,31 @@ def main(argv=None):
         return process_cluster(cluster, hamiltonian, ground_state, noisy_ground_state,
                                noisy_log_coeff_fn, args.order, args.global_cutoff, args.annealing)
 
+    def work_many(some):
+        """CSV lines of a list of clusters, their annealing batched --batch clusters at a time."""
+        if args.batch <= 1 or not args.annealing:
+            return [",".join(r.to_csv_str() for r in work(c)) for c in some]
+        lines = []
+        for start in range(0, len(some), args.batch):
+            chunk = process_clusters_batched(some[start:start + args.batch], hamiltonian,
+                                             ground_state, noisy_ground_state, noisy_log_coeff_fn,
+                                             args.order, args.global_cutoff, args.annealing)
+            lines += [",".join(r.to_csv_str() for r in columns) for columns in chunk]
+        return lines
+
+    def append(lines):
+        with open(args.output, "a") as f:
+            for line in lines:
+                f.write(line + "\n")
+
     # Clusters are independent problems (SURVEY §8e).  Under torch.distributed (one process per
     # GPU) cluster c is solved by rank c mod world and rank 0 writes the gathered lines; every
     # rank generated the same clusters above (same seed), so the file does not depend on the
     # world size.
     if asp_dist.world_size() > 1:
-        lines = asp_dist.map_sharded(
-            clusters, lambda c: ",".join(r.to_csv_str() for r in work(c)))
+        lines = asp_dist.map_sharded_many(clusters, work_many)
         if writer:
-            with open(args.output, "a") as f:
-                for line in lines:
-                    f.write(line + "\n")
+            append(lines)
         if created_group:
             import torch.distributed as dist
 
@@ -240,20 +294,17 @@ def main(argv=None):
         return
     # With --jobs > 1 several clusters are in flight on one GPU at once — the C calls release
     # the GIL and every Hamiltonian owns its stream.  All randomness was consumed above, so the
-    # lines written are identical for any --jobs.
-    if args.jobs > 1:
+    # lines written are identical for any --jobs and any --batch.
+    if args.jobs > 1 and (args.batch <= 1 or not args.annealing):
         from concurrent.futures import ThreadPoolExecutor
 
         with ThreadPoolExecutor(max_workers=args.jobs) as pool:
-            results = pool.map(work, clusters)
-            for columns in results:
-                with open(args.output, "a") as f:
-                    f.write(",".join(r.to_csv_str() for r in columns) + "\n")
+            for columns in pool.map(work, clusters):
+                append([",".join(r.to_csv_str() for r in columns)])
     else:
-        for cluster in clusters:
-            columns = work(cluster)
-            with open(args.output, "a") as f:
-                f.write(",".join(r.to_csv_str() for r in columns) + "\n")
+        step = max(args.batch, 1)
+        for start in range(0, len(clusters), step):  # (written chunk by chunk: a long job's
+            append(work_many(clusters[start:start + step]))  # output grows as it runs)
 
 
 if __name__ == "__main__":

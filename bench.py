@@ -14,15 +14,21 @@ Weak scaling: every rank runs its own 1024 chains (global replica ids
 rank*1024 ...); value = all ranks' flip attempts / max-over-ranks wall time.
 
 The JSON line also carries
-  roofline      for the sweep kernel: algorithmic bytes (B_flip = 12*dbar + 16 per
-                attempt) / kernel time from HIP events on the launch
-                stream, against the 8 TB/s HBM3E peak;
+  roofline      for the sweep kernel, against the resource that binds it — VALU
+                issue: (VALU instructions per flip from the committed PMC summary) x
+                (SIMD cycles per instruction from the on-chip probe) x (flips/s from
+                HIP events on the launch stream, live) over 1024 SIMDs x 2.4 GHz;
+                beside it the measured HBM fraction, the useful-f64-FMA fraction, the
+                algorithmic bytes/s (B_flip = 12*dbar + 16) and the rate
+                with every proposal evaluated (field cache / inert skipping off);
   cpu_baseline  the oracle's OpenMP port of the same sweep on the host cores,
                 timed on a bounded sample (rank 0, N = 1 only);
   build         the coupling build (build_matrix) on the K = 1e5 cluster, device
                 resident, next to the reference's own C timed on a sample;
   reference_default_call  the reference's default solve (5120 sweeps x 64 chains)
-                on one 1e5-spin cluster, team sweep vs one workgroup per chain.
+                on one 1e5-spin cluster, team sweep vs one workgroup per chain;
+  batched_small_clusters  the production shape: 128 clusters of 1e2..1e4 spins, 64
+                chains x 5120 sweeps each, one batched call vs the per-cluster loop.
 """
 from __future__ import annotations
 
@@ -40,6 +46,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+NUM_SIMDS = 1024        # 256 CUs x 4
+CLOCK_GHZ = 2.4         # peak engine clock: the VALU-issue peak is NUM_SIMDS * CLOCK_GHZ cycles/s
+F64_VALU_PEAK_TFLOPS = 78.6  # vector f64 (MI355X_MICROARCH.md: half the 157.3 TF f32 vector peak)
 CLUSTER_SIZES = (10000, 30000, 100000)
 CLUSTER_SEED = 783494  # experiments/sampled_connected_components.py:621
 
@@ -58,6 +67,20 @@ def parse_args():
     p.add_argument("--no-build", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     return p.parse_args()
+
+
+def sweep_counters_from_profiles():
+    """VALU instructions per flip attempt and the measured clock of the sweep kernel on this
+    workload (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE), and the SIMD cycles one such
+    instruction occupies (tools/issue_rate_probe.hip), from the committed summary."""
+    path = os.path.join(ROOT, "profiles", "sweep_counters.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
 
 
 def traffic_from_profiles():
@@ -281,6 +304,57 @@ def bench_default_call():
     return out
 
 
+def bench_batched_clusters(num_problems=128, serial_every=8):
+    """The reference's production shape (experiments/sampled_connected_components.py:764-767,
+    common.py:236-239): many sampled clusters, each solved with 64 chains x 5120 sweeps.  A
+    log-uniform mix of cluster sizes in [1e2, 1e4]; one asp_sa_anneal_batch call for all of them
+    next to the per-cluster loop (timed on every `serial_every`-th problem), identical results
+    required."""
+    from annealing_sign_problem_amd import _lib, synthetic
+    from annealing_sign_problem_amd import annealer as sa
+
+    lib = _lib.load()
+    rng = np.random.default_rng(CLUSTER_SEED)
+    sizes = [int(round(np.exp(rng.uniform(np.log(1e2), np.log(1e4))))) for _ in range(num_problems)]
+    hams = []
+    for i, k in enumerate(sizes):
+        J, h, _ = synthetic.planted_cluster(k, seed=CLUSTER_SEED + i)
+        ham = sa.Hamiltonian(J, h)
+        ham.info()  # plan resident before the timed region
+        hams.append(ham)
+    sweeps, reps = 5120, 64
+    sa.anneal_batch(hams[:4], seed=1, number_sweeps=8, repetitions=reps)  # warm-up
+    t0 = time.perf_counter()
+    batched = sa.anneal_batch(hams, seed=12345, number_sweeps=sweeps, repetitions=reps)
+    t_batched = time.perf_counter() - t0
+    batched_kernel_ms = float(lib.asp_sa_batch_last_ms())
+    subset = list(range(0, num_problems, serial_every))
+    sa.anneal(hams[subset[0]], seed=1, number_sweeps=8, repetitions=reps)  # warm-up
+    t0 = time.perf_counter()
+    serial = [sa.anneal(hams[i], seed=12345, number_sweeps=sweeps, repetitions=reps) for i in subset]
+    t_serial = time.perf_counter() - t0
+    for i, (x, e) in zip(subset, serial):
+        if not (np.array_equal(x, batched[i][0]) and e == batched[i][1]):
+            raise RuntimeError("batched anneal disagrees with the per-cluster call")
+    flips_all = float(sum(sizes)) * reps * sweeps
+    flips_subset = float(sum(sizes[i] for i in subset)) * reps * sweeps
+    for ham in hams:
+        ham.release()
+    return {
+        "workload": "%d planted clusters, K log-uniform in [1e2, 1e4] (sum K = %d), %d chains x %d "
+                    "sweeps each" % (num_problems, sum(sizes), reps, sweeps),
+        "batched_s": t_batched,
+        "batched_sweep_kernels_ms": batched_kernel_ms,
+        "batched_flips_per_s": flips_all / t_batched,
+        "batched_problems_per_s": num_problems / t_batched,
+        "serial_sample": "every %dth problem (%d problems)" % (serial_every, len(subset)),
+        "serial_s": t_serial,
+        "serial_flips_per_s": flips_subset / t_serial,
+        "serial_problems_per_s": len(subset) / t_serial,
+        "speedup": (flips_all / t_batched) / (flips_subset / t_serial),
+    }
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -374,21 +448,55 @@ def main():
         alg_bytes = sum(c["J"].shape[0] * replicas * args.sweeps * c["b_flip"] for c, _ in sweep_ms)
         kernel_s = sum(ms for _, ms in sweep_ms) * 1e-3
         launches = max(1, len(sweep_ms))
-        achieved = alg_bytes / kernel_s / 1e9
+        kernel_flips = flips_per_step * args.steps / kernel_s
         traffic = traffic_from_profiles()
+        counters = sweep_counters_from_profiles()
+        # every proposal evaluated: field cache and inert-block skipping off (results identical)
+        no_skip_ms = 0.0
+        for c in clusters:
+            _lib.check(lib.asp_sa_set_field_cache(c["ham"].plan(), 0))
+            sa.anneal_raw(c["ham"], 12345, c["betas"], replicas, offset)
+            no_skip_ms += lib.asp_sa_last_sweep_ms(c["ham"].plan())
+            _lib.check(lib.asp_sa_set_field_cache(c["ham"].plan(), 1))
+        kernel_flips_no_skip = flips_per_step / (no_skip_ms * 1e-3)
+        # The sweep kernel is bound by VALU ISSUE, not by HBM (couplings are L2/MALL-resident
+        # and shared by the replicas of a workgroup; spins never leave LDS): achieved = SIMD
+        # issue cycles its VALU instructions occupy per second = (instructions per flip, PMC)
+        # x (cycles per instruction, on-chip probe) x (flips/s, measured live here).
+        peak_issue = NUM_SIMDS * CLOCK_GHZ  # G SIMD-cycles/s
+        if counters:
+            issue = (counters["valu_insts_per_flip"] * counters["cycles_per_valu_inst"]
+                     * kernel_flips / 1e9)
+        else:
+            issue = None
+        mean_offdiag = sum((c["dbar"] - 1.0) * c["J"].shape[0] for c in clusters) / sum(
+            c["J"].shape[0] for c in clusters)
+        hbm_bytes = traffic.get("hbm_bytes_per_launch") if traffic else None
         roofline = {
-            "bound": "hbm",
+            "bound": "valu",
             "kernel": "k_sa_sweep",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic.get("hbm_bytes_per_launch") if traffic else None,
+            "achieved": issue,
+            "peak": peak_issue,
+            "unit": "G SIMD issue cycles/s",
+            "frac": issue / peak_issue if issue is not None else None,
+            "traffic": hbm_bytes,
+            "valu_insts_per_flip": counters.get("valu_insts_per_flip") if counters else None,
+            "cycles_per_valu_inst": counters.get("cycles_per_valu_inst") if counters else None,
+            "measured_clock_ghz": counters.get("clock_ghz") if counters else None,
+            "frac_at_measured_clock": (issue / (NUM_SIMDS * counters["clock_ghz"])
+                                       if counters and counters.get("clock_ghz") else None),
+            "hbm_measured_frac": (hbm_bytes / (kernel_s / launches) / 1e9 / HBM_PEAK_GBS
+                                  if hbm_bytes else None),
+            "f64_fma_frac": kernel_flips * mean_offdiag * 2.0 / 1e12 / F64_VALU_PEAK_TFLOPS,
+            "algorithmic_GBps": alg_bytes / kernel_s / 1e9,
             "algorithmic_bytes_per_launch": alg_bytes / launches,
             "avg_launch_ms": kernel_s * 1e3 / launches,
-            "kernel_flips_per_s": flips_per_step * args.steps / kernel_s,
-            "note": "couplings are cache-resident and shared by the replicas of a workgroup, so "
-                    "algorithmic bytes/s may exceed the HBM peak; see DESIGN.md §6",
+            "kernel_flips_per_s": kernel_flips,
+            "kernel_flips_per_s_no_skip": kernel_flips_no_skip,
+            "note": "bound = VALU issue (DESIGN.md §6): algorithmic_GBps = B_flip x flips/s is the "
+                    "traffic of a one-replica CPU sweep and exceeds the HBM peak because rows are "
+                    "shared by the replicas of a workgroup and stay cache-resident; the HBM side "
+                    "is hbm_measured_frac",
         }
         out = {
             "metric": "SA spin-flips/sec, kagome_36-sized clusters",
@@ -412,6 +520,7 @@ def main():
                 "launch": launch,
             },
             "roofline": roofline,
+            "value_no_skip": value * kernel_flips_no_skip / kernel_flips,
         }
         if world == 1 and not args.no_cpu_baseline:
             cores = usable_cores()
@@ -420,6 +529,7 @@ def main():
         if world == 1 and not args.no_build:
             out["build"] = bench_build(clusters[-1]["J"], 1)
             out["reference_default_call"] = bench_default_call()
+            out["batched_small_clusters"] = bench_batched_clusters()
         print(json.dumps(out))
 
     if world > 1:

@@ -286,7 +286,9 @@ int asp_sa_last_layout(asp_sa_plan const *p);
 /* Few chains on a large cluster (chains <= CUs / 2, e.g. the reference's default of 64
  * repetitions): each chain is spread over a TEAM of 2, 4 or 8 workgroups that split every colour
  * class, exchange one flip word per block and meet at a device-scope barrier per colour
- * (cooperative launch).  team = -1 chooses automatically (default), 0 never, 2/4/8 forces that
+ * (all of a team's workgroups must be resident together: the grid stays within the CU count,
+ * team launches of one process take turns, and if the device is shared and a barrier times out the
+ * call is repeated without teams — one process per GPU is assumed).  team = -1 chooses automatically (default), 0 never, 2/4/8 forces that
  * team size when the chains fit (tests, measurements).  Chains are bit-identical either way;
  * asp_sa_last_layout reports 4 for a team launch. */
 int asp_sa_set_team(asp_sa_plan *p, int team);
@@ -317,6 +319,30 @@ int asp_sa_anneal(asp_sa_plan *p, uint64_t seed, double const *betas,
 int asp_sa_anneal_trace(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_sweeps,
                         uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0,
                         uint64_t *out_x, double *out_e, int64_t *out_trace);
+
+/* MANY independent problems in one call — the shape of the reference's production job: tens of
+ * thousands of sampled clusters, each solved with 64 repetitions x 5120 sweeps
+ * (Makefile:9,115-127; experiments/sampled_connected_components.py:764-767; common.py:236-239).
+ * Item i is exactly asp_sa_anneal(plan, seed, betas, num_sweeps, repetitions, replica_offset,
+ * NULL, out_x, out_e): every chain is bit-identical to that call's.  The groups of all problems
+ * become the workgroups of a few shared launches (one per wavefront count), so a batch of small
+ * clusters fills the chip instead of leaving > 90 % of it idle launch by launch.  Plans must
+ * be distinct.  Problems that need the bit-packed spin layouts, and a batch of one, take the
+ * single-problem path inside the call. */
+typedef struct asp_sa_batch_item {
+  asp_sa_plan *plan;
+  uint64_t seed;
+  double const *betas;  /* num_sweeps values */
+  uint32_t num_sweeps;
+  uint32_t repetitions;
+  uint32_t replica_offset;
+  uint32_t reserved;    /* 0 */
+  uint64_t *out_x;      /* repetitions * ceil(K/64) words */
+  double *out_e;        /* repetitions */
+} asp_sa_batch_item;
+int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count);
+/* Device time (ms) of the sweep launches of this thread's last asp_sa_anneal_batch call. */
+float asp_sa_batch_last_ms(void);
 
 /* Replaces ising_glass_annealer.greedy_solve (call site common.py:250; the only in-tree
  * description is the commented prototype at common.py:298-438): couplings are visited

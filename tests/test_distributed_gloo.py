@@ -157,6 +157,7 @@ def _main_worker(rank, world, port, out_path, expect_refusal):
 
     sc.generate_clusters = fake_clusters
     sc.process_cluster = fake_process
+    sc.process_clusters_batched = lambda clusters, *rest: [fake_process(c, *rest) for c in clusters]
     argv = ["--model", "heisenberg_kagome_16", "--output", out_path, "--order", "1",
             "--number-samples", "5", "--seed", "3"]
     if expect_refusal:

@@ -166,3 +166,20 @@ def test_components_on_long_chains_match_scipy():
         bo.sort_indices()
         assert np.array_equal(keep, keep_o), trial
         assert np.array_equal(block.indices, bo.indices) and block.data.tobytes() == bo.data.tobytes()
+
+
+def test_batched_annealing_gives_identical_output(tmp_path):
+    """The pipeline's --batch (all models' annealing chains in one asp_sa_anneal_batch call) must
+    write the file the per-model loop writes, SA columns included."""
+    from annealing_sign_problem_amd import sampled_components
+
+    common_args = ["--model", "heisenberg_kagome_16", "--order", "1", "--number-samples", "7",
+                   "--seed", "5", "--max-cluster-size", "400"]
+    a, b, c = tmp_path / "loop.csv", tmp_path / "batch.csv", tmp_path / "batch3.csv"
+    sampled_components.main(common_args + ["--output", str(a), "--batch", "1"])
+    sampled_components.main(common_args + ["--output", str(b)])
+    sampled_components.main(common_args + ["--output", str(c), "--batch", "3"])
+    assert a.read_text() == b.read_text() == c.read_text()
+    rows = [l for l in a.read_text().splitlines() if not l.startswith("#")]
+    v = np.array([float(t) for t in rows[0].split(",")]).reshape(2, 6)
+    assert np.all(np.isfinite(v[:, 3:5]))  # the SA columns are filled

@@ -689,3 +689,91 @@ def test_randomised_configurations_match_oracle():
         assert np.array_equal(xs, oxs), label
         assert es.tobytes() == oes.tobytes(), label
         assert np.array_equal(tracked, otr) and np.array_equal(accepted, oacc), label
+
+
+# ---------------------------------------------------------------------------------------------
+# Batched anneal: many problems in shared launches (asp_sa_anneal_batch)
+# ---------------------------------------------------------------------------------------------
+
+def _batch_problems(sizes, seed0, degree=6.0):
+    from annealing_sign_problem_amd import annealer as sa
+    from annealing_sign_problem_amd import synthetic
+
+    problems = []
+    for i, k in enumerate(sizes):
+        J, h, _ = synthetic.planted_cluster(k, seed=seed0 + i, mean_degree=degree)
+        ham = sa.Hamiltonian(J, h)
+        info = ham.info()
+        sweeps = 20 + 3 * (i % 5)
+        problems.append(dict(J=J, h=h, ham=ham, seed=1000 + 17 * i, reps=3 + (5 * i) % 13,
+                             offset=(i % 3) * 5,
+                             betas=sa.make_schedule(info.beta0_auto, min(info.beta1_auto, 1e6), sweeps),
+                             S=info.energy_scale_exp))
+    return problems
+
+
+@pytest.mark.parametrize("forced_m", [None, 1, 2, 4, 8])
+def test_batch_equals_single_launches_and_oracle(forced_m, monkeypatch):
+    """Every problem of a batch — different sizes, chain counts, ladders, seeds and replica
+    offsets, spread over several wavefront classes — returns exactly what its own
+    asp_sa_anneal call returns and what the oracle computes (spins, energies, tracked energies,
+    accepted flips), for every number of replicas per workgroup."""
+    from annealing_sign_problem_amd import annealer as sa
+
+    if forced_m is None:
+        monkeypatch.delenv("ASP_BATCH_M", raising=False)
+    else:
+        monkeypatch.setenv("ASP_BATCH_M", str(forced_m))
+    sizes = [70, 130, 64, 400, 900, 1500, 2600, 5200, 3, 11000, 333, 1]
+    problems = _batch_problems(sizes, 50)
+    results = sa.anneal_batch_raw([p["ham"] for p in problems], [p["seed"] for p in problems],
+                                  [p["betas"] for p in problems], [p["reps"] for p in problems],
+                                  [p["offset"] for p in problems])
+    stats = [_stats(p["ham"], p["reps"]) for p in problems]
+    for p, (xs, es), (tracked, accepted) in zip(problems, results, stats):
+        oxs, oes, otracked, oaccepted = oracle.sa_anneal(p["J"], p["h"], p["seed"], p["betas"],
+                                                        p["reps"], p["offset"], None, p["S"],
+                                                        num_threads=8)
+        assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+        assert np.array_equal(tracked, otracked) and np.array_equal(accepted, oaccepted)
+        sxs, ses = sa.anneal_raw(p["ham"], p["seed"], p["betas"], p["reps"], p["offset"])
+        assert np.array_equal(xs, sxs) and es.tobytes() == ses.tobytes()
+
+
+def test_batch_many_small_clusters_fill_the_chip_and_match():
+    """The production shape: many clusters, 64 chains each (common.py:238), launcher's own choice
+    of replicas per workgroup; chains still equal the oracle's."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    rng = np.random.default_rng(5)
+    sizes = [int(round(np.exp(rng.uniform(np.log(100), np.log(3000))))) for _ in range(96)]
+    problems = _batch_problems(sizes, 900, degree=10.0)
+    results = sa.anneal_batch_raw([p["ham"] for p in problems], [12345] * len(problems),
+                                  [p["betas"] for p in problems], [64] * len(problems))
+    assert _lib.load().asp_sa_batch_last_ms() > 0
+    for i in (0, 17, 40, 95):
+        p = problems[i]
+        oxs, oes, _, _ = oracle.sa_anneal(p["J"], p["h"], 12345, p["betas"], 64, 0, None, p["S"],
+                                          num_threads=16)
+        assert np.array_equal(results[i][0], oxs) and results[i][1].tobytes() == oes.tobytes()
+    # the public form: one (x, e) per problem = the first minimum of its chains
+    best = sa.anneal_batch([p["ham"] for p in problems[:5]], seed=7, number_sweeps=30, repetitions=8)
+    for p, (x, e) in zip(problems[:5], best):
+        x1, e1 = sa.anneal(p["ham"], seed=7, number_sweeps=30, repetitions=8)
+        assert np.array_equal(x, x1) and e == e1
+
+
+def test_batch_rejects_bad_items():
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    problems = _batch_problems([100, 200], 3)
+    ham = problems[0]["ham"]
+    with pytest.raises(ValueError):
+        sa.anneal_batch_raw([ham, ham], [1, 2], [problems[0]["betas"]] * 2, [2, 2])
+    bad = problems[1]["betas"].copy()
+    bad[3] = -1.0
+    with pytest.raises(_lib.AspError):
+        sa.anneal_batch_raw([p["ham"] for p in problems], [1, 2], [problems[0]["betas"], bad], [2, 2])
+    assert sa.anneal_batch_raw([], [], [], []) == []
