@@ -198,6 +198,23 @@ def anneal_raw(hamiltonian: Hamiltonian, seed: int, betas: np.ndarray, repetitio
     return xs[:, :words], es
 
 
+def anneal_raw_into(hamiltonian: Hamiltonian, seed: int, betas: np.ndarray, repetitions: int,
+                    replica_offset: int, x0, out_x_ptr: int, out_e_ptr: int) -> None:
+    """``anneal_raw`` writing into caller-owned memory given as raw addresses — host or DEVICE
+    (e.g. ``tensor.data_ptr()`` of torch tensors on this library's GPU): ``out_x`` receives
+    ``repetitions * ceil(K/64)`` words, ``out_e`` ``repetitions`` doubles."""
+    lib = _lib.load()
+    betas = np.ascontiguousarray(betas, dtype=np.float64)
+    if x0 is not None:
+        x0 = np.ascontiguousarray(x0, dtype=np.uint64).reshape(-1)
+        if x0.shape[0] != (hamiltonian.size + 63) // 64:
+            raise ValueError("'x0' must have {} words".format((hamiltonian.size + 63) // 64))
+    _lib.check(lib.asp_sa_anneal(hamiltonian.plan(), ctypes.c_uint64(seed), _lib.ptr(betas),
+                                 ctypes.c_uint32(betas.shape[0]), ctypes.c_uint32(repetitions),
+                                 ctypes.c_uint32(replica_offset), _lib.ptr(x0),
+                                 ctypes.c_void_p(out_x_ptr), ctypes.c_void_p(out_e_ptr)))
+
+
 def anneal(hamiltonian: Hamiltonian, x0=None, seed=None, number_sweeps: int = 5120,
            beta0: Optional[float] = None, beta1: Optional[float] = None, repetitions: int = 1,
            only_best: bool = True, distributed: bool = True):

@@ -25,6 +25,10 @@ __all__ = [
     "make_ising_model",
     "solve_ising_model",
     "solve_ising_models",
+    "dump_ising_model_to_hdf5",
+    "load_ising_model_from_hdf5",
+    "load_ground_state",
+    "save_ground_state",
     "compute_accuracy_and_overlap",
     "make_hamiltonian_extension",
     "sparsify_using_global_cutoff",
@@ -332,6 +336,103 @@ def invert_permutation(p) -> np.ndarray:
     s = np.empty_like(p)
     s[p] = np.arange(p.size)
     return s
+
+
+def _h5py_or_none():
+    try:
+        import h5py  # optional: not part of this image's main interpreter
+
+        return h5py
+    except Exception:
+        return None
+
+
+def dump_ising_model_to_hdf5(model: IsingModel, ground_state, filename: str) -> None:
+    """The reference's dump of an Ising model (common.py:750-769), same dataset names, dtypes and
+    layout: ``elements f64[nnz]``, ``indices i32[nnz]``, ``indptr i32[K+1]`` (CSR of J),
+    ``field f64[K]``, ``energy`` (<psi|H|psi>, scalar f64) and ``signs u64[ceil(K/64)]`` at the
+    root.  Written with h5py when it is importable, otherwise with :mod:`.hdf5_lite`."""
+    matrix = scipy.sparse.csr_matrix(model.ising_hamiltonian.exchange)
+    ground_state = np.asarray(ground_state, dtype=np.float64)
+    energy = float(np.real(model.quantum_hamiltonian.expectation(ground_state)))
+    content = {
+        "elements": np.asarray(matrix.data, dtype=np.float64),
+        "indices": np.asarray(matrix.indices, dtype=np.int32),
+        "indptr": np.asarray(matrix.indptr, dtype=np.int32),
+        "field": np.asarray(model.ising_hamiltonian.field, dtype=np.float64),
+        "energy": np.float64(energy),
+        "signs": sa.signs_to_bits(np.sign(ground_state)),
+    }
+    h5py = _h5py_or_none()
+    if h5py is not None:
+        with h5py.File(filename, "w") as out:
+            for key, value in content.items():
+                out[key] = value
+        return
+    from . import hdf5_lite
+
+    hdf5_lite.write(filename, content)
+
+
+def load_ising_model_from_hdf5(filename: str):
+    """Inverse of :func:`dump_ising_model_to_hdf5`: ``(Hamiltonian, energy, signs)``."""
+    h5py = _h5py_or_none()
+    if h5py is not None:
+        with h5py.File(filename, "r") as f:
+            c = {k: np.asarray(f[k]) for k in ("elements", "indices", "indptr", "field", "energy", "signs")}
+    else:
+        from . import hdf5_lite
+
+        c = hdf5_lite.read(filename)
+    n = c["field"].shape[0]
+    exchange = scipy.sparse.csr_matrix(
+        (np.asarray(c["elements"], dtype=np.float64), np.asarray(c["indices"], dtype=np.int32),
+         np.asarray(c["indptr"], dtype=np.int32)), shape=(n, n))
+    return (sa.Hamiltonian(exchange, np.asarray(c["field"], dtype=np.float64)), float(c["energy"]),
+            np.asarray(c["signs"], dtype=np.uint64))
+
+
+def load_ground_state(filename: str):
+    """``(ground_state f64[N], energy, basis_representatives u64[N])`` of a SpinED output file
+    (common.py:772-780): ``/hamiltonian/eigenvectors`` (first vector), ``/hamiltonian/eigenvalues``
+    and ``/basis/representatives``."""
+    h5py = _h5py_or_none()
+    if h5py is not None:
+        with h5py.File(filename, "r") as f:
+            vectors = np.asarray(f["/hamiltonian/eigenvectors"], dtype=np.float64)
+            values = np.asarray(f["/hamiltonian/eigenvalues"], dtype=np.float64)
+            representatives = np.asarray(f["/basis/representatives"], dtype=np.uint64)
+    else:
+        from . import hdf5_lite
+
+        tree = hdf5_lite.read(filename)
+        vectors = np.asarray(hdf5_lite.lookup(tree, "/hamiltonian/eigenvectors"), dtype=np.float64)
+        values = np.asarray(hdf5_lite.lookup(tree, "/hamiltonian/eigenvalues"), dtype=np.float64)
+        representatives = np.asarray(hdf5_lite.lookup(tree, "/basis/representatives"), dtype=np.uint64)
+    ground_state = vectors.squeeze()
+    if ground_state.ndim > 1:
+        ground_state = ground_state[0, :]
+    return np.ascontiguousarray(ground_state), float(values.reshape(-1)[0]), representatives
+
+
+def save_ground_state(filename: str, ground_state, energy: float, representatives) -> None:
+    """A file in the layout :func:`load_ground_state` (and the reference) reads."""
+    content = {
+        "hamiltonian": {"eigenvectors": np.asarray(ground_state, dtype=np.float64).reshape(1, -1),
+                        "eigenvalues": np.asarray([energy], dtype=np.float64)},
+        "basis": {"representatives": np.asarray(representatives, dtype=np.uint64)},
+    }
+    h5py = _h5py_or_none()
+    if h5py is not None:
+        with h5py.File(filename, "w") as out:
+            for group, members in content.items():
+                g = out.create_group(group)
+                for key, value in members.items():
+                    g[key] = value
+        return
+    from . import hdf5_lite
+
+    hdf5_lite.write(filename, content)
 
 
 def load_hamiltonian(filename: str):

@@ -66,6 +66,12 @@
 #ifndef ASP_ABS_LDS
 #define ASP_ABS_LDS 1
 #endif
+#ifndef ASP_SIGN_SHR
+#define ASP_SIGN_SHR 1  // byte layout: v_lshrrev (fast VOP2) + v_lshl_or instead of v_lshlrev + v_bfi
+#endif
+#ifndef ASP_PHILOX_SKIP
+#define ASP_PHILOX_SKIP 1  // no random numbers for a block none of whose proposals needs one
+#endif
 #ifndef ASP_MAX_THREADS
 #define ASP_MAX_THREADS 1024  // launch bound of the sweep kernel (VGPR budget = 512 / waves per SIMD)
 #endif
@@ -170,10 +176,19 @@ __device__ __forceinline__ double spin_factor(uint32_t spin_byte, int m) {
   if (m == 0) {
     hi = (spin_byte << 31) | 0x3FF00000u;  // v_lshl_or_b32: nothing but bit 0 survives the shift
   } else {
+#if ASP_SIGN_SHR
+    // replica m's bit to bit 0 with a RIGHT shift — a plain VOP2, 2.5 SIMD cycles per wave64 on
+    // this chip, where every left shift and every VOP3 costs 4.3-4.4
+    // (profiles/r02_issue_rate_probe.txt) — then the m = 0 instruction: 12.1 cycles per term
+    // and replica with the FMA instead of 13.3
+    const uint32_t down = spin_byte >> m;
+    asm("v_lshl_or_b32 %0, %1, 31, %2" : "=v"(hi) : "v"(down), "s"(0x3FF00000u));
+#else
     // bit 31 from the shifted byte, everything else from 1.0's high word: one v_bfi_b32
     // (hipcc folds the constant mask and emits v_and + v_or instead)
     const uint32_t shifted = spin_byte << (31 - m);
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hi) : "s"(0x80000000u), "v"(shifted), "v"(0x3FF00000u));
+#endif
   }
   return __hiloint2double(static_cast<int>(hi), 0);
 }
@@ -713,19 +728,36 @@ __device__ __forceinline__ void sa_sweep_body(const SweepArgs &a, const uint32_t
         }
         uint32_t flip = 0;
         bool open = false;  // some proposal of this lane is not a certain rejection
-        Philox4 rnd{};
-        uint32_t have = 0xFFFFFFFFu;
+        bool need = false;  // some proposal of this lane needs a random number
+        double de[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) {
           const double g = __dadd_rn(acc[m], h);
           const bool negative = (own >> (WIDE ? 8 * m + 7 : m)) & 1u;  // s = -1
-          const double de = __dmul_rn(negative ? 2.0 : -2.0, g);
-          bool accept;
+          de[m] = __dmul_rn(negative ? 2.0 : -2.0, g);
           if constexpr (DESCENT) {
-            accept = valid && de < 0.0;
-            open = open || accept;
+            open = open || (valid && de[m] < 0.0);
           } else {
-            open = open || (valid && !(__dmul_rn(beta, de) >= 23.0));
+            const bool maybe = valid && !(__dmul_rn(beta, de[m]) >= 23.0);  // not a certain rejection
+            open = open || maybe;
+            need = need || (maybe && !(de[m] <= 0.0));
+          }
+        }
+        // Random numbers only when some proposal of the block is undecided without one
+        // (dE <= 0 is accepted, beta * dE >= 23 rejected, whatever the draw): a wave-uniform
+        // branch around the 10 Philox rounds and the exp filter.  Counter-based RNG: skipping
+        // a draw changes nothing downstream.
+#if ASP_PHILOX_SKIP
+        const bool draw = !DESCENT && __ballot(need) != 0ull;
+#else
+        const bool draw = !DESCENT;
+#endif
+        uint32_t accept_mask = 0;
+        if (draw) {
+          Philox4 rnd{};
+          uint32_t have = 0xFFFFFFFFu;
+#pragma unroll
+          for (int m = 0; m < M; ++m) {
             const uint32_t r = r0 + m;
             if (m == 0 || (r >> 2) != have) {
               have = r >> 2;
@@ -736,31 +768,42 @@ __device__ __forceinline__ void sa_sweep_body(const SweepArgs &a, const uint32_t
 #endif
             }
             const uint32_t word = pick_word(rnd, r & 3u);
-            const double u = __dmul_rn(__dadd_rn(static_cast<double>(word), 0.5), 0x1p-32);
+            bool accept;
 #if ASP_ABL_NO_ACCEPT
-            asm volatile("" ::"v"(de), "v"(u));
+            asm volatile("" ::"v"(de[m]), "v"(word));
             accept = false;
-#else
-#if ASP_ABL_NO_EXP
-            accept = valid && (de <= 0.0 || u < __dmul_rn(beta, de) * 1e-3);
+#elif ASP_ABL_NO_EXP
+            accept = valid && (de[m] <= 0.0 || word < static_cast<uint32_t>(__dmul_rn(beta, de[m])));
 #elif ASP_EXP_FILTER == 2
-            accept = valid && (de <= 0.0 || metropolis_accept_word(word, __dmul_rn(beta, de)));
-#elif ASP_EXP_FILTER
-            accept = valid && (de <= 0.0 || metropolis_accept(u, __dmul_rn(beta, de)));
+            accept = valid && (de[m] <= 0.0 || metropolis_accept_word(word, __dmul_rn(beta, de[m])));
 #else
-            accept = valid && (de <= 0.0 || u < expneg(__dmul_rn(beta, de)));
+            const double u = __dmul_rn(__dadd_rn(static_cast<double>(word), 0.5), 0x1p-32);
+#if ASP_EXP_FILTER
+            accept = valid && (de[m] <= 0.0 || metropolis_accept(u, __dmul_rn(beta, de[m])));
+#else
+            accept = valid && (de[m] <= 0.0 || u < expneg(__dmul_rn(beta, de[m])));
 #endif
 #endif
+            accept_mask |= (accept ? 1u : 0u) << m;
           }
-          if (accept) {
+        } else {
+#pragma unroll
+          for (int m = 0; m < M; ++m) {
+            const bool accept = valid && (DESCENT ? de[m] < 0.0 : de[m] <= 0.0);
+            accept_mask |= (accept ? 1u : 0u) << m;
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          if ((accept_mask >> m) & 1u) {
             flip |= 1u << m;
             // rint(dE * 2^S) as int64: |dE * 2^S| < 2^51 by the plan's choice of S, so adding
             // 1.5 * 2^52 leaves the rounded integer in the mantissa (ties to even, = rint)
 #if ASP_MAGIC_RINT
-            q_acc[m] += __double_as_longlong(__dadd_rn(__dmul_rn(de, a.scale), 0x1.8p52)) -
+            q_acc[m] += __double_as_longlong(__dadd_rn(__dmul_rn(de[m], a.scale), 0x1.8p52)) -
                         0x4338000000000000ll;
 #else
-            q_acc[m] += static_cast<long long>(__builtin_rint(__dmul_rn(de, a.scale)));
+            q_acc[m] += static_cast<long long>(__builtin_rint(__dmul_rn(de[m], a.scale)));
 #endif
             n_acc[m] += 1;
           }
@@ -1885,8 +1928,11 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
     ASP_HIP_TRY(hipGetLastError());
   }
   ASP_HIP_TRY(hipEventRecord(p->ev[3], s));
-  ASP_TRY(d_x.download(out_x, static_cast<uint64_t>(repetitions) * words, s));
-  ASP_TRY(d_e.download(out_e, repetitions, s));
+  // hipMemcpyDefault: out_x / out_e may be host pointers (the usual call) or device pointers
+  // (distributed.py hands over RCCL-ready tensors, so a gather needs no host round trip)
+  ASP_HIP_TRY(hipMemcpyAsync(out_x, d_x.ptr, static_cast<uint64_t>(repetitions) * words * sizeof(uint64_t),
+                             hipMemcpyDefault, s));
+  ASP_HIP_TRY(hipMemcpyAsync(out_e, d_e.ptr, repetitions * sizeof(double), hipMemcpyDefault, s));
   p->last_tracked.assign(repetitions, 0);
   p->last_accepted.assign(repetitions, 0);
   ASP_HIP_TRY(hipMemcpyAsync(p->last_tracked.data(), d_tracked.ptr, repetitions * sizeof(int64_t),
@@ -2145,20 +2191,24 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
     }
     return kNumClasses - 1;
   };
-  // ---- replicas per workgroup: as many as still fill the chip (rows are then shared by more
-  // replicas); 16 wavefronts per CU are resident at this kernel's register budget ----
+  // ---- replicas per workgroup ----
   int m = 1;
   if (const char *env = std::getenv("ASP_BATCH_M")) {  // tuning aid
     const int forced = std::atoi(env);
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8) m = forced;
   } else {
-    for (int cand : {8, 4, 2}) {
+    // Measured on the production mix (tools/tune_batch.py, K log-uniform in [1e2, 1e4], 64 chains
+    // x 5120 sweeps): four replicas per workgroup — the word layout with its one-instruction
+    // signs — is fastest from 128 problems (127 G flips/s against 101 with eight, 95 with two,
+    // 62 with one) to 512 (161, the same as eight); fewer replicas per workgroup only when four
+    // would leave SIMDs without a wavefront.
+    for (int cand : {4, 2}) {
       uint64_t waves = 0;
       for (const BatchEntry &e : entries) {
         const uint32_t reps = items[e.item].repetitions;
         waves += static_cast<uint64_t>((reps + cand - 1) / cand) * kClasses[class_of(e.waves)];
       }
-      if (waves >= static_cast<uint64_t>(num_cus) * 16u) {
+      if (waves >= static_cast<uint64_t>(num_cus) * 4u) {
         m = cand;
         break;
       }

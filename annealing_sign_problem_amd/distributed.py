@@ -136,9 +136,14 @@ def all_gather_rows(local: np.ndarray, counts, group=None) -> np.ndarray:
 
 def anneal_sharded(hamiltonian, seed: int, betas: np.ndarray, repetitions: int, x0=None,
                    group=None):
-    """Run this rank's block of chains, then gather: (xs[R, words], es[R]) on every rank."""
-    from .annealer import anneal_raw
+    """Run this rank's block of chains, then gather: (xs[R, words], es[R]) on every rank.
 
+    With RCCL (backend ``nccl``) the kernel's results are copied device-to-device into the
+    tensors that are gathered — no host round trip before the collective; with gloo (CPU tests)
+    they go through host arrays."""
+    from . import annealer
+
+    import torch
     import torch.distributed as dist
 
     check_device_binding(group)
@@ -146,17 +151,30 @@ def anneal_sharded(hamiltonian, seed: int, betas: np.ndarray, repetitions: int, 
     me = dist.get_rank(group)
     offset, count = shard_range(repetitions, world, me)
     words = (hamiltonian.size + 63) // 64
-    if count > 0:
-        xs, es = anneal_raw(hamiltonian, seed, betas, count, offset, x0)
-    else:
-        xs = np.zeros((0, words), dtype=np.uint64)
-        es = np.zeros(0, dtype=np.float64)
     counts = [shard_range(repetitions, world, k)[1] for k in range(world)]
-    # one payload: [packed spins | energy bits] per chain
-    payload = np.concatenate(
-        [np.ascontiguousarray(xs, dtype=np.uint64).view(np.int64).reshape(count, words),
-         np.ascontiguousarray(es, dtype=np.float64).view(np.int64).reshape(count, 1)], axis=1)
-    full = all_gather_rows(payload, counts, group)
+    most = max(max(counts), 1)
+    if dist.get_backend(group) == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
+        # one payload row per chain: [packed spins | energy bits]
+        xs_t = torch.zeros((most, max(words, 1)), dtype=torch.int64, device=device)
+        es_t = torch.zeros((most,), dtype=torch.float64, device=device)
+        if count > 0:
+            annealer.anneal_raw_into(hamiltonian, seed, betas, count, offset, x0,
+                                     xs_t.data_ptr(), es_t.data_ptr())
+        mine = torch.cat([xs_t[:, :words], es_t.view(torch.int64).unsqueeze(1)], dim=1).contiguous()
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        full = torch.cat([parts[k][: counts[k]] for k in range(world)], dim=0).cpu().numpy()
+    else:
+        if count > 0:
+            xs, es = annealer.anneal_raw(hamiltonian, seed, betas, count, offset, x0)
+        else:
+            xs = np.zeros((0, words), dtype=np.uint64)
+            es = np.zeros(0, dtype=np.float64)
+        payload = np.concatenate(
+            [np.ascontiguousarray(xs, dtype=np.uint64).view(np.int64).reshape(count, words),
+             np.ascontiguousarray(es, dtype=np.float64).view(np.int64).reshape(count, 1)], axis=1)
+        full = all_gather_rows(payload, counts, group)
     xs_all = np.ascontiguousarray(full[:, :words]).view(np.uint64)
     es_all = np.ascontiguousarray(full[:, words]).view(np.float64)
     return xs_all, es_all

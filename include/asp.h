@@ -305,7 +305,9 @@ int asp_sa_set_field_cache(asp_sa_plan *p, int enable);
  * (ceil(K/64) words, bit set = +1).  Outputs (host): out_x[repetitions *
  * ceil(K/64)] best configuration of each chain, out_e[repetitions] its energy.
  * The result depends only on (J, h, seed, betas, global replica id), not on the
- * launch geometry or the number of GPUs. */
+ * launch geometry or the number of GPUs.  out_x / out_e may also be DEVICE pointers on the
+ * library's device (the copies use hipMemcpyDefault): the multi-GPU layer gathers them over
+ * RCCL without a host round trip. */
 int asp_sa_anneal(asp_sa_plan *p, uint64_t seed, double const *betas,
                   uint32_t num_sweeps, uint32_t repetitions, uint32_t replica_offset,
                   uint64_t const *x0, uint64_t *out_x, double *out_e);

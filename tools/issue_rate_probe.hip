@@ -41,7 +41,9 @@ enum Kind {
   kFmaF64, kAddF64, kMulF64, kFmaF32, kBfi, kLshlrev, kLshlOr, kXor, kAddU32, kMulHiU32, kMulLoU32,
   kOrSdwa, kExpF32, kCvtF64U32, kCvtF32F64, kMixBytes, kMixWide, kMixPhilox,
   kMov, kAnd, kOr, kCndmask, kCmp, kLshrrev, kSub, kAndOr, kOr3, kAdd3, kBfe, kPerm, kAlignbit,
-  kMadU64, kXorSdwa, kFmacF64, kAddF32, kMulF32, kMixXorAdd, kXad, kLshlAdd, kNumKinds
+  kMadU64, kXorSdwa, kFmacF64, kAddF32, kMulF32, kMixXorAdd, kXad, kLshlAdd,
+  kCndmaskSgpr, kCmpCndmask, kLshlrev31, kLshlrevVar, kCvtUbyte, kFmaak, kMulU24, kReadlane,
+  kLshlAddU64, kMovB64, kMbcnt, kMixShrLshlOrFma, kAshrrev, kNumKinds
 };
 
 static const char *kNames[kNumKinds] = {
@@ -55,10 +57,16 @@ static const char *kNames[kNumKinds] = {
     "v_lshrrev_b32", "v_sub_u32", "v_and_or_b32", "v_or3_b32", "v_add3_u32", "v_bfe_u32",
     "v_perm_b32", "v_alignbit_b32", "v_mad_u64_u32", "v_xor_b32_sdwa (byte select, no preserve)",
     "v_fmac_f64 (VOP2)", "v_add_f32", "v_mul_f32", "mix: xor (sign flip of hi word) + add_f64",
-    "v_xad_u32", "v_lshl_add_u32"};
+    "v_xad_u32", "v_lshl_add_u32",
+    "v_cndmask_b32_e64 (sgpr-pair mask)", "mix: v_cmp_lt_u32 vcc + v_cndmask_b32 vcc",
+    "v_lshlrev_b32 by 31", "v_lshlrev_b32 by vgpr", "v_cvt_f32_ubyte1", "v_fmaak_f32",
+    "v_mul_u32_u24", "v_readlane_b32 + v_writelane_b32", "v_lshl_add_u64", "v_mov_b64",
+    "v_mbcnt_lo + v_mbcnt_hi", "mix: lshrrev + lshl_or + fma_f64 (byte layout, proposed)",
+    "v_ashrrev_i32"};
 // instructions per "unit" of the unrolled body (mixes issue several)
 static const int kPerUnit[kNumKinds] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 3, 2, 4,
-                                        1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1};
+                                        1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1,
+                                        1, 2, 1, 1, 1, 1, 1, 2, 1, 1, 2, 3, 1};
 
 template <int KIND>
 __global__ __launch_bounds__(1024) void probe(unsigned long long *cycles, uint32_t iters,
@@ -177,6 +185,39 @@ __global__ __launch_bounds__(1024) void probe(unsigned long long *cycles, uint32
           asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(x[j]) : "v"(y), "v"(z));
         } else if constexpr (KIND == kLshlAdd) {
           asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(x[j]) : "v"(y));
+        } else if constexpr (KIND == kCndmaskSgpr) {
+          asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x[j]) : "v"(y), "s"(0x5555AAAA3333CCCCull));
+        } else if constexpr (KIND == kCmpCndmask) {
+          asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %1, vcc"
+                       : "+v"(x[j]) : "v"(y), "v"(z) : "vcc");
+        } else if constexpr (KIND == kLshlrev31) {
+          asm volatile("v_lshlrev_b32 %0, 31, %1" : "=v"(x[j]) : "v"(y));
+        } else if constexpr (KIND == kLshlrevVar) {
+          asm volatile("v_lshlrev_b32 %0, %1, %0" : "+v"(x[j]) : "v"(z));
+        } else if constexpr (KIND == kCvtUbyte) {
+          asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(f[j]) : "v"(x[j]));
+        } else if constexpr (KIND == kFmaak) {
+          asm volatile("v_fmaak_f32 %0, %0, %1, 0x3ff00000" : "+v"(f[j]) : "v"(g));
+        } else if constexpr (KIND == kMulU24) {
+          asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x[j]) : "v"(y));
+        } else if constexpr (KIND == kReadlane) {
+          uint32_t sv;
+          asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sv) : "v"(x[j]));
+          asm volatile("v_writelane_b32 %0, %1, 5" : "+v"(x[j]) : "s"(sv));
+        } else if constexpr (KIND == kLshlAddU64) {
+          asm volatile("v_lshl_add_u64 %0, %0, 3, %1" : "+v"(a[j]) : "v"(b));
+        } else if constexpr (KIND == kMovB64) {
+          asm volatile("v_mov_b64 %0, %1" : "=v"(a[j]) : "v"(b));
+        } else if constexpr (KIND == kMbcnt) {
+          asm volatile("v_mbcnt_lo_u32_b32 %0, -1, %0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "+v"(x[j]));
+        } else if constexpr (KIND == kMixShrLshlOrFma) {
+          uint32_t t, hi;
+          asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(t) : "v"(x[j]));
+          asm volatile("v_lshl_or_b32 %0, %1, 31, %2" : "=v"(hi) : "v"(t), "v"(z));
+          const double factor = __hiloint2double(static_cast<int>(hi), 0);
+          asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(a[j]) : "v"(b), "v"(factor));
+        } else if constexpr (KIND == kAshrrev) {
+          asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(x[j]));
         }
       }
     }
@@ -280,6 +321,19 @@ int main() {
   rc |= run_kind<kMixXorAdd>(num_cus, d_cycles, d_sink, iters);
   rc |= run_kind<kXad>(num_cus, d_cycles, d_sink, iters);
   rc |= run_kind<kLshlAdd>(num_cus, d_cycles, d_sink, iters);
+  rc |= run_kind<kCndmaskSgpr>(num_cus, d_cycles, d_sink, iters);
+  rc |= run_kind<kCmpCndmask>(num_cus, d_cycles, d_sink, iters);
+  rc |= run_kind<kLshlrev31>(num_cus, d_cycles, d_sink, iters);
+  rc |= run_kind<kLshlrevVar>(num_cus, d_cycles, d_sink, iters);
+  rc |= run_kind<kCvtUbyte>(num_cus, d_cycles, d_sink, iters);
+  rc |= run_kind<kFmaak>(num_cus, d_cycles, d_sink, iters);
+  rc |= run_kind<kMulU24>(num_cus, d_cycles, d_sink, iters);
+  rc |= run_kind<kReadlane>(num_cus, d_cycles, d_sink, iters);
+  rc |= run_kind<kLshlAddU64>(num_cus, d_cycles, d_sink, iters);
+  rc |= run_kind<kMovB64>(num_cus, d_cycles, d_sink, iters);
+  rc |= run_kind<kMbcnt>(num_cus, d_cycles, d_sink, iters);
+  rc |= run_kind<kMixShrLshlOrFma>(num_cus, d_cycles, d_sink, iters);
+  rc |= run_kind<kAshrrev>(num_cus, d_cycles, d_sink, iters);
   (void)hipFree(d_cycles);
   (void)hipFree(d_sink);
   return rc;

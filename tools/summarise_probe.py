@@ -21,7 +21,12 @@ NAMES = ["v_fma_f64", "v_add_f64", "v_mul_f64", "v_fma_f32", "v_bfi_b32", "v_lsh
          "v_lshrrev_b32", "v_sub_u32", "v_and_or_b32", "v_or3_b32", "v_add3_u32", "v_bfe_u32",
          "v_perm_b32", "v_alignbit_b32", "v_mad_u64_u32", "v_xor_b32_sdwa (byte select)",
          "v_fmac_f64 (VOP2)", "v_add_f32", "v_mul_f32", "mix xor(hi word) + add_f64",
-         "v_xad_u32", "v_lshl_add_u32"]
+         "v_xad_u32", "v_lshl_add_u32",
+         "v_cndmask_b32_e64 (sgpr-pair mask)", "mix v_cmp_lt_u32 vcc + v_cndmask_b32 vcc",
+         "v_lshlrev_b32 by 31", "v_lshlrev_b32 by vgpr", "v_cvt_f32_ubyte1", "v_fmaak_f32",
+         "v_mul_u32_u24", "v_readlane_b32 + v_writelane_b32", "v_lshl_add_u64", "v_mov_b64",
+         "v_mbcnt_lo + v_mbcnt_hi", "mix lshrrev+lshl_or+fma_f64 (byte layout, new)",
+         "v_ashrrev_i32"]
 ITERS, UNROLL = 20000, 32
 dispatches = collections.OrderedDict()
 for f in glob.glob(os.path.join(prof, "**", "*_counter_collection.csv"), recursive=True):
