@@ -90,6 +90,8 @@ SIGNATURES = {
     "asp_operator_create": (c_int, [ctypes.c_uint32, ctypes.c_uint32, c_void_p, c_void_p, c_void_p,
                                     ctypes.POINTER(c_void_p)]),
     "asp_operator_destroy": (None, [c_void_p]),
+    "asp_operator_set_symmetry": (c_int, [c_void_p, c_u32, c_void_p, c_i32]),
+    "asp_operator_state_info": (c_int, [c_void_p, c_u64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "asp_operator_unique_targets": (c_int, [c_void_p]),
     "asp_operator_max_connections": (ctypes.c_uint32, [c_void_p]),
     "asp_operator_apply": (c_int, [c_void_p, c_u64, c_void_p, c_u64, c_void_p, c_void_p, c_void_p,

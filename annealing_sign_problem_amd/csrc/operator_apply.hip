@@ -302,6 +302,97 @@ __global__ __launch_bounds__(kThreads) void k_scatter_first(const uint64_t *__re
   if (flag[i]) out[position[i]] = sorted[i];
 }
 
+// ---------------------------------------------------------------------------
+// sector-0 symmetry-adapted bases (annealing_sign_problem_amd/symmetry.py)
+// ---------------------------------------------------------------------------
+// Representative = smallest image under the group; norm^2 = (sum of the characters of the
+// stabiliser) / |G|.  One lane per state, all lanes walk the permutations together, so the
+// destination table (u8[P][64], site i -> table[g][i]) is read with scalar loads.  Spin inversion
+// needs no second walk: the flipped image is the complement of the plain one.
+
+struct SymmetryArgs {
+  const uint8_t *table;  // [num_permutations][64]
+  uint32_t num_permutations;
+  uint32_t number_spins;
+  int32_t inversion;  // 0, +1, -1
+  uint64_t mask;      // low number_spins bits
+};
+
+struct StateInfo {
+  uint64_t representative;
+  double character;  // of an element mapping the state onto its representative
+  double norm;       // 0: the state is outside the sector
+};
+
+__device__ __forceinline__ StateInfo state_info(const SymmetryArgs &g, uint64_t x) {
+  uint64_t best = x;  // the identity is element 0
+  int32_t stabiliser = 0;
+  bool through_flip = false;
+  for (uint32_t e = 0; e < g.num_permutations; ++e) {
+    const uint8_t *dst = g.table + static_cast<size_t>(e) * 64u;
+    uint64_t y = 0;
+    for (uint32_t i = 0; i < g.number_spins; ++i) {
+      y |= ((x >> i) & 1ull) << dst[i];
+    }
+    stabiliser += y == x ? 1 : 0;
+    if (y < best) {
+      best = y;
+      through_flip = false;
+    }
+    if (g.inversion != 0) {
+      const uint64_t z = ~y & g.mask;
+      stabiliser += z == x ? g.inversion : 0;
+      if (z < best) {
+        best = z;
+        through_flip = true;
+      }
+    }
+  }
+  const double order = static_cast<double>(g.num_permutations) * (g.inversion != 0 ? 2.0 : 1.0);
+  StateInfo out;
+  out.representative = best;
+  out.character = (through_flip && g.inversion < 0) ? -1.0 : 1.0;
+  // the same expression as the numpy reference: sqrt(max(stabiliser, 0) / |G|)
+  out.norm = sqrt(static_cast<double>(stabiliser > 0 ? stabiliser : 0) / order);
+  return out;
+}
+
+// norm of every source state (row)
+__global__ __launch_bounds__(kThreads) void k_source_norms(SymmetryArgs g,
+                                                          const uint64_t *__restrict__ keys,
+                                                          uint64_t n, double *__restrict__ norms) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (i >= n) return;
+  norms[i] = state_info(g, keys[i]).norm;
+}
+
+// Every emitted connection: target -> representative, coefficient -> c * chi * norm(target) /
+// norm(source).  The row of an entry is found by bisection in the offsets.
+__global__ __launch_bounds__(kThreads) void k_symmetrise(SymmetryArgs g,
+                                                        const int64_t *__restrict__ offsets,
+                                                        uint64_t num_rows,
+                                                        const double *__restrict__ source_norms,
+                                                        uint64_t total,
+                                                        uint64_t *__restrict__ other_keys,
+                                                        double *__restrict__ other_coeffs) {
+  const uint64_t e = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (e >= total) return;
+  uint64_t lo = 0, hi = num_rows;  // offsets[lo] <= e < offsets[hi]
+  while (hi - lo > 1) {
+    const uint64_t mid = (lo + hi) / 2;
+    if (static_cast<uint64_t>(offsets[mid]) <= e) {
+      lo = mid;
+    } else {
+      hi = mid;
+    }
+  }
+  const StateInfo info = state_info(g, other_keys[e]);
+  other_keys[e] = info.representative;
+  // numpy: values * character * norm / source_norm, left to right
+  other_coeffs[e] = __ddiv_rn(__dmul_rn(__dmul_rn(other_coeffs[e], info.character), info.norm),
+                              source_norms[lo]);
+}
+
 thread_local float g_last_ms = 0.0f;
 
 struct Timer {
@@ -340,6 +431,14 @@ struct asp_operator {
   bool unique_targets = true;
   std::vector<Bond> bonds;
   DeviceBuffer<Bond> d_bonds;
+  // symmetry-adapted basis (asp_operator_set_symmetry); num_permutations == 0: plain basis
+  uint32_t num_permutations = 0;
+  int32_t inversion = 0;
+  DeviceBuffer<uint8_t> d_table;
+  SymmetryArgs symmetry() const {
+    return SymmetryArgs{d_table.ptr, num_permutations, number_spins, inversion,
+                        number_spins >= 64 ? ~0ull : ((1ull << number_spins) - 1ull)};
+  }
 };
 
 namespace {
@@ -370,6 +469,21 @@ int count_connections(const asp_operator *op, uint64_t n, const uint64_t *keys, 
                              stream));
   ASP_HIP_TRY(hipStreamSynchronize(stream));
   w->total = static_cast<uint64_t>(total);
+  return ASP_OK;
+}
+
+// After k_apply<true>: representatives and rescaled coefficients for a symmetry-adapted basis.
+// Fails with ASP_ERR_INVALID when a source state lies outside the sector (norm 0).
+int symmetrise_batch(const asp_operator *op, uint64_t n, const ApplyBatch &w, uint64_t *d_other,
+                     double *d_coeffs, DeviceBuffer<double> *d_norms, hipStream_t stream) {
+  if (op->num_permutations == 0 || n == 0) return ASP_OK;
+  ASP_TRY(d_norms->alloc(n));
+  const SymmetryArgs g = op->symmetry();
+  hipLaunchKernelGGL(k_source_norms, dim3(grid_for(n, kThreads)), dim3(kThreads), 0, stream, g,
+                     w.d_keys.ptr, n, d_norms->ptr);
+  hipLaunchKernelGGL(k_symmetrise, dim3(grid_for(w.total, kThreads)), dim3(kThreads), 0, stream, g,
+                     w.d_offsets.ptr, n, d_norms->ptr, w.total, d_other, d_coeffs);
+  ASP_HIP_TRY(hipGetLastError());
   return ASP_OK;
 }
 
@@ -462,6 +576,94 @@ void asp_operator_destroy(asp_operator *op) {
   delete op;
 }
 
+int asp_operator_set_symmetry(asp_operator *op, uint32_t num_permutations, uint8_t const *table,
+                              int32_t spin_inversion) {
+  asp_clear_error();
+  ASP_TRY(check_operator(op));
+  if (spin_inversion < -1 || spin_inversion > 1) {
+    return asp::set_error(ASP_ERR_INVALID, "spin_inversion must be -1, 0 or 1");
+  }
+  if (num_permutations == 0 || !table) {
+    return asp::set_error(ASP_ERR_INVALID, "a group holds at least the identity");
+  }
+  for (uint32_t e = 0; e < num_permutations; ++e) {
+    uint64_t seen = 0;
+    for (uint32_t i = 0; i < op->number_spins; ++i) {
+      const uint32_t d = table[static_cast<size_t>(e) * 64 + i];
+      if (d >= op->number_spins || ((seen >> d) & 1ull)) {
+        return asp::set_error(ASP_ERR_INVALID, "element %u is not a permutation of the sites", e);
+      }
+      seen |= 1ull << d;
+    }
+    if (e == 0) {
+      for (uint32_t i = 0; i < op->number_spins; ++i) {
+        if (table[i] != i) return asp::set_error(ASP_ERR_INVALID, "element 0 must be the identity");
+      }
+    }
+  }
+  ASP_TRY(op->d_table.alloc(static_cast<size_t>(num_permutations) * 64));
+  ASP_TRY(op->d_table.upload(table, static_cast<size_t>(num_permutations) * 64, nullptr));
+  ASP_HIP_TRY(hipStreamSynchronize(nullptr));
+  op->num_permutations = num_permutations;
+  op->inversion = spin_inversion;
+  // equal targets are no longer excluded: two connections may share a representative
+  op->unique_targets = false;
+  return ASP_OK;
+}
+
+int asp_operator_state_info(asp_operator const *op, uint64_t n, uint64_t const *keys,
+                            uint64_t *representatives, double *characters, double *norms) {
+  asp_clear_error();
+  ASP_TRY(check_operator(op));
+  if (n == 0) return ASP_OK;
+  if (!keys) return asp::set_error(ASP_ERR_INVALID, "null keys");
+  if (op->num_permutations == 0) {
+    return asp::set_error(ASP_ERR_INVALID, "the operator's basis has no symmetries");
+  }
+  asp::ScopedStream scoped;
+  ASP_TRY(scoped.acquire());
+  hipStream_t stream = scoped.stream;
+  // one "row" per key with a single entry (the key itself, coefficient 1, source norm 1):
+  // k_symmetrise then leaves (representative, character * norm) behind
+  DeviceBuffer<uint64_t> d_keys;
+  DeviceBuffer<double> d_coeffs, d_ones;
+  DeviceBuffer<int64_t> d_offsets;
+  asp::StreamFence fence(stream);
+  ASP_TRY(d_keys.alloc(n));
+  ASP_TRY(d_coeffs.alloc(n));
+  ASP_TRY(d_ones.alloc(n));
+  ASP_TRY(d_offsets.alloc(n + 1));
+  std::vector<double> ones(n, 1.0);
+  std::vector<int64_t> iota(n + 1);
+  for (uint64_t i = 0; i <= n; ++i) iota[i] = static_cast<int64_t>(i);
+  ASP_TRY(d_keys.upload(keys, n, stream));
+  ASP_TRY(d_coeffs.upload(ones.data(), n, stream));
+  ASP_TRY(d_ones.upload(ones.data(), n, stream));
+  ASP_TRY(d_offsets.upload(iota.data(), n + 1, stream));
+  const SymmetryArgs g = op->symmetry();
+  if (norms) {
+    // norms alone come from k_source_norms; characters need the second pass
+    DeviceBuffer<double> d_norms;
+    ASP_TRY(d_norms.alloc(n));
+    hipLaunchKernelGGL(k_source_norms, dim3(grid_for(n, kThreads)), dim3(kThreads), 0, stream, g,
+                       d_keys.ptr, n, d_norms.ptr);
+    ASP_HIP_TRY(hipGetLastError());
+    ASP_TRY(d_norms.download(norms, n, stream));
+    ASP_HIP_TRY(hipStreamSynchronize(stream));
+  }
+  hipLaunchKernelGGL(k_symmetrise, dim3(grid_for(n, kThreads)), dim3(kThreads), 0, stream, g,
+                     d_offsets.ptr, n, d_ones.ptr, n, d_keys.ptr, d_coeffs.ptr);
+  ASP_HIP_TRY(hipGetLastError());
+  if (representatives) ASP_TRY(d_keys.download(representatives, n, stream));
+  std::vector<double> signed_norm(characters ? n : 0);
+  if (characters) ASP_TRY(d_coeffs.download(signed_norm.data(), n, stream));
+  ASP_HIP_TRY(hipStreamSynchronize(stream));
+  if (characters) {
+    for (uint64_t i = 0; i < n; ++i) characters[i] = signed_norm[i] < 0.0 ? -1.0 : 1.0;
+  }
+  return ASP_OK;
+}
+
 int asp_operator_unique_targets(asp_operator const *op) { return op && op->unique_targets ? 1 : 0; }
 
 uint32_t asp_operator_max_connections(asp_operator const *op) {
@@ -491,7 +693,7 @@ int asp_operator_apply(asp_operator const *op, uint64_t n, uint64_t const *keys,
                           (unsigned long long)w.total, (unsigned long long)capacity);
   }
   DeviceBuffer<uint64_t> d_other;
-  DeviceBuffer<double> d_coeffs;
+  DeviceBuffer<double> d_coeffs, d_norms;
   asp::StreamFence fence(stream);  // error exits wait for the stream before the buffers go
   ASP_TRY(d_other.alloc(w.total));
   ASP_TRY(d_coeffs.alloc(w.total));
@@ -500,6 +702,7 @@ int asp_operator_apply(asp_operator const *op, uint64_t n, uint64_t const *keys,
                        op->d_bonds.ptr, op->num_bonds, w.d_keys.ptr, n, w.d_offsets.ptr, nullptr,
                        d_other.ptr, d_coeffs.ptr);
     ASP_HIP_TRY(hipGetLastError());
+    ASP_TRY(symmetrise_batch(op, n, w, d_other.ptr, d_coeffs.ptr, &d_norms, stream));
   }
   ASP_TRY(timer.stop());
   ASP_TRY(d_other.download(other_keys, w.total, stream));
@@ -633,7 +836,7 @@ int asp_operator_extend(asp_operator const *op, uint64_t n, uint64_t const *keys
   const uint64_t N = w.total;
   if (N >= (1ull << 32)) return asp::set_error(ASP_ERR_TOO_LARGE, "more than 2^32 connections");
   DeviceBuffer<uint64_t> d_targets, d_sorted, d_unique;
-  DeviceBuffer<double> d_coeffs;  // written by k_apply<true>, not used here
+  DeviceBuffer<double> d_coeffs, d_norms;  // written by k_apply<true>, not used here
   DeviceBuffer<uint32_t> d_flag;
   DeviceBuffer<int64_t> d_pos, d_scratch;
   DeviceBuffer<uint8_t> d_temp;
@@ -648,6 +851,8 @@ int asp_operator_extend(asp_operator const *op, uint64_t n, uint64_t const *keys
                      op->d_bonds.ptr, op->num_bonds, w.d_keys.ptr, n, w.d_offsets.ptr, nullptr,
                      d_targets.ptr, d_coeffs.ptr);
   ASP_HIP_TRY(hipGetLastError());
+  // symmetry-adapted basis: the extension is the set of the targets' REPRESENTATIVES
+  ASP_TRY(symmetrise_batch(op, n, w, d_targets.ptr, d_coeffs.ptr, &d_norms, stream));
   size_t temp_bytes = 0;
   ASP_HIP_TRY(rocprim::radix_sort_keys(nullptr, temp_bytes, d_targets.ptr, d_sorted.ptr, N, 0,
                                        op->number_spins, stream));

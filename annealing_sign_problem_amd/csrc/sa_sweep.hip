@@ -1530,10 +1530,9 @@ void choose_launch(const asp_sa_plan *p, uint32_t repetitions, int *m_out, int *
   if (!threads) {
     // one wavefront per block of the LARGEST colour class (DSATUR classes are skewed, the
     // first is the biggest), at most 16
-    // 16 wavefronts pay once a colour step is many rounds long; below ~80 blocks per colour
-    // 12 (three per SIMD) finish the same rounds sooner (measured: +7 % at K = 1e4, +5 % at
-    // 3e4, -4 % at 5e4; tools/tune_sweep.py --threads)
-    const uint32_t most = widest >= 80 ? 16u : 12u;
+    // (round 1 preferred 12 wavefronts below ~80 blocks per colour; with this round's accept
+    // phase 16 are faster at every size: K = 1e4 180 -> 198 G flips/s, 3e4 238 -> 253, two boxes)
+    const uint32_t most = 16u;
     threads = static_cast<int>(std::min<uint32_t>(widest, most)) * 64;
   }
   *m_out = m;
@@ -2163,7 +2162,7 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
     const uint32_t widest = widest_color(L);
     BatchEntry e{};
     e.item = i;
-    e.waves = std::min<uint32_t>(widest, widest >= 80 ? 16u : 12u);
+    e.waves = std::min<uint32_t>(widest, 16u);
     e.work = static_cast<double>(it.num_sweeps) * static_cast<double>(L.ell_off.back() + L.num_blocks);
     entries.push_back(e);
   }
@@ -2191,17 +2190,15 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
     }
     return kNumClasses - 1;
   };
-  // ---- replicas per workgroup ----
-  int m = 1;
-  if (const char *env = std::getenv("ASP_BATCH_M")) {  // tuning aid
-    const int forced = std::atoi(env);
-    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) m = forced;
-  } else {
-    // Measured on the production mix (tools/tune_batch.py, K log-uniform in [1e2, 1e4], 64 chains
-    // x 5120 sweeps): four replicas per workgroup — the word layout with its one-instruction
-    // signs — is fastest from 128 problems (127 G flips/s against 101 with eight, 95 with two,
-    // 62 with one) to 512 (161, the same as eight); fewer replicas per workgroup only when four
-    // would leave SIMDs without a wavefront.
+  // ---- replicas per workgroup, per class ----
+  // Measured on the production mix (tools/tune_batch.py, K log-uniform in [1e2, 1e4], 64 chains x
+  // 5120 sweeps): four replicas per workgroup — the word layout with its one-instruction signs —
+  // is fastest from 64 problems (86 G flips/s against 73 with two) over 128 (127 against 101
+  // with eight, 95 with two, 62 with one) to 512 (161, the same as eight); fewer replicas per
+  // workgroup only when four would leave SIMDs without a wavefront.
+  int m_of_class[kNumClasses];
+  {
+    int m = 1;
     for (int cand : {4, 2}) {
       uint64_t waves = 0;
       for (const BatchEntry &e : entries) {
@@ -2213,7 +2210,26 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
         break;
       }
     }
+    for (int c = 0; c < kNumClasses; ++c) m_of_class[c] = m;
+    // (fewer replicas per workgroup for the classes of the largest problems, to shorten the
+    // batch's longest workgroup, was measured and LOSES: 123 -> 97 G flips/s at 128 problems,
+    // 157 -> 120 at 512; the word layout's efficiency outweighs the shorter tail)
+    if (const char *env = std::getenv("ASP_BATCH_BIG_M")) {  // tuning aid
+      const int forced = std::atoi(env);
+      if (forced == 1 || forced == 2 || forced == 4 || forced == 8) {
+        for (int c = 0; c < kNumClasses; ++c) {
+          if (kClasses[c] >= 8) m_of_class[c] = forced;
+        }
+      }
+    }
+    if (const char *env = std::getenv("ASP_BATCH_M")) {  // tuning aid
+      const int forced = std::atoi(env);
+      if (forced == 1 || forced == 2 || forced == 4 || forced == 8) {
+        for (int c = 0; c < kNumClasses; ++c) m_of_class[c] = forced;
+      }
+    }
   }
+  auto m_of = [&](const BatchEntry &e) { return m_of_class[class_of(e.waves)]; };
   // ---- per-problem buffer offsets ----
   struct Offsets {
     uint64_t best, stat, cache, partial, e, x, groups, padded;
@@ -2224,6 +2240,7 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
   for (size_t k = 0; k < entries.size(); ++k) {
     const asp_sa_batch_item &it = items[entries[k].item];
     const asp::SaHostLayout &L = it.plan->host;
+    const uint64_t m = static_cast<uint64_t>(m_of(entries[k]));
     const uint64_t groups = (it.repetitions + m - 1) / m, padded = groups * m;
     const uint64_t words = (L.num_spins + 63) / 64;
     off[k] = Offsets{n_best, n_stat, n_cache, n_partial, n_e, n_x, groups, padded};
@@ -2269,7 +2286,8 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
   std::vector<BatchSlot> h_chains;
   h_chains.reserve(n_e);
   size_t energy_lds = 0;
-  std::vector<bool> wide_ok(kNumClasses, m == 4);
+  std::vector<bool> wide_ok(kNumClasses);
+  for (int c = 0; c < kNumClasses; ++c) wide_ok[c] = m_of_class[c] == 4;
   for (size_t k = 0; k < entries.size(); ++k) {
     const asp_sa_plan *p = items[entries[k].item].plan;
     if (!(p->allow_wide && p->ell_col4.ptr && sweep_lds_bytes(p->host, kWide) <= max_lds)) {
@@ -2401,7 +2419,7 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
     if (wide_ok[c]) {
       kernel = k_sa_sweep_batch<4, kWide>;
     } else {
-      switch (m) {
+      switch (m_of_class[c]) {
         case 1: kernel = k_sa_sweep_batch<1, kBytes>; break;
         case 2: kernel = k_sa_sweep_batch<2, kBytes>; break;
         case 4: kernel = k_sa_sweep_batch<4, kBytes>; break;
@@ -2460,7 +2478,7 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
     p->last_accepted.assign(h_accepted.begin() + off[k].stat,
                             h_accepted.begin() + off[k].stat + it.repetitions);
     const int c = class_of(entries[k].waves);
-    p->last_m = wide_ok[c] ? 4 : m;
+    p->last_m = m_of_class[c];
     p->last_layout = wide_ok[c] ? kWide : kBytes;
     p->last_threads = static_cast<int>(64u * kClasses[c]);
     p->last_groups = static_cast<int>(off[k].groups);

@@ -1,13 +1,15 @@
-"""Symmetry-free spin-1/2 bases and two-site operators in numpy.
+"""Spin-1/2 bases (plain and sector-0 symmetry-adapted) and two-site operators in numpy.
 
 The reference gets these from ``lattice_symmetries`` (annealing_sign_problem/
 common.py:9; ``ls.SpinBasis``, ``ls.Operator``), a third-party C library that is
 not part of the reference tree.  This module restates the subset the coupling
 build consumes — the call surface at common.py:29,38,86,96,283,786-787,817 — for
-bases WITHOUT lattice symmetries (``symmetries: []``, e.g.
-physical_systems/heisenberg_kagome_16.yaml:1-4), so that tests and benchmarks
-can produce real ``batched_apply`` outputs.  Symmetry-adapted bases
-(kagome_36, pyrochlore) are out of scope.
+bases without lattice symmetries (``symmetries: []``, e.g.
+physical_systems/heisenberg_kagome_16.yaml:1-4) and for symmetry-adapted bases whose
+generators are all in sector 0, with or without spin inversion (heisenberg_kagome_18.yaml:4,
+heisenberg_kagome_36.yaml:7-29, heisenberg_pyrochlore_2x2x2.yaml:1-17; :mod:`.symmetry`).
+The numpy code here is the host reference (exact diagonalisation, tests); the same action
+runs on the GPU through :class:`DeviceOperator` (csrc/operator_apply.hip).
 
 Conventions (unpinned against lattice_symmetries, which is unavailable): bit
 ``i`` of a basis state is site ``i``, 1 = up; a two-site matrix acts on
@@ -30,13 +32,16 @@ SIGMA_DOT_SIGMA = np.array(
 
 
 class SpinBasis:
-    """All bit strings of ``number_spins`` sites, optionally at fixed hamming weight."""
+    """All bit strings of ``number_spins`` sites, optionally at fixed hamming weight; with a
+    :class:`~.symmetry.SymmetryGroup` the basis states are the orbit REPRESENTATIVES of
+    non-zero norm (the smallest state of each orbit)."""
 
-    def __init__(self, number_spins: int, hamming_weight: Optional[int] = None):
+    def __init__(self, number_spins: int, hamming_weight: Optional[int] = None, group=None):
         if not 0 < number_spins <= 64:
             raise ValueError("number_spins must be in 1..64")
         self.number_spins = int(number_spins)
         self.hamming_weight = None if hamming_weight is None else int(hamming_weight)
+        self.group = None if (group is None or group.is_trivial) else group
         self._states: Optional[np.ndarray] = None
 
     def build(self, representatives: Optional[np.ndarray] = None) -> None:
@@ -47,7 +52,8 @@ class SpinBasis:
         if w is None:
             if n > 26:
                 raise ValueError("refusing to enumerate 2^{} states".format(n))
-            self._states = np.arange(1 << n, dtype=np.uint64)
+            states = np.arange(1 << n, dtype=np.uint64)
+            self._states = states if self.group is None else self.group.representatives(states)
             return
         count = 1
         for k in range(w):
@@ -58,6 +64,8 @@ class SpinBasis:
             (sum(1 << b for b in bits) for bits in combinations(range(n), w)),
             dtype=np.uint64, count=count)
         states.sort()
+        if self.group is not None:
+            states = self.group.representatives(states)
         self._states = states
 
     @property
@@ -105,13 +113,11 @@ class Operator:
     @classmethod
     def from_config(cls, config: dict) -> "Operator":
         """``{"basis": {...}, "hamiltonian": {"terms": [{"matrix", "sites"}]}}``: the
-        schema of physical_systems/*.yaml (symmetries must be empty)."""
+        schema of physical_systems/*.yaml (lattice symmetries in sector 0, spin inversion +-1)."""
+        from . import symmetry
+
         b = config["basis"]
-        if b.get("symmetries"):
-            raise ValueError("symmetry-adapted bases are not supported")
-        if b.get("spin_inversion") not in (None, 0):
-            raise ValueError("spin-inversion sectors are not supported")
-        basis = SpinBasis(b["number_spins"], b.get("hamming_weight"))
+        basis = SpinBasis(b["number_spins"], b.get("hamming_weight"), symmetry.group_from_config(b))
         terms = [Term(np.asarray(t["matrix"]), [tuple(s) for s in t["sites"]])
                  for t in config["hamiltonian"]["terms"]]
         return cls(basis, terms)
@@ -135,7 +141,8 @@ class Operator:
         if getattr(self, "_device", None) is None:
             if not self.is_real:
                 raise ValueError("the HIP operator needs real matrices")
-            self._device = DeviceOperator(self.basis.number_spins, *self.bond_table())
+            self._device = DeviceOperator(self.basis.number_spins, *self.bond_table(),
+                                          group=self.basis.group)
         return self._device
 
     # -- action on basis states ------------------------------------------------
@@ -175,7 +182,18 @@ class Operator:
         out = np.zeros((row.shape[0], 8), dtype=np.uint64)
         out[:, 0] = np.concatenate(targets)[order]
         counts = np.bincount(row, minlength=n).astype(np.int64)
-        return out, np.concatenate(coeffs)[order], counts
+        values = np.concatenate(coeffs)[order]
+        if self.basis.group is not None:
+            # symmetry-adapted basis: every target is replaced by its representative and the
+            # coefficient by c * chi(g) * norm(target) / norm(source)   (symmetry.py)
+            group = self.basis.group
+            _, _, source_norm = group.state_info(spins)
+            if np.any(source_norm == 0):
+                raise ValueError("a state outside the symmetry sector was passed to batched_apply")
+            rep, character, norm = group.state_info(out[:, 0])
+            out[:, 0] = rep
+            values = values * character * norm / np.repeat(source_norm, counts)
+        return out, values, counts
 
     def apply(self, spin):
         other, coeffs, _ = self.batched_apply(np.array([spin], dtype=np.uint64))
@@ -190,8 +208,11 @@ class Operator:
         rows = np.searchsorted(states, other[:, 0])
         ok = (rows < states.shape[0])
         ok[ok] &= states[rows[ok]] == other[ok, 0]
-        if not ok.all():
+        # (in a symmetry sector with a character -1 a connection can point at an orbit of zero
+        # norm: its coefficient is exactly 0 and it is simply absent from the basis)
+        if not (ok | (coeffs == 0)).all():
             raise ValueError("operator leaves the basis")
+        rows, cols, coeffs = rows[ok], cols[ok], coeffs[ok]
         matrix = scipy.sparse.coo_matrix((coeffs, (rows, cols)), shape=(states.shape[0],) * 2)
         return matrix.tocsr()
 
@@ -221,7 +242,7 @@ class DeviceOperator:
     on the GPU (csrc/operator_apply.hip).  No CPU fallback: construction fails without a GPU."""
 
     def __init__(self, number_spins: int, site_a: np.ndarray, site_b: np.ndarray,
-                 matrices: np.ndarray):
+                 matrices: np.ndarray, group=None):
         import ctypes
 
         from . import _lib
@@ -234,6 +255,10 @@ class DeviceOperator:
             int(number_spins), int(site_a.shape[0]), _lib.ptr(site_a), _lib.ptr(site_b),
             _lib.ptr(matrices), ctypes.byref(handle)))
         self._handle = handle
+        if group is not None:
+            table = group.device_table()
+            _lib.check(self._lib.asp_operator_set_symmetry(
+                handle, int(table.shape[0]), _lib.ptr(table), int(group.spin_inversion)))
         self.number_spins = int(number_spins)
         self.unique_targets = bool(self._lib.asp_operator_unique_targets(handle))
         self.max_connections = int(self._lib.asp_operator_max_connections(handle))
@@ -272,6 +297,18 @@ class DeviceOperator:
                                                 _lib.ptr(counts), ctypes.byref(total)))
         t = int(total.value)
         return other[:t].copy(), coeffs[:t].copy(), counts[:n]
+
+    def state_info(self, keys) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """``(representative, character, norm)`` of every key (symmetry-adapted bases only)."""
+        _lib = self._lib_module
+        keys = np.ascontiguousarray(keys, dtype=np.uint64).reshape(-1)
+        n = keys.shape[0]
+        rep = np.zeros(max(n, 1), dtype=np.uint64)
+        character = np.zeros(max(n, 1), dtype=np.float64)
+        norm = np.zeros(max(n, 1), dtype=np.float64)
+        _lib.check(self._lib.asp_operator_state_info(self._handle, n, _lib.ptr(keys), _lib.ptr(rep),
+                                                     _lib.ptr(character), _lib.ptr(norm)))
+        return rep[:n], character[:n], norm[:n]
 
     def ising(self, keys, psi) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """COO ``(row i32, col i32, val f64)`` of ``0.5 * (M + M^T)`` sorted by (row, col)."""

@@ -162,6 +162,24 @@ int asp_operator_create(uint32_t number_spins, uint32_t num_bonds, uint8_t const
                         uint8_t const *site_b, double const *matrices, asp_operator **out);
 void asp_operator_destroy(asp_operator *op);
 
+/* Symmetry-adapted basis in the trivial sector of a group of site permutations, with optional
+ * global spin inversion of character spin_inversion = +1 / -1 (0: none) — the bases of
+ * physical_systems/heisenberg_kagome_36.yaml:7-29, heisenberg_pyrochlore_2x2x2.yaml:1-17 and
+ * heisenberg_kagome_18.yaml:4, which the reference gets from lattice_symmetries.
+ * table[e * 64 + i] = destination site of site i under element e, for ALL elements of the group
+ * (closed under composition; element 0 the identity).  Afterwards keys are orbit representatives
+ * (the smallest state of an orbit), asp_operator_apply returns for every connection the
+ * representative of the target and the coefficient c * chi(g) * norm(target) / norm(source),
+ * norm(s)^2 = (sum of the stabiliser's characters) / |G|, and asp_operator_extend the sorted
+ * unique representatives.  Equal targets within a row are not merged (asp_operator_ising is
+ * then unavailable: make_ising_model takes the asp_ising_elements route). */
+int asp_operator_set_symmetry(asp_operator *op, uint32_t num_permutations, uint8_t const *table,
+                              int32_t spin_inversion);
+/* (representative, character of a group element mapping the key onto it, norm) of n keys; any
+ * output may be NULL.  norm 0: the key's orbit is not part of the sector. */
+int asp_operator_state_info(asp_operator const *op, uint64_t n, uint64_t const *keys,
+                            uint64_t *representatives, double *characters, double *norms);
+
 /* 1 when every row's targets are pairwise distinct for every input state (distinct flip
  * masks), which asp_operator_ising requires; 0 otherwise. */
 int asp_operator_unique_targets(asp_operator const *op);

@@ -111,12 +111,19 @@ def export_models():
     import yaml
 
     models = {}
-    for name in ["heisenberg_kagome_16", "j1j2_square_4x4", "sk_16_1", "sk_16_2", "sk_16_3"]:
+    for name in ["heisenberg_kagome_16", "j1j2_square_4x4", "sk_16_1", "sk_16_2", "sk_16_3",
+                 "heisenberg_kagome_18", "heisenberg_kagome_36", "heisenberg_pyrochlore_2x2x2",
+                 "sk_32_1"]:
         with open(os.path.join(REFERENCE, "physical_systems", name + ".yaml")) as f:
             cfg = yaml.load(f, Loader=yaml.SafeLoader)
+        basis = {"number_spins": cfg["basis"]["number_spins"],
+                 "hamming_weight": cfg["basis"]["hamming_weight"],
+                 "symmetries": [{"permutation": s["permutation"], "sector": s["sector"]}
+                                for s in cfg["basis"].get("symmetries") or []]}
+        if cfg["basis"].get("spin_inversion") is not None:
+            basis["spin_inversion"] = cfg["basis"]["spin_inversion"]
         models[name] = {
-            "basis": {"number_spins": cfg["basis"]["number_spins"],
-                      "hamming_weight": cfg["basis"]["hamming_weight"], "symmetries": []},
+            "basis": basis,
             "hamiltonian": {"terms": [{"matrix": t["matrix"], "sites": t["sites"]}
                                       for t in cfg["hamiltonian"]["terms"]]},
         }

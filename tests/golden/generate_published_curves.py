@@ -13,7 +13,8 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-MODELS = ["heisenberg_kagome_16", "j1j2_square_4x4", "sk_16_1", "sk_16_2", "sk_16_3"]
+MODELS = ["heisenberg_kagome_16", "j1j2_square_4x4", "sk_16_1", "sk_16_2", "sk_16_3",
+          "heisenberg_kagome_18"]  # (kagome_18: symmetry-adapted basis, no round-1 measurement)
 TRIALS_R1 = {"heisenberg_kagome_16": 10, "j1j2_square_4x4": 10, "sk_16_1": 5, "sk_16_2": 5,
              "sk_16_3": 5}
 
@@ -31,7 +32,7 @@ for name in MODELS:
                 "residual_prob_mean": float(r["residual_prob_mean"]),
             }
     mine = os.path.join(ROOT, "profiles", "full_hilbert_space", "fhs_%s.csv" % name)
-    with open(mine) as f:
+    with open(mine if os.path.exists(mine) else os.devnull) as f:
         for r in csv.DictReader(f):
             k = int(r["number_sweeps"])
             if k in rows:

@@ -26,7 +26,9 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 POINTS = [("heisenberg_kagome_16", 100), ("heisenberg_kagome_16", 1600),
-          ("heisenberg_kagome_16", 25600), ("sk_16_1", 100), ("sk_16_1", 1600), ("sk_16_1", 25600)]
+          ("heisenberg_kagome_16", 25600), ("sk_16_1", 100), ("sk_16_1", 1600), ("sk_16_1", 25600),
+          # the symmetry-adapted basis of heisenberg_kagome_18.yaml:4 (24 310 representatives)
+          ("heisenberg_kagome_18", 100), ("heisenberg_kagome_18", 400)]
 TRIALS = 8
 _sims = {}
 
@@ -48,9 +50,10 @@ def test_success_probability_matches_published_curve(name, sweeps):
                         for trial in range(TRIALS)])
     acc, residual = results[:, 0].mean(), results[:, 2].mean()
     assert residual == acc, "P(residual <= 1e-12) and P(accuracy > 0.995) differ"
-    published, own = row["acc_prob_mean"], row["mi355x_r01_acc_prob_mean"]
+    published, own = row["acc_prob_mean"], row.get("mi355x_r01_acc_prob_mean")
     assert published - 0.03 <= acc <= published + 0.07, \
         "%s @ %d sweeps: %.4f vs published %.4f (%s)" % (name, sweeps, acc, published,
                                                         row["reference_line"])
-    assert abs(acc - own) <= 0.03, \
-        "%s @ %d sweeps: %.4f vs this repository's round-1 %.4f" % (name, sweeps, acc, own)
+    if own is not None:
+        assert abs(acc - own) <= 0.03, \
+            "%s @ %d sweeps: %.4f vs this repository's round-1 %.4f" % (name, sweeps, acc, own)
