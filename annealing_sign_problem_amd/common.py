@@ -436,9 +436,9 @@ def save_ground_state(filename: str, ground_state, energy: float, representative
 
 
 def load_hamiltonian(filename: str):
-    """The operator of a ``physical_systems/*.yaml`` file (common.py:783-788) for bases without
-    lattice symmetries; the result runs its action on the GPU.  Symmetry-adapted bases raise
-    ``ValueError`` (they need lattice_symmetries)."""
+    """The operator of a ``physical_systems/*.yaml`` file (common.py:783-788): plain bases and
+    symmetry-adapted ones whose generators are in sector 0, with or without spin inversion (every
+    shipped file); the result runs its action on the GPU.  Other sectors raise ``ValueError``."""
     import yaml
 
     from . import operators

@@ -308,7 +308,12 @@ observables: []
     assert abs(e0 + 8.0) < 1e-10          # 4-site Heisenberg ring in sigma.sigma units
     symmetric = text.replace("symmetries: []", "symmetries: [{permutation: [1, 2, 3, 0], sector: 0}]")
     path.write_text(symmetric)
-    with pytest.raises(ValueError):
+    sym = common.load_hamiltonian(str(path))  # translations in sector 0: representatives only
+    sym.basis.build()
+    assert sym.basis.states.tolist() == [0b0011, 0b0101]
+    assert abs(sym.ground_state()[0] + 8.0) < 1e-10  # the ring's ground state is translation-invariant
+    path.write_text(symmetric.replace("sector: 0", "sector: 1"))
+    with pytest.raises(ValueError):  # other sectors need complex characters: not supported
         common.load_hamiltonian(str(path))
     p = np.array([2, 0, 3, 1])
     assert common.invert_permutation(p).tolist() == [1, 3, 0, 2]
