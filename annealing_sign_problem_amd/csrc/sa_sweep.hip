@@ -2162,7 +2162,12 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
     const uint32_t widest = widest_color(L);
     BatchEntry e{};
     e.item = i;
-    e.waves = std::min<uint32_t>(widest, 16u);
+    // wavefronts per workgroup in a shared launch: 8 at most — smaller workgroups interleave
+    // better on a CU than the 16 a lone problem wants (128 problems: 109 -> 133 G flips/s, 512:
+    // 152 -> 185; tools/tune_batch.py)
+    uint32_t cap = 8u;
+    if (const char *env = std::getenv("ASP_BATCH_WAVES")) cap = static_cast<uint32_t>(std::atoi(env));  // tuning aid
+    e.waves = std::min<uint32_t>(widest, std::max(1u, std::min(16u, cap)));
     e.work = static_cast<double>(it.num_sweeps) * static_cast<double>(L.ell_off.back() + L.num_blocks);
     entries.push_back(e);
   }

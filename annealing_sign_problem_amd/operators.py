@@ -192,7 +192,13 @@ class Operator:
                 raise ValueError("a state outside the symmetry sector was passed to batched_apply")
             rep, character, norm = group.state_info(out[:, 0])
             out[:, 0] = rep
-            values = values * character * norm / np.repeat(source_norm, counts)
+            scale, source = character * norm, np.repeat(source_norm, counts)
+            if not np.any(values.imag):
+                # real arithmetic, (c * (chi * norm)) / norm(source) — the device kernel's
+                # sequence (numpy's complex division multiplies by a reciprocal instead)
+                values = ((values.real * scale) / source).astype(np.complex128)
+            else:
+                values = values * scale / source
         return out, values, counts
 
     def apply(self, spin):

@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 MODELS = ["heisenberg_kagome_16", "j1j2_square_4x4", "sk_16_1", "sk_16_2", "sk_16_3",
           "heisenberg_kagome_18"]  # (kagome_18: symmetry-adapted basis, no round-1 measurement)
 TRIALS_R1 = {"heisenberg_kagome_16": 10, "j1j2_square_4x4": 10, "sk_16_1": 5, "sk_16_2": 5,
-             "sk_16_3": 5}
+             "sk_16_3": 5, "heisenberg_kagome_18": 10}
+ROUND = {"heisenberg_kagome_18": 2}  # measured in round 2 (symmetry-adapted basis); others round 1
 
 out = {"source": "experiments/<model>.csv of twesterhout/annealing-sign-problem (make small)",
        "repetitions": 1024, "trials_published": 10, "models": {}}
@@ -36,9 +37,10 @@ for name in MODELS:
         for r in csv.DictReader(f):
             k = int(r["number_sweeps"])
             if k in rows:
-                rows[k]["mi355x_r01_acc_prob_mean"] = float(r["acc_prob_mean"])
-                rows[k]["mi355x_r01_acc_prob_std"] = float(r["acc_prob_std"])
-                rows[k]["mi355x_r01_trials"] = TRIALS_R1[name]
+                rows[k]["mi355x_acc_prob_mean"] = float(r["acc_prob_mean"])
+                rows[k]["mi355x_acc_prob_std"] = float(r["acc_prob_std"])
+                rows[k]["mi355x_trials"] = TRIALS_R1[name]
+                rows[k]["mi355x_round"] = ROUND.get(name, 1)
     out["models"][name] = {str(k): rows[k] for k in sorted(rows)}
 with open(os.path.join(HERE, "published_sa_curves.json"), "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)

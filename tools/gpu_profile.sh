@@ -15,6 +15,11 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -- python $ARGS > $OUT/pmc_l2.log 2>&1 || exit 3
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/pmc_sq1 -- python $ARGS > $OUT/pmc_sq1.log 2>&1 || exit 4
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmc_sq2 -- python $ARGS > $OUT/pmc_sq2.log 2>&1 || exit 5
-python tools/summarise_profile.py $OUT ${1:-r01} > $OUT/summary.log 2>&1
-cp profiles/${1:-r01}_* profiles/traffic.json $OUT/ 2>/dev/null
+# the clock the sweep kernel really ran at (sum over the 8 XCDs / 8 / kernel time)
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_clock -- python $ARGS > $OUT/pmc_clock.log 2>&1 || exit 8
+# the coupling-build / operator / sparsify kernels and the batched anneal: kernel-trace stats
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/build_trace -- python tools/profile_build.py > $OUT/build_trace.log 2>&1 || exit 9
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/batch_trace -- python tools/tune_batch.py 128 > $OUT/batch_trace.log 2>&1 || exit 10
+python tools/summarise_profile.py $OUT ${1:-r02} > $OUT/summary.log 2>&1
+cp profiles/${1:-r02}_* profiles/traffic.json profiles/sweep_counters.json $OUT/ 2>/dev/null
 tail -5 $OUT/bench_trace.log | cut -c1-600

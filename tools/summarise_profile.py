@@ -69,6 +69,45 @@ if "FETCH_SIZE" in pmc:
     hit, miss = pmc.get("TCC_HIT_sum"), pmc.get("TCC_MISS_sum")
     if hit and miss:
         summary["sweep_l2_hit_rate"] = hit["mean"] / (hit["mean"] + miss["mean"])
+# 4. the VALU-issue side of the roofline: instructions per flip, measured clock
+pmc.update(counters("pmc_clock", "k_sa_sweep"))
+if "SQ_INSTS_VALU" in pmc:
+    sys.path.insert(0, root)
+    import bench  # the workload's shape: sizes, chains and sweeps per launch
+
+    flips_per_launch = sum(bench.CLUSTER_SIZES) / len(bench.CLUSTER_SIZES) * 1024 * 128
+    clock = None
+    if "GRBM_GUI_ACTIVE" in pmc:
+        clock = pmc["GRBM_GUI_ACTIVE"]["mean"] / 8.0 / pmc["GRBM_GUI_ACTIVE"]["mean_ns"]
+    with open(os.path.join(out_dir, "sweep_counters.json"), "w") as o:
+        json.dump({
+            "tag": tag, "kernel": "k_sa_sweep", "command": "bench.py (default workload)",
+            "valu_insts_per_launch": pmc["SQ_INSTS_VALU"]["mean"],
+            "flips_per_launch": flips_per_launch,
+            "valu_insts_per_flip": pmc["SQ_INSTS_VALU"]["mean"] / flips_per_launch,
+            "active_valu_quad_cycles_per_launch": pmc.get("SQ_ACTIVE_INST_VALU", {}).get("mean"),
+            "cycles_per_valu_inst": 4.35,
+            "cycles_per_valu_inst_source": "profiles/%s_issue_rate_probe.txt: 4.2-4.4 SIMD cycles per "
+                                           "wave64 instruction for every class the kernel's hot "
+                                           "phases issue at 3-4 waves per SIMD (f64 FMA/add, VOP3 "
+                                           "integer, SDWA, left shifts, 32x32 multiplies); plain VOP2 "
+                                           "and/or/xor/add/right-shift 2.5; v_exp_f32 8.3" % tag,
+            "clock_ghz": clock,
+            "method": "rocprofv3 --pmc SQ_INSTS_VALU (per launch, mean over the launches of the three "
+                      "cluster sizes) / flip attempts per launch; clock = GRBM_GUI_ACTIVE / 8 / kernel "
+                      "time (separate pass)"}, o, indent=1)
+    summary["sweep_valu"] = {"insts_per_flip": pmc["SQ_INSTS_VALU"]["mean"] / flips_per_launch,
+                             "clock_ghz": clock}
+# 5. build-side and batched kernels: kernel-trace stats copied as they are
+for sub, name in [("build_trace", "build_kernel_stats"), ("batch_trace", "batch_kernel_stats")]:
+    for f in glob.glob(os.path.join(prof, sub, "**", "*_kernel_stats.csv"), recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        if not rows:
+            continue
+        with open(os.path.join(out_dir, "%s_%s.csv" % (tag, name)), "w") as o:
+            w = csv.DictWriter(o, fieldnames=rows[0].keys())
+            w.writeheader()
+            w.writerows(rows)
 with open(os.path.join(out_dir, "%s_summary.json" % tag), "w") as o:
     json.dump(summary, o, indent=1)
 print(json.dumps(summary, indent=1))

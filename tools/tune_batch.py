@@ -28,21 +28,14 @@ for n in counts:
           flush=True)
     flips = float(sum(sizes)) * 64 * 5120
     sa.anneal_batch(hams[:4], seed=1, number_sweeps=8, repetitions=64)
-    for m, big in (("auto", "auto"), ("4", "4"), ("4", "2"), ("4", "1"), ("8", "2"), ("2", "2")):
-        for key, value in (("ASP_BATCH_M", m), ("ASP_BATCH_BIG_M", big)):
-            if value == "auto":
-                os.environ.pop(key, None)
-            else:
-                os.environ[key] = value
-        if m != "auto":
-            # ASP_BATCH_M forces every class; the big classes are then set separately
-            os.environ.pop("ASP_BATCH_M", None)
-            os.environ["ASP_BATCH_SMALL_M"] = m
+    for waves in ("8", "6", "4", "3", "2"):
+        os.environ["ASP_BATCH_WAVES"] = waves
         t0 = time.perf_counter()
         sa.anneal_batch(hams, seed=12345, number_sweeps=5120, repetitions=64)
         dt = time.perf_counter() - t0
-        print("  M=%-4s big M=%-4s  %.3f s wall, sweep kernels %.1f ms, %.1f G flips/s, %.0f problems/s" % (
-            m, big, dt, lib.asp_sa_batch_last_ms(), flips / dt / 1e9, n / dt), flush=True)
+        print("  wavefront cap %-3s  %.3f s wall, sweep kernels %.1f ms, %.1f G flips/s, %.0f problems/s" % (
+            waves, dt, lib.asp_sa_batch_last_ms(), flips / dt / 1e9, n / dt), flush=True)
+    os.environ.pop("ASP_BATCH_WAVES", None)
     os.environ.pop("ASP_BATCH_BIG_M", None)
     os.environ.pop("ASP_BATCH_SMALL_M", None)
     os.environ.pop("ASP_BATCH_M", None)

@@ -30,3 +30,20 @@ for k, kind in [(10000, "planted"), (100000, "planted"), (8192, "sk")]:
     m = others.shape[0]
     print("%s K=%d connections=%d nnz=%d: %.3f ms  %.2f Gconn/s  %.0f GB/s algorithmic (96 B/conn)" % (
         kind, k, m, nnz.value, ms, m / ms / 1e6, m * 96 / ms / 1e6), flush=True)
+    # the drop-in symbol itself with host pointers (ctypes call on prepared 512-bit arrays)
+    import time
+    n_rows = spins.shape[0]
+    row = np.empty(max(m, 1), np.uint32)
+    col = np.empty(max(m, 1), np.uint32)
+    el = np.empty(max(m, 1), np.float64)
+    fld = np.empty(max(n_rows, 1), np.float64)
+    times = []
+    for _ in range(6):
+        t0 = time.perf_counter()
+        _build_matrix.lib.build_matrix(n_rows, spins, counts, psi, others, coeffs, oc, opsi, row, col, el, fld)
+        times.append((time.perf_counter() - t0) * 1e3)
+    up = spins.nbytes + others.nbytes + 8 * (3 * n_rows + 2 * m)
+    down = 16 * int(nnz.value) + 8 * n_rows
+    print("   build_matrix(host pointers): %.2f ms median of 5 (first call %.1f ms); %.0f MB up + %.0f MB down "
+          "= %.1f ms at 63 GB/s" % (float(np.median(times[1:])), times[0], up / 1e6, down / 1e6,
+                                    (up + down) / 63e9 * 1e3), flush=True)
