@@ -380,9 +380,17 @@ def main():
     backend = os.environ.get("ASP_BENCH_BACKEND", "nccl")
     if os.environ.get("ASP_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
-    if world > 1:
+    # ASP_BENCH_FORCE_DIST=1: run the multi-rank code path (process group, RCCL gather of each
+    # rank's best chain, max-over-ranks timing) at world size 1 — the rehearsal of the N > 1
+    # path a one-GPU box allows (tests/test_gpu_rccl.py)
+    use_dist = world > 1 or os.environ.get("ASP_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
         dist.init_process_group(backend)
 
     from annealing_sign_problem_amd import _lib, synthetic
@@ -411,20 +419,41 @@ def main():
     sweep_ms = []
     accepted = []
 
+    on_device = use_dist and backend == "nccl"
+    if on_device:
+        # per cluster: the chains' results land in device tensors (D2D from the kernel's
+        # buffers), the best chain is picked there and gathered over RCCL: no host round trip
+        for c in clusters:
+            words = (c["J"].shape[0] + 63) // 64
+            c["xs_t"] = torch.zeros((replicas, words), dtype=torch.int64, device="cuda")
+            c["es_t"] = torch.zeros(replicas, dtype=torch.float64, device="cuda")
+
     def step(record):
         for c in clusters:
-            xs, es = sa.anneal_raw(c["ham"], 12345, c["betas"], replicas, offset)
+            if on_device:
+                sa.anneal_raw_into(c["ham"], 12345, c["betas"], replicas, offset, None,
+                                   c["xs_t"].data_ptr(), c["es_t"].data_ptr())
+                best = torch.argmin(c["es_t"])
+                mine = torch.cat([c["xs_t"][best], c["es_t"][best].view(1).view(torch.int64)])
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(parts, mine)
+                torch.stack(parts).cpu()  # every rank ends up with all ranks' best chains
+                # and, as at N = 1, with all of its own chains on the host (same work per rank)
+                c["xs_t"].cpu()
+                c["es_t"].cpu()
+            else:
+                xs, es = sa.anneal_raw(c["ham"], 12345, c["betas"], replicas, offset)
+                if use_dist:
+                    best = int(np.argmin(es))
+                    words = xs.shape[1]
+                    payload = np.concatenate([xs[best].view(np.int64).reshape(1, words),
+                                              np.array([[es[best]]]).view(np.int64)], axis=1)
+                    asp_dist.all_gather_rows(payload, [1] * world)
             if record:
                 sweep_ms.append((c, lib.asp_sa_last_sweep_ms(c["ham"].plan())))
-            if world > 1:
-                best = int(np.argmin(es))
-                words = xs.shape[1]
-                payload = np.concatenate([xs[best].view(np.int64).reshape(1, words),
-                                          np.array([[es[best]]]).view(np.int64)], axis=1)
-                asp_dist.all_gather_rows(payload, [1] * world)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -436,7 +465,7 @@ def main():
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -459,14 +488,18 @@ def main():
         kernel_flips = flips_per_step * args.steps / kernel_s
         traffic = traffic_from_profiles()
         counters = sweep_counters_from_profiles()
-        # every proposal evaluated: field cache and inert-block skipping off (results identical)
-        no_skip_ms = 0.0
-        for c in clusters:
-            _lib.check(lib.asp_sa_set_field_cache(c["ham"].plan(), 0))
-            sa.anneal_raw(c["ham"], 12345, c["betas"], replicas, offset)
-            no_skip_ms += lib.asp_sa_last_sweep_ms(c["ham"].plan())
-            _lib.check(lib.asp_sa_set_field_cache(c["ham"].plan(), 1))
-        kernel_flips_no_skip = flips_per_step / (no_skip_ms * 1e-3)
+        # every proposal evaluated: field cache and inert-block skipping off (results identical).
+        # Left out under --no-build, the form the rocprofv3 passes use, so that their per-launch
+        # averages cover the timed workload only.
+        kernel_flips_no_skip = None
+        if not args.no_build:
+            no_skip_ms = 0.0
+            for c in clusters:
+                _lib.check(lib.asp_sa_set_field_cache(c["ham"].plan(), 0))
+                sa.anneal_raw(c["ham"], 12345, c["betas"], replicas, offset)
+                no_skip_ms += lib.asp_sa_last_sweep_ms(c["ham"].plan())
+                _lib.check(lib.asp_sa_set_field_cache(c["ham"].plan(), 1))
+            kernel_flips_no_skip = flips_per_step / (no_skip_ms * 1e-3)
         # The sweep kernel is bound by VALU ISSUE, not by HBM (couplings are L2/MALL-resident
         # and shared by the replicas of a workgroup; spins never leave LDS): achieved = SIMD
         # issue cycles its VALU instructions occupy per second = (instructions per flip, PMC)
@@ -528,7 +561,8 @@ def main():
                 "launch": launch,
             },
             "roofline": roofline,
-            "value_no_skip": value * kernel_flips_no_skip / kernel_flips,
+            "value_no_skip": (value * kernel_flips_no_skip / kernel_flips
+                              if kernel_flips_no_skip else None),
         }
         if world == 1 and not args.no_cpu_baseline:
             cores = usable_cores()
@@ -540,7 +574,7 @@ def main():
             out["batched_small_clusters"] = bench_batched_clusters()
         print(json.dumps(out))
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

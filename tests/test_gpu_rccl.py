@@ -84,3 +84,45 @@ def test_pipeline_two_ranks_on_one_gpu_gloo(tmp_path):
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert proc.returncode == 0, proc.stdout + proc.stderr
     assert two.read_text() == single.read_text()
+
+
+def test_bench_multi_rank_path_at_world_size_one():
+    """bench.py's N > 1 code path (process group, device-tensor results, RCCL gather of each
+    rank's best chain, max-over-ranks timing) executed with RCCL at world size 1."""
+    import json
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, ASP_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--sizes", "3000,10000", "--replicas", "256", "--sweeps", "32", "--no-cpu-baseline",
+           "--no-build"]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    line = json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 1e9 and line["scaling"] == "weak"
+
+
+def test_bench_two_ranks_gloo_on_one_gpu():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` as the driver
+    launches it, rehearsed on one GPU (both ranks on device 0, gloo): rank discovery, global
+    replica ids per rank, barriers, max-over-ranks timing, one JSON line from rank 0."""
+    import json
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, ASP_BENCH_BACKEND="gloo", ASP_BENCH_SINGLE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--sizes", "3000,10000", "--replicas", "256",
+           "--sweeps", "32"]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 1e9
+    assert "cpu_baseline" not in line and "build" not in line  # N = 1 legs only

@@ -30,7 +30,7 @@ for _ in range(3):
     sym.device().apply(reps)
 model = common.make_ising_model(cluster[:30000], op, log_psi=np.log(amp[:30000]) + 0j)
 bigger = common.make_hamiltonian_extension(model, lambda s: synthetic.hashed_log_amplitudes(np.asarray(s)))
-for _ in range(3):
-    common.sparsify_using_global_cutoff(bigger, 2e-6, model.spins)
+for _ in range(3):  # (a cutoff small enough to keep the hashed-amplitude cluster connected)
+    common.sparsify_using_global_cutoff(bigger, 1e-12, model.spins)
 print("profile_build done: K=%d connections=%d, extension %d states" % (keys.shape[0], other.shape[0], bigger.size))
 _lib.shutdown()
