@@ -1,7 +1,8 @@
 # Thin wrappers around the Python entry points, with the parameters of the reference's targets
 # (reference Makefile:17-35 `small`, :101-141 `kagome_36` / `pyrochlore_32` / `sk_32_1`).  The
-# reference's inputs are HDF5 ground states it downloads; here the symmetry-free 16-site models of
-# annealing_sign_problem_amd/models.json are diagonalised on the spot.
+# 16- and 18-site models of annealing_sign_problem_amd/models.json are diagonalised on the spot;
+# the large ones need the HDF5 ground states the reference's Makefile downloads (:143-153), given
+# as DATA=<directory holding heisenberg_kagome_36.h5 ...>.
 PYTHON ?= python3
 SEED ?= 435834
 NOISE ?= 0
@@ -10,10 +11,11 @@ ORDER ?= 2
 NUMBER_SAMPLES ?= 1000
 JOBS ?= 8
 MODEL ?= heisenberg_kagome_16
-SMALL_MODELS = heisenberg_kagome_16 j1j2_square_4x4 sk_16_1 sk_16_2 sk_16_3
+SMALL_MODELS = heisenberg_kagome_16 heisenberg_kagome_18 j1j2_square_4x4 sk_16_1 sk_16_2 sk_16_3
+DATA ?= physical_systems/data-large
 OUT ?= experiments
 
-.PHONY: all build test test-gpu bench small clusters
+.PHONY: all build test test-gpu bench small clusters kagome_36 pyrochlore_32 sk_32_1
 all: build
 
 build:
@@ -43,5 +45,18 @@ clusters:
 	@mkdir -p $(OUT)/$(MODEL)/noise_$(NOISE)/cutoff_$(CUTOFF)
 	$(PYTHON) -m annealing_sign_problem_amd.sampled_components --model $(MODEL) --seed $(SEED) \
 		--output $(OUT)/$(MODEL)/noise_$(NOISE)/cutoff_$(CUTOFF)/$(MODEL).csv$(JOBID) \
+		--order $(ORDER) --noise $(NOISE) --no-annealing --global-cutoff $(CUTOFF) \
+		--number-samples $(NUMBER_SAMPLES) --jobs $(JOBS)
+
+# The reference's large targets (Makefile:101-141): greedy only, order $(ORDER), cutoff $(CUTOFF),
+# $(NUMBER_SAMPLES) sampled clusters (reference: 50000), on the model's own symmetry-adapted basis.
+kagome_36: LARGE = heisenberg_kagome_36
+pyrochlore_32: LARGE = heisenberg_pyrochlore_2x2x2
+sk_32_1: LARGE = sk_32_1
+kagome_36 pyrochlore_32 sk_32_1:
+	@test -f $(DATA)/$(LARGE).h5 || { echo "$(DATA)/$(LARGE).h5 not found: the ground states of the large models are downloaded inputs (reference Makefile:143-153); set DATA=<dir>"; exit 1; }
+	@mkdir -p $(OUT)/$(LARGE)/noise_$(NOISE)/cutoff_$(CUTOFF)
+	$(PYTHON) -m annealing_sign_problem_amd.sampled_components --model $(LARGE) --hdf5 $(DATA)/$(LARGE).h5 \
+		--seed $(SEED) --output $(OUT)/$(LARGE)/noise_$(NOISE)/cutoff_$(CUTOFF)/$(LARGE).csv$(JOBID) \
 		--order $(ORDER) --noise $(NOISE) --no-annealing --global-cutoff $(CUTOFF) \
 		--number-samples $(NUMBER_SAMPLES) --jobs $(JOBS)

@@ -39,13 +39,25 @@ CSV_COLUMNS = [
 class Simulation:
     """experiments/full_hilbert_space.py:23-44 (intended form)."""
 
-    def __init__(self, model_name: str):
-        models = synthetic.load_models()
-        if model_name not in models:
-            raise ValueError("unknown model '{}'; available: {}".format(model_name, sorted(models)))
-        self.hamiltonian = operators.Operator.from_config(models[model_name])
-        self.hamiltonian.basis.build()
-        self.energy, self.ground_state = self.hamiltonian.ground_state()
+    def __init__(self, model_name: str = None, yaml_filename: str = None, hdf5_filename: str = None):
+        if yaml_filename is not None:
+            # the reference's inputs (experiments/full_hilbert_space.py:24-29): operator from the
+            # YAML file, ground state and basis representatives from the SpinED output
+            self.hamiltonian = common.load_hamiltonian(yaml_filename)
+            hdf5_filename = hdf5_filename or yaml_filename.replace(".yaml", ".h5")
+        else:
+            models = synthetic.load_models()
+            if model_name not in models:
+                raise ValueError("unknown model '{}'; available: {}".format(model_name, sorted(models)))
+            self.hamiltonian = operators.Operator.from_config(models[model_name])
+        if hdf5_filename is not None:
+            ground_state, self.energy, representatives = common.load_ground_state(hdf5_filename)
+            order = np.argsort(representatives, kind="stable")
+            self.hamiltonian.basis.build(representatives[order])
+            self.ground_state = np.ascontiguousarray(ground_state[order])
+        else:
+            self.hamiltonian.basis.build()
+            self.energy, self.ground_state = self.hamiltonian.ground_state()
         log_psi_fn = common.ground_state_to_log_coeff_fn(self.ground_state, self.hamiltonian.basis)
         self.exact_model = common.make_ising_model(self.hamiltonian.basis.states, self.hamiltonian,
                                                    log_psi_fn=log_psi_fn)
@@ -88,10 +100,11 @@ def summarise(number_sweeps: int, results: np.ndarray) -> List:
 
 
 def run_experiment(model: str, sweeps: Sequence[int], repetitions: int, trials: int, seed: int,
-                   output: str, log=print) -> List[List]:
+                   output: str, log=print, yaml_filename: str = None,
+                   hdf5_filename: str = None) -> List[List]:
     if os.path.exists(output):
         raise ValueError("output file '{}' already exists".format(output))
-    simulation = Simulation(model)
+    simulation = Simulation(model, yaml_filename, hdf5_filename)
     log("model {}: K = {}, E0 = {:.12f}".format(model, simulation.exact_model.size, simulation.energy))
     with open(output, "w") as f:
         f.write(",".join(CSV_COLUMNS) + "\n")
@@ -113,7 +126,9 @@ def run_experiment(model: str, sweeps: Sequence[int], repetitions: int, trials: 
 
 def main(argv=None):
     parser = argparse.ArgumentParser(description="Test Simulated Annealing on a small system.")
-    parser.add_argument("--model", type=str, required=True)
+    parser.add_argument("--model", type=str, help="name in models.json (ground state by ED)")
+    parser.add_argument("--yaml", type=str, help="physical_systems/<model>.yaml of the reference")
+    parser.add_argument("--hdf5", type=str, help="SpinED output (default <yaml>.h5 with --yaml)")
     parser.add_argument("--output", type=str, required=True)
     parser.add_argument("--number-sweeps", type=str, required=True)
     parser.add_argument("--repetitions", type=int, default=1024)
@@ -121,7 +136,10 @@ def main(argv=None):
     parser.add_argument("--seed", type=int, default=12345)
     args = parser.parse_args(argv)
     sweeps = [int(s) for s in args.number_sweeps.split(",")]
-    run_experiment(args.model, sweeps, args.repetitions, args.trials, args.seed, args.output)
+    if (args.model is None) == (args.yaml is None):
+        raise SystemExit("give exactly one of --model and --yaml")
+    run_experiment(args.model, sweeps, args.repetitions, args.trials, args.seed, args.output,
+                   yaml_filename=args.yaml, hdf5_filename=args.hdf5)
 
 
 if __name__ == "__main__":

@@ -11,10 +11,10 @@ Same call sequence and CSV schema as the reference driver:
     score: accuracy / overlap / amplitude overlap   common.py:211-229; driver :719-723
     one CSV line of 6 * (order + 1) numbers         driver :681-693, 804-830
 
-Differences forced by the environment, not by design: the ground state comes from exact
-diagonalisation of a symmetry-free model named in ``models.json`` (the reference loads an HDF5
-file that its Makefile downloads), and the operator is :mod:`.operators` instead of
-``lattice_symmetries``.  Like the reference, all host-side randomness is numpy's global legacy
+Inputs: ``--yaml`` + ``--hdf5`` as in the reference (the operator of a physical_systems/*.yaml
+file, the ground state and basis representatives of the SpinED output its Makefile downloads),
+or ``--model``: a model bundled in ``models.json`` whose ground state is computed on the spot
+(16- and 18-site systems).  The operator is :mod:`.operators` instead of ``lattice_symmetries``.  Like the reference, all host-side randomness is numpy's global legacy
 stream seeded once with ``--seed`` (driver :776).
 """
 from __future__ import annotations
@@ -199,8 +199,14 @@ def process_clusters_batched(clusters: Sequence[np.ndarray], hamiltonian, ground
 
 def parse_command_line(argv=None):
     parser = argparse.ArgumentParser(description="Test Simulated Annealing on sampled clusters.")
-    parser.add_argument("--model", type=str, required=True,
-                        help="name in models.json (stands in for --yaml/--hdf5)")
+    parser.add_argument("--model", type=str,
+                        help="name in models.json; its ground state is computed by exact "
+                             "diagonalisation (16- and 18-site models)")
+    parser.add_argument("--yaml", type=str,
+                        help="physical_systems/<model>.yaml of the reference (driver :755)")
+    parser.add_argument("--hdf5", type=str,
+                        help="SpinED output with the ground state and the basis representatives "
+                             "(driver :757; default <yaml>.h5 when --yaml is given)")
     parser.add_argument("--output", type=str, required=True)
     parser.add_argument("--order", type=int, required=True)
     parser.add_argument("--noise", type=float, default=0)
@@ -224,6 +230,31 @@ def parse_command_line(argv=None):
     return parser.parse_args(argv)
 
 
+def load_input(args):
+    """``(hamiltonian, ground_state)``: either a bundled model diagonalised on the spot
+    (``--model``), or the reference's inputs (``--yaml`` + ``--hdf5``; common.py:791-803): the
+    operator of the YAML file, the first eigenvector of the HDF5 file and its list of basis
+    representatives, which becomes the basis."""
+    if (args.model is None) == (args.yaml is None):
+        raise SystemExit("give exactly one of --model and --yaml")
+    if args.model is not None:
+        models = synthetic.load_models()
+        if args.model not in models:
+            raise SystemExit("unknown model '{}'; available: {}".format(args.model, sorted(models)))
+        hamiltonian = operators.Operator.from_config(models[args.model])
+        if args.hdf5 is None:
+            hamiltonian.basis.build()
+            _, ground_state = hamiltonian.ground_state()
+            return hamiltonian, ground_state
+    else:
+        hamiltonian = common.load_hamiltonian(args.yaml)
+    hdf5 = args.hdf5 if args.hdf5 is not None else args.yaml.replace(".yaml", ".h5")
+    ground_state, _, representatives = common.load_ground_state(hdf5)
+    order = np.argsort(representatives, kind="stable")  # the basis keeps its states sorted
+    hamiltonian.basis.build(representatives[order])
+    return hamiltonian, np.ascontiguousarray(ground_state[order])
+
+
 def main(argv=None):
     from . import distributed as asp_dist
 
@@ -237,10 +268,7 @@ def main(argv=None):
     refuse = asp_dist.broadcast_object(writer and os.path.exists(args.output))
     if refuse:
         raise SystemExit("Output file '{}' already exists: refusing to overwrite".format(args.output))
-    models = synthetic.load_models()
-    hamiltonian = operators.Operator.from_config(models[args.model])
-    hamiltonian.basis.build()
-    _, ground_state = hamiltonian.ground_state()
+    hamiltonian, ground_state = load_input(args)
     if args.noise > 0:
         noisy_ground_state = common.add_noise_to_amplitudes(ground_state, args.noise)
     else:

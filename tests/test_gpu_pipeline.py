@@ -183,3 +183,31 @@ def test_batched_annealing_gives_identical_output(tmp_path):
     rows = [l for l in a.read_text().splitlines() if not l.startswith("#")]
     v = np.array([float(t) for t in rows[0].split(",")]).reshape(2, 6)
     assert np.all(np.isfinite(v[:, 3:5]))  # the SA columns are filled
+
+
+def test_pipeline_from_yaml_and_hdf5_inputs(tmp_path, models):
+    """The reference's own inputs (driver :755-757, common.py:791-803): --yaml names the operator,
+    --hdf5 holds the ground state and the basis representatives (here in shuffled order, which
+    the loader must undo).  Same output as the bundled-model route."""
+    import yaml
+
+    from annealing_sign_problem_amd import common, operators, sampled_components
+
+    name = "heisenberg_kagome_16"
+    op = operators.Operator.from_config(models[name])
+    op.basis.build()
+    energy, psi = op.ground_state()
+    shuffle = np.random.default_rng(0).permutation(op.basis.number_states)
+    h5 = tmp_path / (name + ".h5")
+    common.save_ground_state(str(h5), psi[shuffle], energy, op.basis.states[shuffle])
+    yml = tmp_path / (name + ".yaml")
+    yml.write_text(yaml.safe_dump(models[name]))
+    args = ["--order", "1", "--number-samples", "5", "--seed", "21", "--max-cluster-size", "200",
+            "--no-annealing"]
+    a, b, c = tmp_path / "model.csv", tmp_path / "yaml.csv", tmp_path / "model_h5.csv"
+    sampled_components.main(["--model", name, "--output", str(a)] + args)
+    sampled_components.main(["--yaml", str(yml), "--output", str(b)] + args)  # <yaml>.h5 by default
+    sampled_components.main(["--model", name, "--hdf5", str(h5), "--output", str(c)] + args)
+    assert a.read_text() == b.read_text() == c.read_text()
+    with pytest.raises(SystemExit):
+        sampled_components.main(["--output", str(tmp_path / "none.csv")] + args)

@@ -1,17 +1,26 @@
-"""Markdown table: P(acc > 0.995) of this repo's full-Hilbert-space runs next to the reference's
-published experiments/*.csv (build container only: reads /root/reference)."""
-import csv
+"""Markdown tables for DESIGN.md §6.1 from tests/golden/published_sa_curves.json: the reference's
+published P(accuracy > 0.995) next to this repository's MI355X measurement, with the z-score of
+the difference (standard errors of the two means combined)."""
+import json
+import math
+import os
 import sys
 
-for name in sys.argv[1:]:
-    mine = {int(r["number_sweeps"]): r for r in csv.DictReader(open("profiles/full_hilbert_space/fhs_%s.csv" % name))}
-    ref = {int(r["number_sweeps"]): r for r in csv.DictReader(open("/root/reference/experiments/%s.csv" % name))}
-    print("| %s: sweeps | reference P(acc>0.995) ± std | MI355X P(acc>0.995) ± std | reference = P(residual) | MI355X P(residual≤1e-12) |" % name)
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+data = json.load(open(os.path.join(root, "tests", "golden", "published_sa_curves.json")))
+for name in sys.argv[1:] or sorted(data["models"]):
+    rows = data["models"][name]
+    print("| %s: sweeps | reference ± std (10 trials) | MI355X ± std (trials) | difference | z |" % name)
     print("|---|---|---|---|---|")
-    for k in sorted(mine):
-        r, m = ref.get(k), mine[k]
-        print("| %d | %s | %.4f ± %.4f | %s | %.4f |" % (
-            k, "%.4f ± %.4f" % (float(r["acc_prob_mean"]), float(r["acc_prob_std"])) if r else "-",
-            float(m["acc_prob_mean"]), float(m["acc_prob_std"]),
-            "%.4f" % float(r["residual_prob_mean"]) if r else "-", float(m["residual_prob_mean"])))
+    for k in sorted(rows, key=int):
+        r = rows[k]
+        if "mi355x_acc_prob_mean" not in r:
+            continue
+        n = r["mi355x_trials"]
+        se = math.sqrt(r["acc_prob_std"] ** 2 / 10 + r["mi355x_acc_prob_std"] ** 2 / n)
+        diff = r["mi355x_acc_prob_mean"] - r["acc_prob_mean"]
+        z = "%+.1f" % (diff / se) if se > 0 else "—"
+        print("| %s | %.4f ± %.4f | %.4f ± %.4f (%d) | %+.4f | %s |" % (
+            k, r["acc_prob_mean"], r["acc_prob_std"], r["mi355x_acc_prob_mean"],
+            r["mi355x_acc_prob_std"], n, diff, z))
     print()
