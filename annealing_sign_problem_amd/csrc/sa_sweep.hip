@@ -456,8 +456,9 @@ __device__ __forceinline__ void store_word(uint64_t *p, uint64_t v) {
   }
 }
 
-template <int M, int LAYOUT>
-__device__ __forceinline__ void snapshot(const uint8_t *spins, const SweepArgs &a, uint32_t group,
+// (`Args` is SweepArgs, or SweepArgs in the constant address space: see k_sa_sweep_batch)
+template <int M, int LAYOUT, typename Args>
+__device__ __forceinline__ void snapshot(const uint8_t *spins, const Args &a, uint32_t group,
                                          uint32_t mask) {
   if constexpr (LAYOUT == kWide) {  // a wavefront per block: one ballot per replica
     const uint32_t *wide = reinterpret_cast<const uint32_t *>(spins);
@@ -512,8 +513,8 @@ __device__ __forceinline__ void snapshot(const uint8_t *spins, const SweepArgs &
 // greedy solver's relaxation; the final configuration is snapshotted after every sweep.
 // The whole anneal of one group of M replicas by one workgroup; `group` = index of the group
 // inside its problem (k_sa_sweep: the workgroup id; k_sa_sweep_batch: looked up in a table).
-template <int M, bool DESCENT, int LAYOUT>
-__device__ __forceinline__ void sa_sweep_body(const SweepArgs &a, const uint32_t group) {
+template <int M, bool DESCENT, int LAYOUT, typename Args>
+__device__ __forceinline__ void sa_sweep_body(const Args &a, const uint32_t group) {
   constexpr bool GLOBAL = LAYOUT == kGlobal;
   constexpr bool PACKED = LAYOUT == kBits || GLOBAL;  // one bit per position
   constexpr bool WIDE = LAYOUT == kWide;
@@ -934,8 +935,13 @@ __global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep_batch(BatchArgs b)
   const BatchSlot slot = b.slots[(blockIdx.x & 7u) * b.slots_per_xcd + (blockIdx.x >> 3)];
   const uint32_t problem = __builtin_amdgcn_readfirstlane(slot.problem);
   if (problem == 0xFFFFFFFFu) return;
-  const SweepArgs a = b.problems[problem];
-  sa_sweep_body<M, false, LAYOUT>(a, __builtin_amdgcn_readfirstlane(slot.group));
+  // The descriptor is read through the CONSTANT address space, like kernel arguments: the
+  // compiler may then re-load a field where it needs it instead of keeping all forty of them in
+  // registers (as a by-value copy it spilled SGPRs into VGPR lanes and VGPRs to scratch:
+  // 128 VGPRs + 68 B of scratch against the single-problem kernel's 112 and none; +8 %).
+  using ConstArgs = const SweepArgs __attribute__((address_space(4)));
+  ConstArgs *a = reinterpret_cast<ConstArgs *>(reinterpret_cast<uintptr_t>(b.problems + problem));
+  sa_sweep_body<M, false, LAYOUT>(*a, __builtin_amdgcn_readfirstlane(slot.group));
 }
 
 // ---------------------------------------------------------------------------
@@ -959,6 +965,7 @@ struct TeamArgs {
   uint64_t *flips;               // [num_teams][num_blocks] flip words of the running colour step
   long long *sums;               // [num_teams][3 rotating slots][2] {dq, accepted} of a sweep
   uint32_t *abort;               // set by the watchdog
+  uint32_t spin_limit;           // barrier polls before the watchdog gives up
 };
 
 constexpr uint32_t kTeamSpinLimit = 1u << 24;  // barrier polls before the watchdog gives up
@@ -980,7 +987,7 @@ __device__ __forceinline__ void team_barrier(const TeamArgs &ta, unsigned long l
     uint32_t polls = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       if (__hip_atomic_load(ta.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-      if (++polls > kTeamSpinLimit) {
+      if (++polls > ta.spin_limit) {
         __hip_atomic_store(ta.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
@@ -1858,6 +1865,10 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
     ta.s = args;
     ta.team_size = team;
     ta.num_teams = repetitions;
+    ta.spin_limit = kTeamSpinLimit;
+    if (const char *env = std::getenv("ASP_TEAM_SPIN_LIMIT")) {  // test hook: provoke the watchdog
+      ta.spin_limit = static_cast<uint32_t>(std::strtoul(env, nullptr, 10));
+    }
     const size_t head_bytes = static_cast<size_t>(repetitions) * 8 * 7 + 16;
     const size_t need = head_bytes + static_cast<size_t>(repetitions) * L.num_blocks * 8;
     if (need > p->team_area_bytes) {
@@ -2162,10 +2173,11 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
     const uint32_t widest = widest_color(L);
     BatchEntry e{};
     e.item = i;
-    // wavefronts per workgroup in a shared launch: 8 at most — smaller workgroups interleave
-    // better on a CU than the 16 a lone problem wants (128 problems: 109 -> 133 G flips/s, 512:
-    // 152 -> 185; tools/tune_batch.py)
-    uint32_t cap = 8u;
+    // wavefronts per workgroup in a shared launch: 4 at most — small workgroups interleave
+    // better on a CU than the 16 a lone problem wants (cap 16 / 8 / 4 on the production mix, 128
+    // problems: 109 / 133 / 152 G flips/s, 512: 152 / 200 / 213; tools/tune_batch.py.  A
+    // register budget for 5 or 6 wavefronts per SIMD instead of 4 was also tried: no gain)
+    uint32_t cap = 4u;
     if (const char *env = std::getenv("ASP_BATCH_WAVES")) cap = static_cast<uint32_t>(std::atoi(env));  // tuning aid
     e.waves = std::min<uint32_t>(widest, std::max(1u, std::min(16u, cap)));
     e.work = static_cast<double>(it.num_sweeps) * static_cast<double>(L.ell_off.back() + L.num_blocks);

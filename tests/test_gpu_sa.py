@@ -777,3 +777,50 @@ def test_batch_rejects_bad_items():
     with pytest.raises(_lib.AspError):
         sa.anneal_batch_raw([p["ham"] for p in problems], [1, 2], [problems[0]["betas"], bad], [2, 2])
     assert sa.anneal_batch_raw([], [], [], []) == []
+
+
+def test_team_watchdog_timeout_reruns_without_teams(monkeypatch):
+    """a barrier time-out used to be a hard error.  Provoked here (watchdog limit of one
+    poll): the call must come back with the correct chains through the one-workgroup-per-chain
+    kernel, and the plan must stay off teams afterwards."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    lib = _lib.load()
+    J, h, _ = _planted(6000, 77)
+    betas = np.geomspace(0.5, 5e4, 25)
+    ham = sa.Hamiltonian(J, h)
+    S = ham.info().energy_scale_exp
+    oxs, oes, _, _ = oracle.sa_anneal(J, h, 99, betas, 4, 0, None, S, num_threads=4)
+    _set_team(ham, 8)
+    monkeypatch.setenv("ASP_TEAM_SPIN_LIMIT", "0")
+    xs, es = sa.anneal_raw(ham, 99, betas, 4)
+    assert lib.asp_sa_last_layout(ham.plan()) != 4          # answered by the fallback
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    monkeypatch.delenv("ASP_TEAM_SPIN_LIMIT")
+    xs, es = sa.anneal_raw(ham, 99, betas, 4)                # teams stay off for this plan
+    assert lib.asp_sa_last_layout(ham.plan()) != 4
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+
+
+def test_team_is_refused_for_single_colour_plans():
+    """with one colour class (a diagonal-only J: no couplings at all) the team's single
+    barrier per sweep does not order a fast member's next flip words against a slow member's
+    read.  The launcher must not form teams there, forced or not; results equal the oracle's."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    n = 64 * 80  # 80 blocks in the one colour class: wide enough for the automatic rule
+    rng = np.random.default_rng(12)
+    J = scipy.sparse.diags(rng.normal(size=n)).tocsr()
+    field = rng.normal(size=n)
+    ham = sa.Hamiltonian(J, field)
+    assert ham.info().num_colors == 1
+    betas = np.geomspace(0.1, 50.0, 20)
+    S = ham.info().energy_scale_exp
+    oxs, oes, _, _ = oracle.sa_anneal(J, field, 5, betas, 3, 0, None, S, num_threads=3)
+    for team in (-1, 8):
+        _set_team(ham, team)
+        xs, es = sa.anneal_raw(ham, 5, betas, 3)
+        assert _lib.load().asp_sa_last_layout(ham.plan()) != 4
+        assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()

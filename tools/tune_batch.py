@@ -28,7 +28,7 @@ for n in counts:
           flush=True)
     flips = float(sum(sizes)) * 64 * 5120
     sa.anneal_batch(hams[:4], seed=1, number_sweeps=8, repetitions=64)
-    for waves in ("8", "6", "4", "3", "2"):
+    for waves in os.environ.get("TUNE_WAVES", "8,4").split(","):
         os.environ["ASP_BATCH_WAVES"] = waves
         t0 = time.perf_counter()
         sa.anneal_batch(hams, seed=12345, number_sweeps=5120, repetitions=64)
