@@ -83,14 +83,19 @@ class Hamiltonian:
     """
 
     def __init__(self, exchange, field):
-        matrix = scipy.sparse.csr_matrix(exchange, dtype=np.float64)
+        matrix = scipy.sparse.csr_matrix(exchange, dtype=np.float64, copy=True)  # (frozen below)
         if matrix.shape[0] != matrix.shape[1]:
             raise ValueError("'exchange' must be square, got {}".format(matrix.shape))
         matrix.sum_duplicates()
         matrix.sort_indices()
-        field = np.ascontiguousarray(field, dtype=np.float64)
+        field = np.array(field, dtype=np.float64, order="C", copy=True)
         if field.shape != (matrix.shape[0],):
             raise ValueError("'field' must have shape ({},)".format(matrix.shape[0]))
+        # The device plan is built once from these arrays and cached (the key is the identity of
+        # the two objects): they are frozen, so an in-place edit raises instead of leaving a stale
+        # plan behind.  Assigning a NEW matrix or field to the attributes rebuilds the plan.
+        for array in (matrix.data, matrix.indices, matrix.indptr, field):
+            array.flags.writeable = False
         self.exchange = matrix
         self.field = field
         self._plan = None

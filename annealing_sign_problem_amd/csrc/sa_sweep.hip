@@ -968,7 +968,10 @@ struct TeamArgs {
   uint32_t spin_limit;           // barrier polls before the watchdog gives up
 };
 
-constexpr uint32_t kTeamSpinLimit = 1u << 24;  // barrier polls before the watchdog gives up
+// Barrier polls before the watchdog gives up and the call is repeated without teams: ~ 5 s (a
+// barrier normally completes in ~ 5 us; members can only be kept waiting by other kernels
+// holding compute units — team launches themselves take turns).
+constexpr uint32_t kTeamSpinLimit = 1u << 22;
 
 __device__ __forceinline__ void team_barrier(const TeamArgs &ta, unsigned long long *counter,
                                              unsigned long long &target) {

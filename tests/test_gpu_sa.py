@@ -824,3 +824,32 @@ def test_team_is_refused_for_single_colour_plans():
         xs, es = sa.anneal_raw(ham, 5, betas, 3)
         assert _lib.load().asp_sa_last_layout(ham.plan()) != 4
         assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+
+
+def test_team_exchange_stress_against_single_workgroup_kernel():
+    """The team barrier orders its exchange with `s_waitcnt vmcnt(0)` + relaxed device-scope
+    atomics on fine-grained memory instead of release/acquire fences (a fence costs
+    20 us on this chip).  That rests on hardware behaviour, so it is stressed in the suite (a
+    reduced tools/stress_team.py): shapes x chain counts x team sizes x repeats, long ladders,
+    every result compared bit for bit with the one-workgroup-per-chain kernel."""
+    from annealing_sign_problem_amd import _lib, synthetic
+    from annealing_sign_problem_amd import annealer as sa
+
+    lib = _lib.load()
+    launches = 0
+    for k, degree, sweeps in ((60000, 12.0, 200), (25000, 6.0, 300)):
+        J, h, _ = synthetic.planted_cluster(k, seed=k, mean_degree=degree)
+        ham = sa.Hamiltonian(J, h)
+        info = ham.info()
+        betas = sa.make_schedule(info.beta0_auto, info.beta1_auto, sweeps)
+        for chains in (1, 7, 32):
+            _set_team(ham, 0)
+            ref_x, ref_e = sa.anneal_raw(ham, 99, betas, chains)
+            for team in (2, 4, 8):
+                _set_team(ham, team)
+                for _ in range(2):
+                    x, e = sa.anneal_raw(ham, 99, betas, chains)
+                    assert lib.asp_sa_last_layout(ham.plan()) == 4
+                    assert np.array_equal(x, ref_x) and e.tobytes() == ref_e.tobytes(), (k, chains, team)
+                    launches += 1
+    assert launches == 36

@@ -317,3 +317,21 @@ observables: []
         common.load_hamiltonian(str(path))
     p = np.array([2, 0, 3, 1])
     assert common.invert_permutation(p).tolist() == [1, 3, 0, 2]
+
+
+def test_hamiltonian_arrays_are_frozen_against_stale_plans():
+    """the plan cache is keyed on object identity, so an in-place edit of
+    exchange.data would silently anneal the old couplings.  The arrays are read-only instead."""
+    from annealing_sign_problem_amd import annealer as sa
+
+    m = scipy.sparse.random(30, 30, density=0.2, random_state=1, format="csr")
+    field = np.zeros(30)
+    ham = sa.Hamiltonian(m + m.T, field)
+    with pytest.raises(ValueError):
+        ham.exchange.data[0] = 5.0
+    with pytest.raises(ValueError):
+        ham.field[3] = 1.0
+    field[3] = 1.0  # the caller's own array is a different object (copied on construction)
+    assert ham.field[3] == 0.0
+    # the usual read-only uses of the reference keep working (common.py:444,654,674)
+    assert ham.exchange.tocoo().nnz == ham.exchange.nnz and ham.exchange[:5][:, :5].shape == (5, 5)
