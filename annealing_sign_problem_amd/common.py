@@ -165,12 +165,19 @@ def make_ising_model(
     psi = np.ascontiguousarray(psi.real)
     psi /= np.linalg.norm(psi)
 
-    if _on_device(quantum_hamiltonian) and quantum_hamiltonian.device().unique_targets:
-        # action, search, elements and (M + M^T)/2 fused in one pass on the GPU; the
-        # connections are never materialised (csrc/operator_apply.hip)
-        row, col, val = quantum_hamiltonian.device().ising(spins, psi)
-        matrix = scipy.sparse.coo_matrix((val, (row, col)), shape=(n, n))
-    else:
+    matrix = None
+    if _on_device(quantum_hamiltonian):
+        # action, search, elements and (M + M^T)/2 on the GPU, nothing materialised on the host
+        # (csrc/operator_apply.hip): the pair-fused pass for operators whose rows reach distinct
+        # states, the duplicate-keeping passes for symmetry-adapted bases.  Rows with duplicates
+        # AND one-directional matrix elements are refused: host route below.
+        try:
+            row, col, val = quantum_hamiltonian.device().ising(spins, psi)
+            matrix = scipy.sparse.coo_matrix((val, (row, col)), shape=(n, n))
+        except _lib.AspError as error:
+            if error.code != -3:
+                raise
+    if matrix is None:
         other_spins, other_coeffs, other_counts = _batched_apply(quantum_hamiltonian, spins)
         other_indices, _member, elements, offsets = ising_elements(
             spins, psi, other_spins, other_coeffs, other_counts)

@@ -282,6 +282,156 @@ __global__ __launch_bounds__(kThreads) void k_ising_rows(IsingArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// coupling build when a row may reach a state more than once (symmetry-adapted bases,
+// single-site flips): the reference's arithmetic with its duplicates
+// ---------------------------------------------------------------------------
+// make_ising_model builds csr_matrix((elements, clipped indices, offsets)) — unsorted, with
+// duplicate columns and explicit zeros for targets outside the cluster — and lets scipy form
+// 0.5 * (M + M.T) (common.py:190-196).  scipy's csr + csr on such input sums, per row, the
+// duplicates of each operand in storage order starting from 0 (A_row[col] += Ax), adds the two
+// sums, and keeps the entry iff the result is non-zero; M.T's duplicates come in the storage
+// order of the row they sit in.  So with  Mhat_rj = ((0 + e_1) + e_2) + ...  over row r's entries
+// with column j in connection order:  J_rj = 0.5 * (Mhat_rj + Mhat_jr), kept iff the sum != 0.
+// Entries outside the cluster carry the value 0 in the reference and never change a sum.
+//   k_merge_rows   one wavefront per row: columns through the hash, elements
+//                  (coeff * |psi_j|) * |psi_r|, duplicates summed in connection order, the row's
+//                  distinct columns sorted -> Mhat as CSR
+//   k_sym_rows     one wavefront per row: Mhat_jr by bisection in row j, prune, COO out;
+//                  counts entries whose mirror is missing from Mhat (one-directional matrix
+//                  elements): the caller then leaves the job to the host route
+
+struct MergeArgs {
+  const uint64_t *keys;
+  const double *psi;
+  const unsigned long long *slots;
+  uint64_t mask;
+  const int64_t *offsets;       // connections of row r: [offsets[r], offsets[r+1])
+  const uint64_t *other_keys;   // targets (representatives for a symmetric basis)
+  const double *other_coeffs;
+  uint64_t num_spins;
+  uint32_t row_capacity;        // LDS entries per wavefront
+  const int64_t *mrow_start;    // EMIT
+  uint32_t *mrow_nnz;           // count pass
+  int32_t *mcol;
+  double *mval;
+};
+
+template <bool EMIT>
+__global__ __launch_bounds__(kThreads) void k_merge_rows(MergeArgs a) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint64_t r = static_cast<uint64_t>(blockIdx.x) * kWaves + wave;
+  if (r >= a.num_spins) return;  // whole wavefront; only wave-level barriers below
+  // per wavefront: vals f64[cap] | cols i32[cap] | leader u8[cap]
+  double *vals = reinterpret_cast<double *>(lds) + static_cast<size_t>(wave) * a.row_capacity;
+  int32_t *cols = reinterpret_cast<int32_t *>(reinterpret_cast<double *>(lds) +
+                                              static_cast<size_t>(kWaves) * a.row_capacity) +
+                  static_cast<size_t>(wave) * a.row_capacity;
+  uint8_t *leader = reinterpret_cast<uint8_t *>(reinterpret_cast<int32_t *>(
+                        reinterpret_cast<double *>(lds) + static_cast<size_t>(kWaves) * a.row_capacity) +
+                    static_cast<size_t>(kWaves) * a.row_capacity) +
+                    static_cast<size_t>(wave) * a.row_capacity;
+  const int64_t begin = a.offsets[r];
+  const uint32_t n = static_cast<uint32_t>(a.offsets[r + 1] - begin);
+  const double psi_r = fabs(a.psi[r]);
+  for (uint32_t i = lane; i < n; i += 64u) {
+    const int64_t j = find_key(a.slots, a.mask, a.keys, a.other_keys[begin + i]);
+    cols[i] = static_cast<int32_t>(j);
+    // (coeff * |psi_j|) * |psi_r|, each product rounded (common.py:79,81)
+    vals[i] = j < 0 ? 0.0 : __dmul_rn(__dmul_rn(a.other_coeffs[begin + i], fabs(a.psi[j])), psi_r);
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  uint32_t mine = 0;
+  for (uint32_t i = lane; i < n; i += 64u) {
+    bool first = cols[i] >= 0;
+    for (uint32_t k = 0; k < i && first; ++k) first = cols[k] != cols[i];
+    leader[i] = first ? 1 : 0;
+    mine += first ? 1u : 0u;
+  }
+  uint32_t distinct = mine;
+#pragma unroll
+  for (int step = 1; step < 64; step <<= 1) distinct += __shfl_xor(distinct, step, 64);
+  if (!EMIT) {
+    if (lane == 0) a.mrow_nnz[r] = distinct;
+    return;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  const int64_t out = a.mrow_start[r];
+  for (uint32_t i = lane; i < n; i += 64u) {
+    if (!leader[i]) continue;
+    const int32_t c = cols[i];
+    double sum = 0.0;  // scipy: A_row[col] starts at 0 and takes the duplicates in storage order
+    uint32_t rank = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+      if (k >= i && cols[k] == c) sum = __dadd_rn(sum, vals[k]);
+      rank += (leader[k] && cols[k] < c) ? 1u : 0u;
+    }
+    a.mcol[out + rank] = c;
+    a.mval[out + rank] = sum;
+  }
+}
+
+struct SymArgs {
+  const int64_t *mrow_start;  // num_spins + 1
+  const int32_t *mcol;
+  const double *mval;
+  uint64_t num_spins;
+  const int64_t *row_start;  // EMIT
+  uint32_t *row_nnz;         // count pass
+  unsigned long long *missing_mirrors;
+  int32_t *row;
+  int32_t *col;
+  double *val;
+};
+
+template <bool EMIT>
+__global__ __launch_bounds__(kThreads) void k_sym_rows(SymArgs a) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t r = static_cast<uint64_t>(blockIdx.x) * kWaves + (threadIdx.x >> 6);
+  if (r >= a.num_spins) return;
+  const int64_t begin = a.mrow_start[r], end = a.mrow_start[r + 1];
+  int64_t written = EMIT ? a.row_start[r] : 0;
+  uint32_t kept = 0;
+  for (int64_t base = begin; base < end; base += 64) {
+    const int64_t e = base + lane;
+    bool keep = false;
+    int32_t j = -1;
+    double x = 0.0;
+    if (e < end) {
+      j = a.mcol[e];
+      const double forward = a.mval[e];
+      // Mhat_jr: bisection among row j's sorted columns
+      int64_t lo = a.mrow_start[j], hi = a.mrow_start[j + 1];
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (static_cast<uint64_t>(a.mcol[mid]) < r) {
+          lo = mid + 1;
+        } else {
+          hi = mid;
+        }
+      }
+      const bool mirrored = lo < a.mrow_start[j + 1] && static_cast<uint64_t>(a.mcol[lo]) == r;
+      if (!mirrored && !EMIT) atomicAdd(a.missing_mirrors, 1ull);
+      x = __dadd_rn(forward, mirrored ? a.mval[lo] : 0.0);  // (M + M.T)_rj
+      keep = x != 0.0;
+    }
+    const uint64_t ballot = __ballot(keep);
+    if (EMIT && keep) {
+      const int64_t at = written + __popcll(ballot & ((1ull << lane) - 1ull));
+      a.row[at] = static_cast<int32_t>(r);
+      a.col[at] = j;
+      a.val[at] = __dmul_rn(0.5, x);
+    }
+    written += __popcll(ballot);
+    kept += static_cast<uint32_t>(__popcll(ballot));
+  }
+  if (!EMIT && lane == 0) a.row_nnz[r] = kept;
+}
+
+// ---------------------------------------------------------------------------
 // extension: sorted unique targets
 // ---------------------------------------------------------------------------
 
@@ -484,6 +634,129 @@ int symmetrise_batch(const asp_operator *op, uint64_t n, const ApplyBatch &w, ui
   hipLaunchKernelGGL(k_symmetrise, dim3(grid_for(w.total, kThreads)), dim3(kThreads), 0, stream, g,
                      w.d_offsets.ptr, n, d_norms->ptr, w.total, d_other, d_coeffs);
   ASP_HIP_TRY(hipGetLastError());
+  return ASP_OK;
+}
+
+// asp_operator_ising for operators whose rows may reach a state twice; `missing` receives the
+// number of entries without a mirror (non-zero: the caller must not use the result).
+int ising_with_duplicates(const asp_operator *op, uint64_t K, const uint64_t *keys,
+                          const double *psi, uint64_t capacity, int32_t *row, int32_t *col,
+                          double *val, uint64_t *nnz, hipStream_t stream) {
+  Timer timer;
+  ApplyBatch w;
+  DeviceBuffer<uint64_t> d_other;
+  DeviceBuffer<double> d_coeffs, d_norms, d_psi, d_mval, d_val;
+  DeviceBuffer<unsigned long long> d_slots, d_missing;
+  DeviceBuffer<uint32_t> d_mrow_nnz, d_row_nnz;
+  DeviceBuffer<int64_t> d_mrow_start, d_row_start, d_scratch;
+  DeviceBuffer<int32_t> d_mcol, d_row, d_col;
+  asp::StreamFence fence(stream);
+  ASP_TRY(timer.start(stream));
+  ASP_TRY(count_connections(op, K, keys, &w, stream));
+  ASP_TRY(d_other.alloc(w.total));
+  ASP_TRY(d_coeffs.alloc(w.total));
+  hipLaunchKernelGGL(k_apply<true>, dim3(grid_for(K, kWaves)), dim3(kThreads), 0, stream,
+                     op->d_bonds.ptr, op->num_bonds, w.d_keys.ptr, K, w.d_offsets.ptr, nullptr,
+                     d_other.ptr, d_coeffs.ptr);
+  ASP_HIP_TRY(hipGetLastError());
+  ASP_TRY(symmetrise_batch(op, K, w, d_other.ptr, d_coeffs.ptr, &d_norms, stream));
+  uint64_t slots_n = 1024;
+  while (slots_n < 2 * K) slots_n <<= 1;
+  ASP_TRY(d_psi.alloc(K));
+  ASP_TRY(d_slots.alloc(slots_n));
+  ASP_TRY(d_missing.alloc(1));
+  ASP_TRY(d_mrow_nnz.alloc(K));
+  ASP_TRY(d_row_nnz.alloc(K));
+  ASP_TRY(d_mrow_start.alloc(K + 1));
+  ASP_TRY(d_row_start.alloc(K + 1));
+  ASP_TRY(d_scratch.alloc(asp::scan_scratch_elems(K)));
+  ASP_TRY(d_psi.upload(psi, K, stream));
+  ASP_HIP_TRY(hipMemsetAsync(d_slots.ptr, 0, slots_n * sizeof(unsigned long long), stream));
+  ASP_HIP_TRY(hipMemsetAsync(d_missing.ptr, 0, sizeof(unsigned long long), stream));
+  hipLaunchKernelGGL(k_key_insert, dim3(grid_for(K, kThreads)), dim3(kThreads), 0, stream,
+                     w.d_keys.ptr, K, d_slots.ptr, slots_n - 1);
+  MergeArgs m{};
+  m.keys = w.d_keys.ptr;
+  m.psi = d_psi.ptr;
+  m.slots = d_slots.ptr;
+  m.mask = slots_n - 1;
+  m.offsets = w.d_offsets.ptr;
+  m.other_keys = d_other.ptr;
+  m.other_coeffs = d_coeffs.ptr;
+  m.num_spins = K;
+  m.row_capacity = (op->max_connections + 7u) & ~7u;
+  m.mrow_nnz = d_mrow_nnz.ptr;
+  const size_t lds = static_cast<size_t>(kWaves) * m.row_capacity * (sizeof(double) + sizeof(int32_t) + 1);
+  if (lds > 160u * 1024u) {
+    return asp::set_error(ASP_ERR_TOO_LARGE, "%u connections per row need %zu bytes of LDS",
+                          op->max_connections, lds);
+  }
+  for (const void *kernel : {reinterpret_cast<const void *>(k_merge_rows<false>),
+                             reinterpret_cast<const void *>(k_merge_rows<true>)}) {
+    if (lds > 64u * 1024u) {
+      ASP_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(lds)));
+    }
+  }
+  hipLaunchKernelGGL(k_merge_rows<false>, dim3(grid_for(K, kWaves)), dim3(kThreads), lds, stream, m);
+  ASP_HIP_TRY(hipGetLastError());
+  ASP_TRY(asp::exclusive_scan_u32(d_mrow_nnz.ptr, K, d_mrow_start.ptr, d_scratch.ptr, stream));
+  int64_t merged = 0;
+  ASP_HIP_TRY(hipMemcpyAsync(&merged, d_mrow_start.ptr + K, sizeof merged, hipMemcpyDeviceToHost,
+                             stream));
+  ASP_HIP_TRY(hipStreamSynchronize(stream));
+  ASP_TRY(d_mcol.alloc(static_cast<uint64_t>(merged)));
+  ASP_TRY(d_mval.alloc(static_cast<uint64_t>(merged)));
+  m.mrow_start = d_mrow_start.ptr;
+  m.mcol = d_mcol.ptr;
+  m.mval = d_mval.ptr;
+  hipLaunchKernelGGL(k_merge_rows<true>, dim3(grid_for(K, kWaves)), dim3(kThreads), lds, stream, m);
+  SymArgs y{};
+  y.mrow_start = d_mrow_start.ptr;
+  y.mcol = d_mcol.ptr;
+  y.mval = d_mval.ptr;
+  y.num_spins = K;
+  y.row_nnz = d_row_nnz.ptr;
+  y.missing_mirrors = d_missing.ptr;
+  hipLaunchKernelGGL(k_sym_rows<false>, dim3(grid_for(K, kWaves)), dim3(kThreads), 0, stream, y);
+  ASP_HIP_TRY(hipGetLastError());
+  ASP_TRY(asp::exclusive_scan_u32(d_row_nnz.ptr, K, d_row_start.ptr, d_scratch.ptr, stream));
+  int64_t total = 0;
+  unsigned long long missing = 0;
+  ASP_HIP_TRY(hipMemcpyAsync(&total, d_row_start.ptr + K, sizeof total, hipMemcpyDeviceToHost, stream));
+  ASP_HIP_TRY(hipMemcpyAsync(&missing, d_missing.ptr, sizeof missing, hipMemcpyDeviceToHost, stream));
+  ASP_HIP_TRY(hipStreamSynchronize(stream));
+  if (missing != 0) {
+    return asp::set_error(ASP_ERR_INVALID,
+                          "%llu couplings have no mirror element (one-directional matrix elements): "
+                          "use the host route", missing);
+  }
+  *nnz = static_cast<uint64_t>(total);
+  if (capacity == 0 && !row && !col && !val) {  // sizing call
+    ASP_TRY(timer.stop());
+    ASP_HIP_TRY(hipStreamSynchronize(stream));
+    timer.finish();
+    return ASP_OK;
+  }
+  if (*nnz > capacity || !row || !col || !val) {
+    return asp::set_error(ASP_ERR_INVALID, "%llu couplings do not fit capacity %llu",
+                          (unsigned long long)*nnz, (unsigned long long)capacity);
+  }
+  ASP_TRY(d_row.alloc(*nnz));
+  ASP_TRY(d_col.alloc(*nnz));
+  ASP_TRY(d_val.alloc(*nnz));
+  y.row_start = d_row_start.ptr;
+  y.row = d_row.ptr;
+  y.col = d_col.ptr;
+  y.val = d_val.ptr;
+  hipLaunchKernelGGL(k_sym_rows<true>, dim3(grid_for(K, kWaves)), dim3(kThreads), 0, stream, y);
+  ASP_HIP_TRY(hipGetLastError());
+  ASP_TRY(timer.stop());
+  ASP_TRY(d_row.download(row, *nnz, stream));
+  ASP_TRY(d_col.download(col, *nnz, stream));
+  ASP_TRY(d_val.download(val, *nnz, stream));
+  ASP_HIP_TRY(hipStreamSynchronize(stream));
+  timer.finish();
   return ASP_OK;
 }
 
@@ -721,10 +994,6 @@ int asp_operator_ising(asp_operator const *op, uint64_t num_spins, uint64_t cons
   *nnz = 0;
   const uint64_t K = num_spins;
   if (K && (!keys || !psi)) return asp::set_error(ASP_ERR_INVALID, "null input array");
-  if (!op->unique_targets) {
-    return asp::set_error(ASP_ERR_INVALID,
-                          "operator has coinciding flip masks: rows may reach a state twice");
-  }
   if (K >= 0x7FFFFFFFull) return asp::set_error(ASP_ERR_TOO_LARGE, "more than 2^31-1 spins");
   for (uint64_t i = 1; i < K; ++i) {
     if (keys[i - 1] >= keys[i]) {
@@ -735,6 +1004,11 @@ int asp_operator_ising(asp_operator const *op, uint64_t num_spins, uint64_t cons
   asp::ScopedStream scoped;
   ASP_TRY(scoped.acquire());
   hipStream_t stream = scoped.stream;
+  if (!op->unique_targets) {
+    // rows may reach a state twice (symmetry-adapted bases, single-site flips): the variant that
+    // keeps the reference's duplicate arithmetic
+    return ising_with_duplicates(op, K, keys, psi, capacity, row, col, val, nnz, stream);
+  }
   uint64_t slots_n = 1024;
   while (slots_n < 2 * K) slots_n <<= 1;
   DeviceBuffer<uint64_t> d_keys;

@@ -171,8 +171,8 @@ void asp_operator_destroy(asp_operator *op);
  * (the smallest state of an orbit), asp_operator_apply returns for every connection the
  * representative of the target and the coefficient c * chi(g) * norm(target) / norm(source),
  * norm(s)^2 = (sum of the stabiliser's characters) / |G|, and asp_operator_extend the sorted
- * unique representatives.  Equal targets within a row are not merged (asp_operator_ising is
- * then unavailable: make_ising_model takes the asp_ising_elements route). */
+ * unique representatives.  Equal targets within a row are not merged (asp_operator_ising
+ * then runs its duplicate-keeping variant). */
 int asp_operator_set_symmetry(asp_operator *op, uint32_t num_permutations, uint8_t const *table,
                               int32_t spin_inversion);
 /* (representative, character of a group element mapping the key onto it, norm) of n keys; any
@@ -206,7 +206,14 @@ int asp_operator_apply(asp_operator const *op, uint64_t n, uint64_t const *keys,
  * — the matrix `0.5 * (matrix + matrix.T); sort_indices(); tocoo()` of
  * common.py:194-196, bit for bit.  *nnz receives the length; row/col/val need
  * capacity >= *nnz (call with capacity 0 and NULL outputs to size them).
- * Requires asp_operator_unique_targets(op). */
+ * Operators whose rows reach pairwise distinct states (asp_operator_unique_targets) take one
+ * fused pass.  Otherwise — symmetry-adapted bases, single-site flips — several connections of a
+ * row may end in the same state, and the variant that keeps the reference's arithmetic for
+ * them runs: duplicates of a row summed in connection order from 0 (scipy's csr + csr on
+ * non-canonical input), then 0.5 * (Mhat_rj + Mhat_jr), entries pruned iff that sum is 0.  That
+ * variant needs every coupling to have its mirror (Mhat_rj present iff Mhat_jr present: any
+ * operator with a symmetric pattern); otherwise it fails with ASP_ERR_INVALID and
+ * make_ising_model takes the asp_ising_elements route. */
 int asp_operator_ising(asp_operator const *op, uint64_t num_spins, uint64_t const *keys,
                        double const *psi, uint64_t capacity, int32_t *row, int32_t *col,
                        double *val, uint64_t *nnz);

@@ -37,7 +37,8 @@ def random_operator(seed, kind, number_spins=14, num_bonds=20, num_keys=700):
     kind: "exchange" (symmetric c*sigma.sigma-like, distinct bonds), "general" (all 16 real
     entries, symmetric pattern, distinct bonds incl. pair flips |00><11|), "one_way" (some
     off-diagonal elements present in one direction only), "single_flip" (elements that flip
-    one site: bonds sharing a site then reach the same state twice)."""
+    one site: bonds sharing a site then reach the same state twice; some one-directional),
+    "double_reach" (the same with every element mirrored)."""
     from annealing_sign_problem_amd import operators
 
     rng = np.random.default_rng(seed)
@@ -61,6 +62,12 @@ def random_operator(seed, kind, number_spins=14, num_bonds=20, num_keys=700):
             if rng.random() < 0.5:
                 m[2, 1] = rng.normal()
             m[3, 0] = rng.normal()
+        elif kind == "double_reach":
+            # symmetric single-site flips: bonds sharing a site reach the same state twice, and
+            # every element has its mirror (the device build with duplicate targets applies)
+            m[1, 2] = m[2, 1] = rng.normal()
+            m[0, 1] = m[1, 0] = rng.normal()            # flips site b
+            m[2, 3] = m[3, 2] = rng.normal()            # flips site b
         elif kind == "single_flip":
             m[1, 2] = m[2, 1] = rng.normal()
             m[0, 1], m[1, 0] = rng.normal(size=2)      # flips site b

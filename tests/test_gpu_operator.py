@@ -65,7 +65,8 @@ class _Basis:
 
 
 @pytest.mark.parametrize("seed,kind,unique", [(1, "exchange", True), (2, "general", True),
-                                              (3, "one_way", True), (4, "single_flip", False)])
+                                              (3, "one_way", True), (4, "single_flip", False),
+                                              (5, "double_reach", False)])
 def test_device_operator_general_matrices(seed, kind, unique):
     from annealing_sign_problem_amd import _lib, common
 
@@ -83,12 +84,15 @@ def test_device_operator_general_matrices(seed, kind, unique):
     _same(counts, o_counts)
     _same(dev.extend(keys), oracle.operator_extend(table, keys))
     o_row, o_col, o_val = oracle.operator_ising(table, keys, psi)
-    if unique:
+    if unique or kind == "double_reach":
+        # distinct targets: the pair-fused build; rows reaching a state twice with mirrored
+        # elements: the build that keeps scipy's duplicate arithmetic (k_merge_rows / k_sym_rows)
         row, col, val = dev.ising(keys, psi)
         _same(row, o_row)
         _same(col, o_col)
         _same(val, o_val)
     else:
+        # duplicates AND one-directional elements: refused, make_ising_model takes the host route
         with pytest.raises(_lib.AspError):
             dev.ising(keys, psi)
     # make_ising_model picks the route itself; either way it is the oracle's J

@@ -48,6 +48,20 @@ def test_state_info_apply_and_extension_equal_the_numpy_restatement(models, name
     model = common.make_ising_model(keys, op, log_psi=log_psi)
     j = model.ising_hamiltonian.exchange
     assert abs(j - j.T).max() == 0.0 and model.size == keys.shape[0]
+    # the device build that keeps scipy's duplicate arithmetic (several connections of a row end
+    # in the same representative) against the reference route in numpy / scipy, bit for bit
+    import scipy.sparse
+
+    from helpers import reference_route_ising
+
+    psi = np.ascontiguousarray(np.exp(log_psi).real)
+    psi /= np.linalg.norm(psi)
+    want = reference_route_ising(op, keys, psi)
+    row, col, val = dev.ising(keys, psi)
+    assert np.array_equal(row, want.row) and np.array_equal(col, want.col)
+    assert val.tobytes() == want.data.tobytes()
+    got = scipy.sparse.coo_matrix(j)
+    assert np.array_equal(got.row, want.row) and got.data.tobytes() == want.data.tobytes()
     bigger = common.make_hamiltonian_extension(model, lambda s: np.zeros(len(s), dtype=complex))
     assert np.array_equal(bigger.spins, np.unique(want_other[:, 0]))
 
