@@ -1311,6 +1311,59 @@ __global__ __launch_bounds__(512) void k_sa_energy_blocks(EnergyArgs a) {
   energy_blocks_body<STAGED>(a, blockIdx.x);
 }
 
+// R configurations per workgroup: every coupling quad is loaded once and applied to the R staged
+// configurations (the chains of one call share the ELL: R times less load traffic than one
+// configuration per workgroup).  Per configuration the arithmetic — and so the bits — are those
+// of energy_blocks_body.
+template <int R>
+__global__ __launch_bounds__(512) void k_sa_energy_blocks_multi(EnergyArgs a, uint32_t count) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  uint64_t *staged = reinterpret_cast<uint64_t *>(lds);  // [R][num_blocks]
+  const uint32_t r0 = blockIdx.x * R;
+  const uint32_t live = count - r0 < static_cast<uint32_t>(R) ? count - r0 : R;
+  const uint64_t *rows = a.perm_words + static_cast<uint64_t>(r0) * a.num_blocks;
+  for (uint32_t w = threadIdx.x; w < live * a.num_blocks; w += blockDim.x) staged[w] = rows[w];
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t waves = blockDim.x >> 6;
+  for (uint32_t b = threadIdx.x >> 6; b < a.num_blocks; b += waves) {
+    const uint32_t quads = a.block_width[b] >> 2;
+    const uint64_t first_quad = a.ell_off[b] >> 2;
+    const uint4 *cptr = reinterpret_cast<const uint4 *>(a.ell_col) + first_quad * 64u + lane;
+    const double2 *vptr = reinterpret_cast<const double2 *>(a.ell_val) + first_quad * 128u + lane;
+    double acc[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) acc[k] = 0.0;
+    for (uint32_t q = 0; q < quads; ++q) {
+      const uint4 c = cptr[q * 64u];
+      const double2 v01 = vptr[q * 128u];
+      const double2 v23 = vptr[q * 128u + 64u];
+      const uint32_t cs[4] = {c.x, c.y, c.z, c.w};
+      const double vs[4] = {v01.x, v01.y, v23.x, v23.y};
+      const uint32_t *halves = reinterpret_cast<const uint32_t *>(staged);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t word = cs[j] >> 5, bit = cs[j] & 31u;  // 32-bit halves: ds_read_b32
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          // (rows beyond `live` hold stale LDS: their sums are computed and never stored)
+          const uint32_t neg = (halves[k * 2u * a.num_blocks + word] >> bit) & 1u;
+          acc[k] = __dadd_rn(acc[k], signed_coupling(vs[j], neg, 0));
+        }
+      }
+    }
+    const double field = a.field_pos[b * 64u + lane];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (static_cast<uint32_t>(k) >= live) break;  // workgroup-uniform
+      const double g = __dadd_rn(__dmul_rn(0.5, acc[k]), field);
+      const bool negative = (staged[k * a.num_blocks + b] >> lane) & 1ull;
+      const double total = wave_tree_sum_f64(negative ? -g : g);
+      if (lane == 0) a.partial[static_cast<uint64_t>(r0 + k) * a.num_blocks + b] = total;
+    }
+  }
+}
+
 // One wavefront per configuration folds its block sums 64 at a time, in place.
 __device__ __forceinline__ void energy_fold_body(double *partial, uint32_t num_blocks,
                                                  double diag_sum, double *out_e, const uint32_t r) {
@@ -1382,26 +1435,29 @@ __global__ __launch_bounds__(256) void k_permute_bits(const uint64_t *__restrict
   perm_words[idx] = word;
 }
 
-// Permuted sign-bit words -> packed original-order configurations (bit = +1).
+// Permuted sign-bit words -> packed original-order configurations (bit = +1).  A wavefront per
+// output word: lane j owns spin 64 w + j, its position is read once (coalesced) and used for
+// kUnpermuteChains configurations; the word of each is one ballot.
+constexpr uint32_t kUnpermuteChains = 32;
 __global__ __launch_bounds__(256) void k_unpermute_bits(const uint64_t *__restrict__ perm_words,
                                                        uint32_t num_blocks,
                                                        const uint32_t *__restrict__ pos_of_spin,
                                                        uint64_t num_spins, uint32_t words,
                                                        uint32_t count, uint64_t *__restrict__ x) {
-  const uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (idx >= static_cast<uint64_t>(count) * words) return;
-  const uint32_t r = static_cast<uint32_t>(idx / words);
-  const uint32_t w = static_cast<uint32_t>(idx % words);
-  uint64_t word = 0;
-  for (uint32_t j = 0; j < 64; ++j) {
-    const uint64_t spin = static_cast<uint64_t>(w) * 64u + j;
-    if (spin >= num_spins) break;
-    const uint32_t pos = pos_of_spin[spin];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (w >= words) return;  // whole wavefront
+  const uint64_t spin = static_cast<uint64_t>(w) * 64u + lane;
+  const bool live = spin < num_spins;
+  const uint32_t pos = live ? pos_of_spin[spin] : 0u;
+  const uint32_t first = blockIdx.y * kUnpermuteChains;
+  const uint32_t last = first + kUnpermuteChains < count ? first + kUnpermuteChains : count;
+  for (uint32_t r = first; r < last; ++r) {
     const uint64_t neg =
         (perm_words[static_cast<uint64_t>(r) * num_blocks + (pos >> 6)] >> (pos & 63u)) & 1ull;
-    word |= (neg ^ 1ull) << j;
+    const uint64_t word = __ballot(live && neg == 0ull);
+    if (lane == 0) x[static_cast<uint64_t>(r) * words + w] = word;
   }
-  x[idx] = word;
 }
 
 __global__ __launch_bounds__(256) void k_unpermute_bits_batch(const PostProblem *problems,
@@ -1556,7 +1612,16 @@ int energies_of_perm(asp_sa_plan *p, const uint64_t *perm_words, uint32_t count,
   EnergyArgs ea{p->block_width.ptr, p->ell_off.ptr, p->ell_col.ptr, p->ell_val.ptr,
                 p->field_pos.ptr,   perm_words,     partial,        L.num_blocks};
   const size_t lds = static_cast<size_t>(L.num_blocks) * sizeof(uint64_t);
-  if (lds > p->max_lds) {
+  constexpr int kShare = 4;  // configurations per workgroup sharing the coupling loads
+  if (count >= 2 * kShare && lds * kShare <= p->max_lds) {
+    if (lds * kShare > 64 * 1024) {
+      ASP_HIP_TRY(hipFuncSetAttribute(
+          reinterpret_cast<const void *>(k_sa_energy_blocks_multi<kShare>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds * kShare)));
+    }
+    hipLaunchKernelGGL(k_sa_energy_blocks_multi<kShare>, dim3((count + kShare - 1) / kShare),
+                       dim3(512), lds * kShare, p->stream, ea, count);
+  } else if (lds > p->max_lds) {
     hipLaunchKernelGGL(k_sa_energy_blocks<false>, dim3(count), dim3(512), 0, p->stream, ea);
   } else {
     if (lds > 64 * 1024) {
@@ -1933,13 +1998,11 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
   }
   // the first `repetitions` rows of best_perm are the real replicas
   ASP_TRY(energies_of_perm(p, d_best.ptr, repetitions, d_partial.ptr, d_e.ptr));
-  {
-    const uint64_t total = static_cast<uint64_t>(repetitions) * words;
-    hipLaunchKernelGGL(k_unpermute_bits, dim3(static_cast<unsigned>((total + 255) / 256)),
-                       dim3(256), 0, s, d_best.ptr, L.num_blocks, p->pos_of_spin.ptr, K, words,
-                       repetitions, d_x.ptr);
-    ASP_HIP_TRY(hipGetLastError());
-  }
+  hipLaunchKernelGGL(k_unpermute_bits,
+                     dim3((words + 3) / 4, (repetitions + kUnpermuteChains - 1) / kUnpermuteChains),
+                     dim3(256), 0, s, d_best.ptr, L.num_blocks, p->pos_of_spin.ptr, K, words,
+                     repetitions, d_x.ptr);
+  ASP_HIP_TRY(hipGetLastError());
   ASP_HIP_TRY(hipEventRecord(p->ev[3], s));
   // hipMemcpyDefault: out_x / out_e may be host pointers (the usual call) or device pointers
   // (distributed.py hands over RCCL-ready tensors, so a gather needs no host round trip)
