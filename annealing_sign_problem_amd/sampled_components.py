@@ -163,19 +163,23 @@ def process_cluster(cluster, hamiltonian, ground_state, noisy_ground_state, nois
 
 def process_clusters_batched(clusters: Sequence[np.ndarray], hamiltonian, ground_state,
                              noisy_ground_state, noisy_log_coeff_fn, order: int,
-                             global_cutoff: float, annealing: bool) -> List[List[OptimizationResult]]:
+                             global_cutoff: float, annealing: bool,
+                             jobs: int = 1) -> List[List[OptimizationResult]]:
     """``[process_cluster(c, ...) for c in clusters]`` with the annealing of ALL models — every
     cluster at every order — in one batched device call.  The models of a cluster do not depend
     on its solutions (the extension of order i grows from the model of order i-1, common.py:516),
     so they can all be built first; the results are identical to the per-cluster loop."""
     basis = hamiltonian.basis
-    staged = []  # (cluster index, model, exact_signs, weights, result so far)
-    for index, cluster in enumerate(clusters):
+
+    def stage(item):
+        """Models of every order of one cluster, each with its greedy result."""
+        index, cluster = item
         exact_psi = ground_state[np.asarray(basis.batched_index(cluster), dtype=np.int64)]
         exact_signs = sa.signs_to_bits(np.sign(exact_psi))
         weights = exact_psi ** 2
         weights /= np.sum(weights)
         h = None
+        out = []
         for i in range(order + 1):
             if i == 0:
                 h = common.make_ising_model(cluster, hamiltonian, log_psi_fn=noisy_log_coeff_fn)
@@ -184,7 +188,19 @@ def process_clusters_batched(clusters: Sequence[np.ndarray], hamiltonian, ground
                 h = common.sparsify_using_global_cutoff(h, global_cutoff, cluster)
             r = solve_and_test_model(h, cluster, exact_signs, weights, annealing=False)
             r.amplitude_overlap = amplitude_overlap(h.spins, ground_state, noisy_ground_state, basis)
-            staged.append((index, h, exact_signs, weights, r))
+            out.append((index, h, exact_signs, weights, r))
+        return out
+
+    # (cluster index, model, exact_signs, weights, result so far); the builds of different
+    # clusters are independent and their C calls release the GIL: --jobs host threads keep
+    # several in flight on the GPU (own streams); order of the list = cluster order either way
+    if jobs > 1 and len(clusters) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=jobs) as pool:
+            staged = [entry for part in pool.map(stage, enumerate(clusters)) for entry in part]
+    else:
+        staged = [entry for item in enumerate(clusters) for entry in stage(item)]
     if annealing and staged:
         solutions = common.solve_ising_models([m for _, m, _, _, _ in staged],
                                               [clusters[c] for c, _, _, _, _ in staged])
@@ -225,8 +241,8 @@ def parse_command_line(argv=None):
                              "(asp_sa_anneal_batch); 1 = one call per model, as the reference's "
                              "loop.  The output does not depend on it")
     parser.add_argument("--jobs", type=int, default=1,
-                        help="clusters optimised concurrently (independent plans and HIP streams "
-                             "on one GPU; the output does not depend on it)")
+                        help="host threads building / solving clusters concurrently (independent "
+                             "plans and HIP streams on one GPU; the output does not depend on it)")
     return parser.parse_args(argv)
 
 
@@ -297,7 +313,8 @@ def main(argv=None):
         for start in range(0, len(some), args.batch):
             chunk = process_clusters_batched(some[start:start + args.batch], hamiltonian,
                                              ground_state, noisy_ground_state, noisy_log_coeff_fn,
-                                             args.order, args.global_cutoff, args.annealing)
+                                             args.order, args.global_cutoff, args.annealing,
+                                             jobs=args.jobs)
             lines += [",".join(r.to_csv_str() for r in columns) for columns in chunk]
         return lines
 

@@ -179,7 +179,9 @@ def test_batched_annealing_gives_identical_output(tmp_path):
     sampled_components.main(common_args + ["--output", str(a), "--batch", "1"])
     sampled_components.main(common_args + ["--output", str(b)])
     sampled_components.main(common_args + ["--output", str(c), "--batch", "3"])
-    assert a.read_text() == b.read_text() == c.read_text()
+    d = tmp_path / "batch_jobs.csv"
+    sampled_components.main(common_args + ["--output", str(d), "--jobs", "4"])  # threaded staging
+    assert a.read_text() == b.read_text() == c.read_text() == d.read_text()
     rows = [l for l in a.read_text().splitlines() if not l.startswith("#")]
     v = np.array([float(t) for t in rows[0].split(",")]).reshape(2, 6)
     assert np.all(np.isfinite(v[:, 3:5]))  # the SA columns are filled
