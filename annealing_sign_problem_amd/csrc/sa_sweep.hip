@@ -72,6 +72,9 @@
 #ifndef ASP_PHILOX_SKIP
 #define ASP_PHILOX_SKIP 1  // no random numbers for a block none of whose proposals needs one
 #endif
+#ifndef ASP_EXPERIMENT_GLAUBER
+#define ASP_EXPERIMENT_GLAUBER 0  // analysis only (tools/schedule_probe.py): heat-bath acceptance
+#endif                            // 1 / (1 + exp(beta dE)) instead of Metropolis; NOT the specification
 #ifndef ASP_MAX_THREADS
 #define ASP_MAX_THREADS 1024  // launch bound of the sweep kernel (VGPR budget = 512 / waves per SIMD)
 #endif
@@ -741,7 +744,11 @@ __device__ __forceinline__ void sa_sweep_body(const Args &a, const uint32_t grou
           } else {
             const bool maybe = valid && !(__dmul_rn(beta, de[m]) >= 23.0);  // not a certain rejection
             open = open || maybe;
+#if ASP_EXPERIMENT_GLAUBER
+            need = need || maybe;
+#else
             need = need || (maybe && !(de[m] <= 0.0));
+#endif
           }
         }
         // Random numbers only when some proposal of the block is undecided without one
@@ -775,6 +782,12 @@ __device__ __forceinline__ void sa_sweep_body(const Args &a, const uint32_t grou
             accept = false;
 #elif ASP_ABL_NO_EXP
             accept = valid && (de[m] <= 0.0 || word < static_cast<uint32_t>(__dmul_rn(beta, de[m])));
+#elif ASP_EXPERIMENT_GLAUBER
+            {
+              const double x = __dmul_rn(beta, de[m]);
+              const double uu = (static_cast<double>(word) + 0.5) * 0x1p-32;
+              accept = valid && x < 23.0 && uu < 1.0 / (1.0 + exp(x));
+            }
 #elif ASP_EXP_FILTER == 2
             accept = valid && (de[m] <= 0.0 || metropolis_accept_word(word, __dmul_rn(beta, de[m])));
 #else
@@ -790,7 +803,10 @@ __device__ __forceinline__ void sa_sweep_body(const Args &a, const uint32_t grou
         } else {
 #pragma unroll
           for (int m = 0; m < M; ++m) {
-            const bool accept = valid && (DESCENT ? de[m] < 0.0 : de[m] <= 0.0);
+            // (no draw needed: DESCENT, or every proposal decided; with the heat-bath experiment a
+            // skipped draw means every proposal was a certain rejection)
+            const bool accept = valid && (DESCENT ? de[m] < 0.0
+                                                  : (ASP_EXPERIMENT_GLAUBER ? false : de[m] <= 0.0));
             accept_mask |= (accept ? 1u : 0u) << m;
           }
         }
