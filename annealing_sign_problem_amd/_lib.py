@@ -110,6 +110,8 @@ SIGNATURES = {
     "asp_sa_plan_info": (c_int, [c_void_p, ctypes.POINTER(SaInfo)]),
     "asp_sa_layout_host": (c_int, [c_u64, c_void_p, c_void_p, c_void_p, c_void_p,
                                    ctypes.POINTER(SaInfo), c_void_p, c_void_p]),
+    "asp_sa_shuffled_order_host": (c_int, [c_u64, c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_u32,
+                                           c_void_p, c_void_p, ctypes.POINTER(c_u32)]),
     "asp_sa_set_launch": (c_int, [c_void_p, c_int, c_int]),
     "asp_sa_set_packed": (c_int, [c_void_p, c_int]),
     "asp_sa_set_wide": (c_int, [c_void_p, c_int]),
@@ -120,6 +122,8 @@ SIGNATURES = {
                               c_void_p]),
     "asp_sa_anneal_trace": (c_int, [c_void_p, c_u64, c_void_p, c_u32, c_u32, c_u32, c_void_p,
                                     c_void_p, c_void_p, c_void_p]),
+    "asp_sa_anneal_shuffled": (c_int, [c_void_p, c_u64, c_void_p, c_u32, c_u32, c_u32, c_void_p, c_void_p,
+                                       c_void_p]),
     "asp_sa_anneal_batch": (c_int, [ctypes.POINTER(SaBatchItem), c_u32]),
     "asp_sa_batch_last_ms": (c_float, []),
     "asp_sa_greedy": (c_int, [c_void_p, c_u32, c_void_p, c_void_p, ctypes.POINTER(c_u32)]),

@@ -184,8 +184,9 @@ def _resolve_seed(seed) -> int:
 
 
 def anneal_raw(hamiltonian: Hamiltonian, seed: int, betas: np.ndarray, repetitions: int,
-               replica_offset: int = 0, x0=None):
-    """All chains, no reduction: (xs[R, words] uint64, es[R] float64)."""
+               replica_offset: int = 0, x0=None, shuffled: bool = False):
+    """All chains, no reduction: (xs[R, words] uint64, es[R] float64).  ``shuffled``: a fresh
+    visiting order every sweep (``asp_sa_anneal_shuffled``) instead of the colour order."""
     lib = _lib.load()
     plan = hamiltonian.plan()
     words = (hamiltonian.size + 63) // 64
@@ -196,10 +197,10 @@ def anneal_raw(hamiltonian: Hamiltonian, seed: int, betas: np.ndarray, repetitio
         x0 = np.ascontiguousarray(x0, dtype=np.uint64).reshape(-1)
         if x0.shape[0] != words:
             raise ValueError("'x0' must have {} words".format(words))
-    _lib.check(lib.asp_sa_anneal(plan, ctypes.c_uint64(seed), _lib.ptr(betas),
-                                 ctypes.c_uint32(betas.shape[0]), ctypes.c_uint32(repetitions),
-                                 ctypes.c_uint32(replica_offset), _lib.ptr(x0), _lib.ptr(xs),
-                                 _lib.ptr(es)))
+    entry = lib.asp_sa_anneal_shuffled if shuffled else lib.asp_sa_anneal
+    _lib.check(entry(plan, ctypes.c_uint64(seed), _lib.ptr(betas),
+                     ctypes.c_uint32(betas.shape[0]), ctypes.c_uint32(repetitions),
+                     ctypes.c_uint32(replica_offset), _lib.ptr(x0), _lib.ptr(xs), _lib.ptr(es)))
     return xs[:, :words], es
 
 
@@ -222,13 +223,19 @@ def anneal_raw_into(hamiltonian: Hamiltonian, seed: int, betas: np.ndarray, repe
 
 def anneal(hamiltonian: Hamiltonian, x0=None, seed=None, number_sweeps: int = 5120,
            beta0: Optional[float] = None, beta1: Optional[float] = None, repetitions: int = 1,
-           only_best: bool = True, distributed: bool = True):
+           only_best: bool = True, distributed: bool = True, sweep_order: str = "colour"):
     """Simulated annealing of ``hamiltonian``.
 
     Returns ``(x, e)``: with ``only_best=True`` the best packed configuration
     (``uint64[ceil(K/64)]``) over all repetitions and its energy; with
     ``only_best=False`` the per-repetition arrays ``(xs[R, words], es[R])``
     (zip-able, experiments/full_hilbert_space.py:176).
+
+    ``sweep_order="colour"`` (default): the fixed colour order of specification ASP-SA-1.
+    ``sweep_order="shuffled"``: a fresh random visiting order every sweep — what the reference's
+    ``ising_glass_annealer`` does as far as its published success probabilities can tell
+    (DESIGN.md §6.1); statistically the library's behaviour, several times slower here and with
+    a LOWER success probability per sweep than the colour order.  Single process only.
 
     When ``torch.distributed`` is initialised with more than one rank (and
     ``distributed`` is true) the repetitions are sharded over the ranks and
@@ -242,7 +249,10 @@ def anneal(hamiltonian: Hamiltonian, x0=None, seed=None, number_sweeps: int = 51
         raise ValueError("'repetitions' must be positive")
     from . import distributed as _dist  # late import: torch is optional plumbing
 
-    sharded = distributed and _dist.shards_chains()
+    if sweep_order not in ("colour", "shuffled"):
+        raise ValueError("'sweep_order' must be 'colour' or 'shuffled'")
+    shuffled = sweep_order == "shuffled"
+    sharded = distributed and _dist.shards_chains() and not shuffled
     seed = _dist.agree_on_seed(seed) if sharded else _resolve_seed(seed)
     if beta0 is None or beta1 is None:
         info = hamiltonian.info()
@@ -255,7 +265,7 @@ def anneal(hamiltonian: Hamiltonian, x0=None, seed=None, number_sweeps: int = 51
     if sharded:
         xs, es = _dist.anneal_sharded(hamiltonian, seed, betas, repetitions, x0)
     else:
-        xs, es = anneal_raw(hamiltonian, seed, betas, repetitions, 0, x0)
+        xs, es = anneal_raw(hamiltonian, seed, betas, repetitions, 0, x0, shuffled=shuffled)
     if only_best:
         best = int(np.argmin(es))  # first minimum: deterministic tie-break
         return xs[best].copy(), float(es[best])

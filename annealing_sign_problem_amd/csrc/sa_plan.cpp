@@ -393,7 +393,107 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
   return ASP_OK;
 }
 
+// ---------------------------------------------------------------------------
+// shuffled visiting orders
+// ---------------------------------------------------------------------------
+
+namespace {
+
+uint32_t philox_word0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  for (int round = 0; round < 10; ++round) {
+    const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c0;
+    const uint64_t p1 = static_cast<uint64_t>(0xCD9E8D57u) * c2;
+    const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = static_cast<uint32_t>(p1);
+    const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = static_cast<uint32_t>(p0);
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c0;
+}
+
+}  // namespace
+
+void shuffled_orders(const SaHostLayout &L, uint64_t seed, uint32_t first, uint32_t count,
+                     uint32_t *order, std::vector<uint32_t> *level_start, uint32_t *cap_out,
+                     uint32_t *num_levels) {
+  const uint64_t K = L.num_spins;
+  const uint32_t k0 = static_cast<uint32_t>(seed), k1 = static_cast<uint32_t>(seed >> 32);
+  const unsigned parts = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  // (the number of levels is the longest descending-priority path: not bounded by the degree)
+  std::vector<std::vector<uint32_t>> starts_of(count);
+  parallel_ranges(count, parts, [&](uint64_t begin, uint64_t end, unsigned) {
+    std::vector<uint64_t> keys(K);
+    std::vector<uint32_t> level(K), fill;
+    for (uint64_t s = begin; s < end; ++s) {
+      const uint32_t t = first + static_cast<uint32_t>(s);
+      for (uint64_t i = 0; i < K; ++i) {
+        keys[i] = (static_cast<uint64_t>(philox_word0(static_cast<uint32_t>(i), t, 0xFFFFFFFEu, 0u, k0, k1)) << 32) | i;
+      }
+      std::sort(keys.begin(), keys.end());
+      std::fill(level.begin(), level.end(), 0u);  // 0 = not visited yet
+      uint32_t deepest = 0;
+      for (uint64_t q = 0; q < K; ++q) {
+        const uint32_t i = static_cast<uint32_t>(keys[q]);
+        uint32_t above = 0;
+        for (int64_t k = L.a_ptr[i]; k < L.a_ptr[i + 1]; ++k) above = std::max(above, level[L.a_col[k]]);
+        level[i] = above + 1;
+        deepest = std::max(deepest, above + 1);
+      }
+      // counting sort by level, the order of `keys` kept inside a level
+      fill.assign(deepest + 2, 0u);
+      for (uint64_t i = 0; i < K; ++i) ++fill[level[i]];  // levels are 1..deepest
+      std::vector<uint32_t> &starts = starts_of[s];
+      starts.assign(deepest + 1, 0u);
+      uint32_t at = 0;
+      for (uint32_t l = 1; l <= deepest; ++l) {
+        starts[l - 1] = at;
+        const uint32_t n = fill[l];
+        fill[l] = at;
+        at += n;
+      }
+      starts[deepest] = at;
+      num_levels[s] = deepest;
+      uint32_t *out = order + s * K;
+      for (uint64_t q = 0; q < K; ++q) {
+        const uint32_t i = static_cast<uint32_t>(keys[q]);
+        out[fill[level[i]]++] = i;
+      }
+    }
+  });
+  uint32_t cap = 1;
+  for (uint32_t s = 0; s < count; ++s) cap = std::max<uint32_t>(cap, static_cast<uint32_t>(starts_of[s].size()));
+  level_start->assign(static_cast<size_t>(count) * cap, static_cast<uint32_t>(K));
+  for (uint32_t s = 0; s < count; ++s) {
+    std::copy(starts_of[s].begin(), starts_of[s].end(), level_start->begin() + static_cast<size_t>(s) * cap);
+  }
+  *cap_out = cap;
+}
+
 }  // namespace asp
+
+extern "C" int asp_sa_shuffled_order_host(uint64_t num_spins, int64_t const *indptr,
+                                          int32_t const *indices, double const *data,
+                                          double const *field, uint64_t seed, uint32_t sweep,
+                                          uint32_t *order, uint32_t *level_of_position,
+                                          uint32_t *num_levels) {
+  asp_clear_error();
+  asp::SaHostLayout L;
+  ASP_TRY(asp::build_sa_layout(num_spins, indptr, indices, data, field, &L));
+  std::vector<uint32_t> starts, ord(num_spins ? num_spins : 1);
+  uint32_t levels = 0, cap = 0;
+  asp::shuffled_orders(L, seed, sweep, 1, ord.data(), &starts, &cap, &levels);
+  if (order) std::copy(ord.begin(), ord.begin() + num_spins, order);
+  if (level_of_position) {
+    for (uint32_t l = 0; l < levels; ++l) {
+      for (uint32_t q = starts[l]; q < starts[l + 1]; ++q) level_of_position[q] = l;
+    }
+  }
+  if (num_levels) *num_levels = levels;
+  return ASP_OK;
+}
 
 static void fill_info(const asp::SaHostLayout &L, asp_sa_info *info) {
   info->num_spins = L.num_spins;

@@ -51,6 +51,18 @@ struct SaHostLayout {
 int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *indices,
                     const double *data, const double *field, SaHostLayout *out);
 
+// Visiting orders of the "shuffled" sweep: sweep t visits the spins in ascending
+// (priority, index), priority_t(i) = word 0 of Philox4x32-10(counter (i, t, 0xFFFFFFFE, 0), key
+// seed).  A sequential sweep in that order equals visiting the LEVELS of the priority graph one
+// after another (level(i) = 1 + max level of the neighbours that come before i; spins of a level
+// are pairwise non-adjacent), which is what the device does.  For sweeps first..first+count-1:
+// order[s * K + k] = k-th spin of sweep s in level-major order, level_start[s * cap + l] = first
+// position of level l (l = 0..num_levels[s]; later entries = K), cap = the chunk's largest number
+// of levels + 1 (the longest descending-priority path; not bounded by the degree).
+void shuffled_orders(const SaHostLayout &layout, uint64_t seed, uint32_t first, uint32_t count,
+                     uint32_t *order, std::vector<uint32_t> *level_start, uint32_t *cap,
+                     uint32_t *num_levels);
+
 // Greedy sign assignment before relaxation (specification DESIGN.md §4.8): packed
 // configuration (bit = +1), ceil(K/64) words.
 int greedy_tree_signs(const SaHostLayout &layout, uint64_t *x);

@@ -1267,6 +1267,148 @@ __global__ __launch_bounds__(1024) void k_sa_sweep_team(TeamArgs ta) {
 }
 
 // ---------------------------------------------------------------------------
+// Shuffled sweep: a fresh visiting order every sweep
+// ---------------------------------------------------------------------------
+// The reference's annealer visits the spins in a fresh random permutation every sweep
+// (that order, not the ladder or the acceptance rule, reproduces its published
+// success probabilities).  A sequential sweep in the order of random priorities equals visiting the
+// LEVELS of the priority graph one after another (csrc/sa_plan.cpp: shuffled_orders); spins of a
+// level are pairwise non-adjacent, so a level is updated in parallel.  The levels change every
+// sweep, so the static colour-block layout of k_sa_sweep is of no use here: one workgroup per
+// chain, spins as LDS bytes in ORIGINAL order, a thread per spin of the level, rows gathered
+// from the CSR of A.  Same proposal arithmetic, random words and energy bookkeeping as §4.4-4.5;
+// several times slower than the colour-ordered sweep — it exists to reproduce the reference's
+// statistics, not for speed.  Long ladders run in chunks (the orders of a chunk are built on the
+// host while the chain state stays in HBM).
+
+struct ShuffledArgs {
+  const int64_t *a_ptr;  // CSR of A over original indices
+  const int32_t *a_col;
+  const double *a_val;
+  const double *field;
+  const double *betas;          // all sweeps of the call
+  const uint32_t *order;        // [chunk][K] level-major visiting order
+  const uint32_t *level_start;  // [chunk][cap]
+  const uint32_t *num_levels;   // [chunk]
+  const uint64_t *x0;           // packed original-order start configuration or nullptr
+  uint8_t *spins;               // [chains][K] 1 = s is -1 (state between chunks)
+  uint8_t *best;                // [chains][K]
+  long long *e_cur, *e_best;    // [chains] tracked energies (fixed point)
+  unsigned long long *accepted; // [chains]
+  uint64_t seed;
+  double scale;
+  uint32_t num_spins, cap, first_sweep, chunk_sweeps, replica_first, initialise;
+};
+
+__global__ __launch_bounds__(1024) void k_sa_sweep_shuffled(ShuffledArgs a) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const uint32_t K = a.num_spins;
+  uint8_t *s = lds;  // K bytes, then the bookkeeping
+  long long *book = reinterpret_cast<long long *>(lds + ((K + 15u) & ~15u));  // [0] dq, [1] dn, [2] flag
+  const uint32_t tid = threadIdx.x;
+  const uint32_t chain = blockIdx.x;
+  const uint32_t r = a.replica_first + chain;
+  const uint32_t key0 = static_cast<uint32_t>(a.seed), key1 = static_cast<uint32_t>(a.seed >> 32);
+  uint8_t *my_spins = a.spins + static_cast<uint64_t>(chain) * K;
+  uint8_t *my_best = a.best + static_cast<uint64_t>(chain) * K;
+  if (a.initialise) {
+    for (uint32_t i = tid; i < K; i += blockDim.x) {
+      uint32_t up;
+      if (a.x0 != nullptr) {
+        up = static_cast<uint32_t>((a.x0[i >> 6] >> (i & 63u)) & 1ull);
+      } else {
+        const Philox4 rnd = philox4x32_10(i, 0xFFFFFFFFu, r >> 2, 0u, key0, key1);
+        up = pick_word(rnd, r & 3u) & 1u;
+      }
+      s[i] = static_cast<uint8_t>(up ^ 1u);
+      my_best[i] = static_cast<uint8_t>(up ^ 1u);
+    }
+  } else {
+    for (uint32_t i = tid; i < K; i += blockDim.x) s[i] = my_spins[i];
+  }
+  if (tid < 3) book[tid] = 0;
+  long long e_cur = a.initialise ? 0 : a.e_cur[chain];
+  long long e_best = a.initialise ? 0 : a.e_best[chain];
+  unsigned long long accepted = a.initialise ? 0ull : a.accepted[chain];
+  __syncthreads();
+  for (uint32_t tt = 0; tt < a.chunk_sweeps; ++tt) {
+    const uint32_t t = a.first_sweep + tt;
+    const double beta = a.betas[t];
+    const uint32_t *order = a.order + static_cast<uint64_t>(tt) * K;
+    const uint32_t *starts = a.level_start + static_cast<uint64_t>(tt) * a.cap;
+    const uint32_t levels = a.num_levels[tt];
+    long long q = 0;
+    uint32_t n = 0;
+    for (uint32_t l = 0; l < levels; ++l) {
+      const uint32_t end = starts[l + 1];
+      for (uint32_t idx = starts[l] + tid; idx < end; idx += blockDim.x) {
+        const uint32_t i = order[idx];
+        double acc = 0.0;
+        for (int64_t k = a.a_ptr[i]; k < a.a_ptr[i + 1]; ++k) {
+          const double v = a.a_val[k];
+          acc = __dadd_rn(acc, s[a.a_col[k]] ? -v : v);
+        }
+        const double g = __dadd_rn(acc, a.field[i]);
+        const bool negative = s[i] != 0;
+        const double de = __dmul_rn(negative ? 2.0 : -2.0, g);
+        bool accept = de <= 0.0;
+        if (!accept) {
+          const Philox4 rnd = philox4x32_10(i, t, r >> 2, 0u, key0, key1);
+          accept = metropolis_accept_word(pick_word(rnd, r & 3u), __dmul_rn(beta, de));
+        }
+        if (accept) {
+          s[i] = static_cast<uint8_t>(negative ? 0 : 1);  // no neighbour of i is in this level
+          q += __double_as_longlong(__dadd_rn(__dmul_rn(de, a.scale), 0x1.8p52)) - 0x4338000000000000ll;
+          n += 1;
+        }
+      }
+      __syncthreads();
+    }
+    // exact (integer) reduction of the sweep's energy change
+    const long long wq = wave_sum_i64(q);
+    const long long wn = wave_sum_i64(static_cast<long long>(n));
+    if ((tid & 63u) == 0 && wn != 0) {
+      atomicAdd(reinterpret_cast<unsigned long long *>(&book[0]), static_cast<unsigned long long>(wq));
+      atomicAdd(reinterpret_cast<unsigned long long *>(&book[1]), static_cast<unsigned long long>(wn));
+    }
+    __syncthreads();
+    e_cur += book[0];                                   // (every thread keeps the same copies)
+    accepted += static_cast<unsigned long long>(book[1]);
+    const bool improved = e_cur < e_best;
+    if (improved) e_best = e_cur;
+    __syncthreads();
+    if (tid == 0) {
+      book[0] = 0;
+      book[1] = 0;
+    }
+    if (improved) {
+      for (uint32_t i = tid; i < K; i += blockDim.x) my_best[i] = s[i];
+    }
+    __syncthreads();
+  }
+  for (uint32_t i = tid; i < K; i += blockDim.x) my_spins[i] = s[i];
+  if (tid == 0) {
+    a.e_cur[chain] = e_cur;
+    a.e_best[chain] = e_best;
+    a.accepted[chain] = accepted;
+  }
+}
+
+// Best configurations (a byte per spin, 1 = -1) -> packed original-order words (bit = +1).
+__global__ __launch_bounds__(256) void k_pack_spin_bytes(const uint8_t *__restrict__ bytes,
+                                                        uint64_t num_spins, uint32_t words,
+                                                        uint32_t count, uint64_t *__restrict__ x) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t idx = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (idx >= static_cast<uint64_t>(count) * words) return;  // whole wavefront
+  const uint32_t rr = static_cast<uint32_t>(idx / words), w = static_cast<uint32_t>(idx % words);
+  const uint64_t spin = static_cast<uint64_t>(w) * 64u + lane;
+  const bool up = spin < num_spins && bytes[static_cast<uint64_t>(rr) * num_spins + spin] == 0;
+  const uint64_t word = __ballot(up);
+  if (lane == 0) x[idx] = word;
+}
+
+// ---------------------------------------------------------------------------
 // Energy of packed configurations: E = D + T, T = radix-64
 // pairwise tree over the blocks of t_p = s_p (A_p . s / 2 + h_p).
 // ---------------------------------------------------------------------------
@@ -1536,6 +1678,10 @@ struct asp_sa_plan {
   int team_mode = -1;  // asp_sa_set_team: -1 auto, 0 off, G >= 2 forced
   bool use_field_cache = true;
   uint32_t team_abort_host = 0;  // landing place of the watchdog flag's asynchronous read-back
+  // CSR of A over original indices + field (shuffled sweep only; uploaded on first use)
+  DeviceBuffer<int64_t> a_ptr_dev;
+  DeviceBuffer<int32_t> a_col_dev;
+  DeviceBuffer<double> a_val_dev, field_dev;
 };
 
 namespace {
@@ -2076,6 +2222,152 @@ int asp_sa_anneal_trace(asp_sa_plan *p, uint64_t seed, double const *betas, uint
   if (!out_trace) return asp::set_error(ASP_ERR_INVALID, "null trace pointer");
   return run_chains(p, seed, betas, num_sweeps, repetitions, replica_offset, x0, false, out_x,
                     out_e, out_trace);
+}
+
+int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_sweeps,
+                           uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0,
+                           uint64_t *out_x, double *out_e) {
+  asp_clear_error();
+  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  ASP_TRY(asp::bind_device());
+  if (repetitions == 0) return ASP_OK;
+  if (!out_x || !out_e || (num_sweeps && !betas)) return asp::set_error(ASP_ERR_INVALID, "null argument");
+  if (num_sweeps >= 0xFFFFFFFEu) return asp::set_error(ASP_ERR_INVALID, "num_sweeps too large");
+  if (static_cast<uint64_t>(replica_offset) + repetitions + 8 > 0xFFFFFFFFull) {
+    return asp::set_error(ASP_ERR_INVALID, "replica ids exceed 32 bits");
+  }
+  for (uint32_t t = 0; t < num_sweeps; ++t) {
+    if (!(betas[t] >= 0.0)) return asp::set_error(ASP_ERR_INVALID, "betas[%u] is not >= 0", t);
+  }
+  const asp::SaHostLayout &L = p->host;
+  const uint64_t K = L.num_spins;
+  const uint32_t words = static_cast<uint32_t>((K + 63) / 64);
+  p->last_sweep_ms = p->last_total_ms = 0.0f;
+  if (K == 0) {
+    for (uint32_t r = 0; r < repetitions; ++r) out_e[r] = 0.0;
+    return ASP_OK;
+  }
+  const size_t lds = ((K + 15) & ~size_t{15}) + 64;
+  if (lds > p->max_lds) {
+    return asp::set_error(ASP_ERR_TOO_LARGE, "the shuffled sweep keeps a byte per spin in LDS: %llu "
+                                             "spins do not fit", (unsigned long long)K);
+  }
+  hipStream_t s = p->stream;
+  asp::StreamFence fence(s);
+  // CSR of A and the field in original order: resident with the plan from the first call on
+  if (!p->a_ptr_dev.ptr) {
+    std::vector<double> field(K);
+    for (uint64_t i = 0; i < K; ++i) field[i] = L.field_pos[L.pos_of_spin[i]];
+    ASP_TRY(upload_vector(p->a_ptr_dev, L.a_ptr, s));
+    ASP_TRY(upload_vector(p->a_col_dev, L.a_col, s));
+    ASP_TRY(upload_vector(p->a_val_dev, L.a_val, s));
+    ASP_TRY(upload_vector(p->field_dev, field, s));
+    ASP_HIP_TRY(hipStreamSynchronize(s));  // `field` dies with this scope
+  }
+  // sweeps per chunk: at most 64 MiB of visiting orders at a time
+  const uint32_t chunk = static_cast<uint32_t>(std::max<uint64_t>(
+      1, std::min<uint64_t>(num_sweeps ? num_sweeps : 1, (64ull << 20) / (4 * K))));
+  DeviceBuffer<double> d_betas, d_partial, d_e;
+  DeviceBuffer<uint32_t> d_order, d_starts, d_levels;
+  DeviceBuffer<uint64_t> d_x0, d_x, d_perm;
+  DeviceBuffer<uint8_t> d_spins, d_best;
+  DeviceBuffer<long long> d_ecur, d_ebest;
+  DeviceBuffer<unsigned long long> d_accepted;
+  asp::StreamFence fence2(s);  // (declared after the buffers: waits before they are released)
+  ASP_TRY(d_betas.alloc(num_sweeps));
+  ASP_TRY(d_order.alloc(static_cast<uint64_t>(chunk) * K));
+  ASP_TRY(d_levels.alloc(chunk));
+  ASP_TRY(d_spins.alloc(static_cast<uint64_t>(repetitions) * K));
+  ASP_TRY(d_best.alloc(static_cast<uint64_t>(repetitions) * K));
+  ASP_TRY(d_ecur.alloc(repetitions));
+  ASP_TRY(d_ebest.alloc(repetitions));
+  ASP_TRY(d_accepted.alloc(repetitions));
+  ASP_TRY(d_x.alloc(static_cast<uint64_t>(repetitions) * words));
+  ASP_TRY(d_perm.alloc(static_cast<uint64_t>(repetitions) * L.num_blocks));
+  ASP_TRY(d_partial.alloc(static_cast<uint64_t>(repetitions) * L.num_blocks));
+  ASP_TRY(d_e.alloc(repetitions));
+  ASP_TRY(d_betas.upload(betas, num_sweeps, s));
+  if (x0) {
+    ASP_TRY(d_x0.alloc(words));
+    ASP_TRY(d_x0.upload(x0, words, s));
+  }
+  ShuffledArgs a{};
+  a.a_ptr = p->a_ptr_dev.ptr;
+  a.a_col = p->a_col_dev.ptr;
+  a.a_val = p->a_val_dev.ptr;
+  a.field = p->field_dev.ptr;
+  a.betas = d_betas.ptr;
+  a.order = d_order.ptr;
+  a.level_start = d_starts.ptr;
+  a.num_levels = d_levels.ptr;
+  a.x0 = x0 ? d_x0.ptr : nullptr;
+  a.spins = d_spins.ptr;
+  a.best = d_best.ptr;
+  a.e_cur = d_ecur.ptr;
+  a.e_best = d_ebest.ptr;
+  a.accepted = d_accepted.ptr;
+  a.seed = seed;
+  a.scale = std::ldexp(1.0, L.energy_scale_exp);
+  a.num_spins = static_cast<uint32_t>(K);
+  a.replica_first = replica_offset;
+  if (lds > 64 * 1024) {
+    ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sa_sweep_shuffled),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+  }
+  const unsigned threads = K >= 4096 ? 1024u : (K >= 512 ? 256u : 64u);
+  std::vector<uint32_t> h_order(static_cast<size_t>(chunk) * K), h_starts, h_levels(chunk);
+  ASP_HIP_TRY(hipEventRecord(p->ev[0], s));
+  bool first_launch = true;
+  for (uint32_t done = 0; done < num_sweeps || first_launch; done += chunk) {
+    const uint32_t now = num_sweeps > done ? std::min(chunk, num_sweeps - done) : 0u;
+    if (now) {
+      uint32_t cap = 0;
+      asp::shuffled_orders(L, seed, done, now, h_order.data(), &h_starts, &cap, h_levels.data());
+      a.cap = cap;
+      ASP_TRY(d_starts.ensure(h_starts.size()));
+      a.level_start = d_starts.ptr;
+      ASP_TRY(d_order.upload(h_order.data(), static_cast<size_t>(now) * K, s));
+      ASP_TRY(d_starts.upload(h_starts.data(), h_starts.size(), s));
+      ASP_TRY(d_levels.upload(h_levels.data(), now, s));
+    }
+    a.first_sweep = done;
+    a.chunk_sweeps = now;
+    a.initialise = first_launch ? 1u : 0u;
+    hipLaunchKernelGGL(k_sa_sweep_shuffled, dim3(repetitions), dim3(threads), lds, s, a);
+    ASP_HIP_TRY(hipGetLastError());
+    ASP_HIP_TRY(hipStreamSynchronize(s));  // the host buffers are refilled for the next chunk
+    first_launch = false;
+  }
+  ASP_HIP_TRY(hipEventRecord(p->ev[2], s));
+  // packed original-order bits of the best configurations, then the energies of §4.6
+  {
+    const uint64_t total = static_cast<uint64_t>(repetitions) * words;
+    hipLaunchKernelGGL(k_pack_spin_bytes, dim3(static_cast<unsigned>((total + 3) / 4)), dim3(256), 0, s,
+                       d_best.ptr, K, words, repetitions, d_x.ptr);
+    const uint64_t blocks = static_cast<uint64_t>(repetitions) * L.num_blocks;
+    hipLaunchKernelGGL(k_permute_bits, dim3(static_cast<unsigned>((blocks + 255) / 256)), dim3(256), 0, s,
+                       d_x.ptr, words, p->spin_of_pos.ptr, L.num_blocks, repetitions, d_perm.ptr);
+    ASP_HIP_TRY(hipGetLastError());
+  }
+  ASP_TRY(energies_of_perm(p, d_perm.ptr, repetitions, d_partial.ptr, d_e.ptr));
+  ASP_HIP_TRY(hipEventRecord(p->ev[3], s));
+  ASP_HIP_TRY(hipMemcpyAsync(out_x, d_x.ptr, static_cast<uint64_t>(repetitions) * words * sizeof(uint64_t),
+                             hipMemcpyDefault, s));
+  ASP_HIP_TRY(hipMemcpyAsync(out_e, d_e.ptr, repetitions * sizeof(double), hipMemcpyDefault, s));
+  p->last_tracked.assign(repetitions, 0);
+  p->last_accepted.assign(repetitions, 0);
+  ASP_HIP_TRY(hipMemcpyAsync(p->last_tracked.data(), d_ebest.ptr, repetitions * sizeof(int64_t),
+                             hipMemcpyDeviceToHost, s));
+  ASP_HIP_TRY(hipMemcpyAsync(p->last_accepted.data(), d_accepted.ptr, repetitions * sizeof(uint64_t),
+                             hipMemcpyDeviceToHost, s));
+  ASP_HIP_TRY(hipStreamSynchronize(s));
+  p->last_m = 1;
+  p->last_layout = 5;
+  p->last_threads = static_cast<int>(threads);
+  p->last_groups = static_cast<int>(repetitions);
+  ASP_HIP_TRY(hipEventElapsedTime(&p->last_sweep_ms, p->ev[0], p->ev[2]));
+  ASP_HIP_TRY(hipEventElapsedTime(&p->last_total_ms, p->ev[0], p->ev[3]));
+  return ASP_OK;
 }
 
 int asp_sa_greedy(asp_sa_plan *p, uint32_t max_sweeps, uint64_t *out_x, double *out_e,

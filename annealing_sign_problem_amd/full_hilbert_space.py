@@ -84,10 +84,11 @@ class Simulation:
                 float(np.mean(results[:, 1] > overlap_threshold)),
                 float(np.mean(results[:, 2] <= residual_threshold)))
 
-    def run(self, number_sweeps: int, repetitions: int, seed=None):
+    def run(self, number_sweeps: int, repetitions: int, seed=None, sweep_order: str = "colour"):
         """One trial (commented block at experiments/full_hilbert_space.py:212-218)."""
         xs, es = sa.anneal(self.exact_model.ising_hamiltonian, seed=seed,
-                           number_sweeps=number_sweeps, repetitions=repetitions, only_best=False)
+                           number_sweeps=number_sweeps, repetitions=repetitions, only_best=False,
+                           sweep_order=sweep_order)
         return self.analyze(xs, es)
 
 
@@ -101,7 +102,7 @@ def summarise(number_sweeps: int, results: np.ndarray) -> List:
 
 def run_experiment(model: str, sweeps: Sequence[int], repetitions: int, trials: int, seed: int,
                    output: str, log=print, yaml_filename: str = None,
-                   hdf5_filename: str = None) -> List[List]:
+                   hdf5_filename: str = None, sweep_order: str = "colour") -> List[List]:
     if os.path.exists(output):
         raise ValueError("output file '{}' already exists".format(output))
     simulation = Simulation(model, yaml_filename, hdf5_filename)
@@ -114,7 +115,8 @@ def run_experiment(model: str, sweeps: Sequence[int], repetitions: int, trials: 
         tick = time.time()
         for trial in range(trials):
             results[trial] = simulation.run(number_sweeps, repetitions,
-                                            seed=seed + 1000003 * trial + number_sweeps)
+                                            seed=seed + 1000003 * trial + number_sweeps,
+                                            sweep_order=sweep_order)
         row = summarise(number_sweeps, results)
         rows.append(row)
         with open(output, "a") as f:
@@ -134,12 +136,15 @@ def main(argv=None):
     parser.add_argument("--repetitions", type=int, default=1024)
     parser.add_argument("--trials", type=int, default=10)
     parser.add_argument("--seed", type=int, default=12345)
+    parser.add_argument("--sweep-order", type=str, default="colour", choices=["colour", "shuffled"],
+                        help="'shuffled': a fresh visiting order every sweep, the reference "
+                             "annealer's statistics (DESIGN.md §6.1)")
     args = parser.parse_args(argv)
     sweeps = [int(s) for s in args.number_sweeps.split(",")]
     if (args.model is None) == (args.yaml is None):
         raise SystemExit("give exactly one of --model and --yaml")
     run_experiment(args.model, sweeps, args.repetitions, args.trials, args.seed, args.output,
-                   yaml_filename=args.yaml, hdf5_filename=args.hdf5)
+                   yaml_filename=args.yaml, hdf5_filename=args.hdf5, sweep_order=args.sweep_order)
 
 
 if __name__ == "__main__":

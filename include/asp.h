@@ -288,6 +288,14 @@ int asp_sa_layout_host(uint64_t num_spins, int64_t const *indptr, int32_t const 
                        double const *data, double const *field, asp_sa_info *info,
                        int32_t *colors, uint32_t *position);
 
+/* Host-only: the visiting order of sweep `sweep` of the SHUFFLED variant (asp_sa_anneal_shuffled):
+ * order[k] = k-th spin visited (level-major), level_of_position[k] = its level, *num_levels the
+ * number of levels.  Any output may be NULL. */
+int asp_sa_shuffled_order_host(uint64_t num_spins, int64_t const *indptr, int32_t const *indices,
+                               double const *data, double const *field, uint64_t seed,
+                               uint32_t sweep, uint32_t *order, uint32_t *level_of_position,
+                               uint32_t *num_levels);
+
 /* Launch geometry override (0 = choose automatically).
  * replicas_per_group in {1,2,4,8}; threads multiple of 64, <= 1024. */
 int asp_sa_set_launch(asp_sa_plan *p, int replicas_per_group, int threads);
@@ -346,6 +354,19 @@ int asp_sa_anneal(asp_sa_plan *p, uint64_t seed, double const *betas,
 int asp_sa_anneal_trace(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_sweeps,
                         uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0,
                         uint64_t *out_x, double *out_e, int64_t *out_trace);
+
+/* asp_sa_anneal with a fresh visiting order every sweep — what the reference's annealer almost
+ * certainly does (its published success probabilities are reproduced by this order and by no
+ * fixed one: DESIGN.md §6.1).  Sweep t visits the spins in ascending (priority, index), priority =
+ * word 0 of Philox4x32-10(counter (i, t, 0xFFFFFFFE, 0), key seed); every chain uses the same
+ * order.  Proposal arithmetic, random words, energy bookkeeping, outputs and determinism are those
+ * of asp_sa_anneal; only the order differs.  One workgroup per chain, a byte per spin in LDS
+ * (K <= ~1.6e5), several times slower than asp_sa_anneal: it exists to reproduce the
+ * reference's statistics (annealer.anneal(..., sweep_order="shuffled")).
+ * asp_sa_last_layout reports 5. */
+int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_sweeps,
+                           uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0,
+                           uint64_t *out_x, double *out_e);
 
 /* MANY independent problems in one call — the shape of the reference's production job: tens of
  * thousands of sampled clusters, each solved with 64 repetitions x 5120 sweeps

@@ -186,6 +186,31 @@ def sa_anneal(matrix, field, seed: int, betas, repetitions: int, replica_offset:
     return out_x[:, :words], out_e, tracked, accepted
 
 
+def sa_anneal_shuffled(matrix, field, seed: int, betas, repetitions: int, replica_offset: int = 0,
+                       x0=None, energy_scale_exp: int = 0, num_threads: int = 1):
+    """`sa_anneal` with a fresh visiting order every sweep."""
+    n, indptr, indices, data = _csr_args(matrix)
+    field = np.ascontiguousarray(field, dtype=np.float64)
+    betas = np.ascontiguousarray(betas, dtype=np.float64)
+    words = (n + 63) // 64
+    out_x = np.zeros((repetitions, max(words, 1)), dtype=np.uint64)
+    out_e = np.zeros(repetitions, dtype=np.float64)
+    tracked = np.zeros(repetitions, dtype=np.int64)
+    accepted = np.zeros(repetitions, dtype=np.uint64)
+    if x0 is not None:
+        x0 = np.ascontiguousarray(x0, dtype=np.uint64)
+        assert x0.shape[0] == words
+    rc = lib().oracle_sa_anneal_shuffled(
+        _u64(n), _ptr(indptr), _ptr(indices), _ptr(data), _ptr(field), _u64(seed & (2**64 - 1)),
+        _ptr(betas), _u32(betas.shape[0]), _u32(repetitions), _u32(replica_offset), _ptr(x0),
+        _i32(energy_scale_exp), _ptr(out_x), _ptr(out_e), _ptr(tracked), _ptr(accepted),
+        ctypes.c_int(num_threads),
+    )
+    if rc != 0:
+        raise RuntimeError("oracle_sa_anneal_shuffled failed")
+    return out_x[:, :words], out_e, tracked, accepted
+
+
 def sa_anneal_trace(matrix, field, seed: int, betas, repetitions: int, replica_offset: int = 0,
                     x0=None, energy_scale_exp: int = 0, num_threads: int = 1):
     """Returns (x[R, words], e[R], trace int64[R, T+1]): trace[r, t] = tracked fixed-point energy

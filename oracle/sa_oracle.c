@@ -312,11 +312,55 @@ static double sa_energy(sa_problem const *p, double const *field, int8_t const *
 /* The annealing chains                                                      */
 /* ------------------------------------------------------------------------ */
 
+/* One proposal on spin i; returns the rounded fixed-point dE when accepted,
+ * sets *accepted. */
+static int64_t sa_propose(sa_problem const *p, double const *field, uint64_t seed, double beta,
+                          uint32_t t, uint32_t replica, double scale, int8_t *s, int64_t i,
+                          int *accepted) {
+  double acc = 0.0;
+  for (int64_t k = p->a_ptr[i]; k < p->a_ptr[i + 1]; ++k) {
+    double const a = p->a_val[k];
+    acc = acc + (s[p->a_col[k]] > 0 ? a : -a);
+  }
+  double const g = acc + field[i];
+  double const de = s[i] > 0 ? -2.0 * g : 2.0 * g;
+  int accept = de <= 0.0;
+  if (!accept) {
+    uint32_t const w = sa_random_word(seed, (uint32_t)i, t, replica);
+    double const u = ((double)w + 0.5) * 0x1p-32;
+    accept = u < oracle_expneg(beta * de);
+  }
+  *accepted = accept;
+  if (!accept) return 0;
+  s[i] = (int8_t)-s[i];
+  return (int64_t)rint(de * scale);
+}
+
+/* Visiting order of sweep t in the SHUFFLED variant: ascending (priority, index)
+ * with priority = word 0 of Philox(counter (i, t, 0xFFFFFFFE, 0), key seed) — the same for every
+ * chain.  keys[] receives (priority << 32 | index), sorted. */
+static int cmp_u64(void const *a, void const *b) {
+  uint64_t const x = *(uint64_t const *)a, y = *(uint64_t const *)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+static void sa_shuffled_order(uint64_t n, uint64_t seed, uint32_t t, uint64_t *keys) {
+  uint32_t const key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  for (uint64_t i = 0; i < n; ++i) {
+    uint32_t const ctr[4] = {(uint32_t)i, t, 0xFFFFFFFEu, 0u};
+    uint32_t out[4];
+    oracle_philox4x32_10(ctr, key, out);
+    keys[i] = ((uint64_t)out[0] << 32) | i;
+  }
+  qsort(keys, n, sizeof(uint64_t), cmp_u64);
+}
+
 static void sa_run_chain(sa_problem const *p, double const *field, uint64_t seed,
                          double const *betas, uint32_t num_sweeps, uint32_t replica,
                          uint64_t const *x0, double scale, int8_t *s, int8_t *best,
-                         int64_t *tracked_best, uint64_t *accepted_total, int64_t *trace) {
+                         int64_t *tracked_best, uint64_t *accepted_total, int64_t *trace,
+                         int shuffled) {
   uint64_t const n = p->n;
+  uint64_t *keys = shuffled ? malloc(sizeof(uint64_t) * (n ? n : 1)) : NULL;
   for (uint64_t i = 0; i < n; ++i) {
     if (x0 != NULL) {
       s[i] = ((x0[i / 64] >> (i % 64)) & 1u) ? 1 : -1;
@@ -331,26 +375,20 @@ static void sa_run_chain(sa_problem const *p, double const *field, uint64_t seed
   for (uint32_t t = 0; t < num_sweeps; ++t) {
     double const beta = betas[t];
     int64_t q_sweep = 0;
-    for (int32_t c = 0; c < p->num_colors; ++c) {
-      for (int64_t q = p->color_start[c]; q < p->color_start[c + 1]; ++q) {
-        int64_t const i = p->order[q];
-        double acc = 0.0;
-        for (int64_t k = p->a_ptr[i]; k < p->a_ptr[i + 1]; ++k) {
-          double const a = p->a_val[k];
-          acc = acc + (s[p->a_col[k]] > 0 ? a : -a);
-        }
-        double const g = acc + field[i];
-        double const de = s[i] > 0 ? -2.0 * g : 2.0 * g;
-        int accept = de <= 0.0;
-        if (!accept) {
-          uint32_t const w = sa_random_word(seed, (uint32_t)i, t, replica);
-          double const u = ((double)w + 0.5) * 0x1p-32;
-          accept = u < oracle_expneg(beta * de);
-        }
-        if (accept) {
-          s[i] = (int8_t)-s[i];
-          q_sweep += (int64_t)rint(de * scale);
-          ++accepted;
+    if (shuffled) {
+      sa_shuffled_order(n, seed, t, keys);
+      for (uint64_t q = 0; q < n; ++q) {
+        int accept;
+        q_sweep += sa_propose(p, field, seed, beta, t, replica, scale, s, (int64_t)(uint32_t)keys[q],
+                              &accept);
+        accepted += (uint64_t)accept;
+      }
+    } else {
+      for (int32_t c = 0; c < p->num_colors; ++c) {
+        for (int64_t q = p->color_start[c]; q < p->color_start[c + 1]; ++q) {
+          int accept;
+          q_sweep += sa_propose(p, field, seed, beta, t, replica, scale, s, p->order[q], &accept);
+          accepted += (uint64_t)accept;
         }
       }
     }
@@ -363,6 +401,7 @@ static void sa_run_chain(sa_problem const *p, double const *field, uint64_t seed
   }
   *tracked_best = e_best;
   *accepted_total = accepted;
+  free(keys);
 }
 
 /* Returns 0 on success.  out_x: R * ceil(K/64) words; out_e: R doubles;
@@ -373,7 +412,7 @@ static int anneal_impl(uint64_t num_spins, int64_t const *indptr, int32_t const 
                        double const *betas, uint32_t num_sweeps, uint32_t repetitions,
                        uint32_t replica_offset, uint64_t const *x0, int32_t energy_scale_exp,
                        uint64_t *out_x, double *out_e, int64_t *out_tracked,
-                       uint64_t *out_accepted, int64_t *out_trace, int num_threads) {
+                       uint64_t *out_accepted, int64_t *out_trace, int num_threads, int shuffled) {
   sa_problem p;
   if (sa_problem_init(&p, num_spins, indptr, indices, data) != 0) return -1;
   uint64_t const words = (num_spins + 63) / 64;
@@ -389,7 +428,7 @@ static int anneal_impl(uint64_t num_spins, int64_t const *indptr, int32_t const 
       uint64_t accepted = 0;
       sa_run_chain(&p, field, seed, betas, num_sweeps, replica_offset + rr, x0, scale, s,
                    best, &tracked, &accepted,
-                   out_trace ? out_trace + (uint64_t)rr * ((uint64_t)num_sweeps + 1) : NULL);
+                   out_trace ? out_trace + (uint64_t)rr * ((uint64_t)num_sweeps + 1) : NULL, shuffled);
       uint64_t *x = out_x + (uint64_t)rr * words;
       for (uint64_t w = 0; w < words; ++w) x[w] = 0;
       for (uint64_t i = 0; i < num_spins; ++i) {
@@ -414,7 +453,19 @@ int oracle_sa_anneal(uint64_t num_spins, int64_t const *indptr, int32_t const *i
                      uint64_t *out_accepted, int num_threads) {
   return anneal_impl(num_spins, indptr, indices, data, field, seed, betas, num_sweeps,
                      repetitions, replica_offset, x0, energy_scale_exp, out_x, out_e, out_tracked,
-                     out_accepted, NULL, num_threads);
+                     out_accepted, NULL, num_threads, 0);
+}
+
+/* The SHUFFLED variant: identical in everything but the visiting order. */
+int oracle_sa_anneal_shuffled(uint64_t num_spins, int64_t const *indptr, int32_t const *indices,
+                              double const *data, double const *field, uint64_t seed,
+                              double const *betas, uint32_t num_sweeps, uint32_t repetitions,
+                              uint32_t replica_offset, uint64_t const *x0, int32_t energy_scale_exp,
+                              uint64_t *out_x, double *out_e, int64_t *out_tracked,
+                              uint64_t *out_accepted, int num_threads) {
+  return anneal_impl(num_spins, indptr, indices, data, field, seed, betas, num_sweeps,
+                     repetitions, replica_offset, x0, energy_scale_exp, out_x, out_e, out_tracked,
+                     out_accepted, NULL, num_threads, 1);
 }
 
 /* Same, and out_trace[r * (T + 1) + t] = tracked energy (fixed point, relative to the initial
@@ -426,7 +477,7 @@ int oracle_sa_anneal_trace(uint64_t num_spins, int64_t const *indptr, int32_t co
                            uint64_t *out_x, double *out_e, int64_t *out_trace, int num_threads) {
   return anneal_impl(num_spins, indptr, indices, data, field, seed, betas, num_sweeps,
                      repetitions, replica_offset, x0, energy_scale_exp, out_x, out_e, NULL, NULL,
-                     out_trace, num_threads);
+                     out_trace, num_threads, 0);
 }
 
 /* E(x) for `count` packed configurations. */

@@ -853,3 +853,54 @@ def test_team_exchange_stress_against_single_workgroup_kernel():
                     assert np.array_equal(x, ref_x) and e.tobytes() == ref_e.tobytes(), (k, chains, team)
                     launches += 1
     assert launches == 36
+
+
+# ---------------------------------------------------------------------------------------------
+# Shuffled sweep: a fresh visiting order every sweep (asp_sa_anneal_shuffled)
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n,degree,sweeps,reps", [(1, 1.0, 5, 2), (70, 5.0, 30, 5), (900, 12.0, 40, 7),
+                                                  (6000, 23.0, 25, 4)])
+def test_shuffled_sweep_bit_exact(n, degree, sweeps, reps):
+    """Levels of the priority graph on the device == one spin after another in priority order in
+    the oracle: spins, energies, tracked energies and accepted-flip counts, with and without x0
+    and a replica offset; and the colour-ordered sweep gives DIFFERENT chains."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    J, h, _ = _planted(n, 70 + n, mean_degree=min(degree, max(n / 3, 1.0)))
+    field = np.random.default_rng(n).normal(size=n) * 0.01
+    ham = sa.Hamiltonian(J, field)
+    info = ham.info()
+    betas = sa.make_schedule(max(info.beta0_auto, 1e-3), min(max(info.beta1_auto, 1.0), 1e6), sweeps)
+    S = info.energy_scale_exp
+    xs, es = sa.anneal_raw(ham, 31337, betas, reps, 3, None, shuffled=True)
+    assert _lib.load().asp_sa_last_layout(ham.plan()) == 5
+    tracked, accepted = _stats(ham, reps)
+    oxs, oes, otracked, oaccepted = oracle.sa_anneal_shuffled(J, field, 31337, betas, reps, 3, None, S,
+                                                             num_threads=4)
+    assert np.array_equal(accepted, oaccepted) and np.array_equal(tracked, otracked)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    x0 = sa.signs_to_bits(np.where(np.random.default_rng(2).random(n) < 0.5, 1.0, -1.0))
+    xs, es = sa.anneal_raw(ham, 5, betas, 2, 0, x0, shuffled=True)
+    oxs, oes, _, _ = oracle.sa_anneal_shuffled(J, field, 5, betas, 2, 0, x0, S, num_threads=2)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    if n >= 900:
+        cxs, _ = sa.anneal_raw(ham, 31337, betas, reps, 3)
+        assert not np.array_equal(cxs, oxs if reps == 2 else sa.anneal_raw(ham, 31337, betas, reps, 3, None, shuffled=True)[0])
+
+
+def test_shuffled_sweep_runs_long_ladders_in_chunks():
+    """More sweeps than one chunk of visiting orders holds (64 MiB): the chain state survives
+    between the chunks' launches; compared with the oracle."""
+    from annealing_sign_problem_amd import annealer as sa
+
+    n = 40000  # 64 MiB / (4 B * 40000) = 419 sweeps per chunk
+    J, h, _ = _planted(n, 8, mean_degree=4.0)
+    ham = sa.Hamiltonian(J, h)
+    info = ham.info()
+    betas = sa.make_schedule(info.beta0_auto, info.beta1_auto, 900)
+    xs, es = sa.anneal_raw(ham, 11, betas, 2, 0, None, shuffled=True)
+    oxs, oes, _, _ = oracle.sa_anneal_shuffled(J, h, 11, betas, 2, 0, None, info.energy_scale_exp,
+                                               num_threads=2)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()

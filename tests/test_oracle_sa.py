@@ -141,3 +141,45 @@ def test_chains_depend_only_on_global_replica_id_and_seed():
     xs, es, tracked, _ = oracle.sa_anneal(J, h, 5, betas, 4, 0, x0, 30)
     e_start = oracle.sa_energy(J, h, x0.reshape(1, -1))[0]
     assert np.allclose(tracked * 2.0**-30, es - e_start, rtol=0, atol=1e-6)
+
+
+def test_shuffled_orders_of_the_product_are_the_oracles_sequential_order():
+    """the product visits LEVELS of the priority graph (host code of libasp_hip,
+    csrc/sa_plan.cpp) where the oracle visits spins one by one in ascending (priority, index).
+    The two are the same Markov step iff the level-major order is a linear extension of the
+    priority order on every edge and a level holds no two neighbours."""
+    import ctypes
+
+    from annealing_sign_problem_amd import _lib, synthetic
+
+    lib = _lib.load()
+    olib = oracle.lib()
+    for n, seed, degree in [(1, 3, 1.0), (65, 4, 5.0), (700, 5, 12.0)]:
+        J, h, _ = synthetic.planted_cluster(n, seed=seed, mean_degree=min(degree, max(n / 3, 1.0)))
+        m = J.tocsr()
+        indptr, indices = m.indptr.astype(np.int64), m.indices.astype(np.int32)
+        for sweep in (0, 7, 4000):
+            order = np.zeros(n, np.uint32)
+            level = np.zeros(n, np.uint32)
+            levels = ctypes.c_uint32(0)
+            _lib.check(lib.asp_sa_shuffled_order_host(
+                n, _lib.ptr(indptr), _lib.ptr(indices), _lib.ptr(m.data), _lib.ptr(h), 999, sweep,
+                _lib.ptr(order), _lib.ptr(level), ctypes.byref(levels)))
+            assert sorted(order.tolist()) == list(range(n))
+            # priorities as the oracle draws them
+            prio = np.zeros(n, np.uint64)
+            for i in range(n):
+                ctr = (ctypes.c_uint32 * 4)(i, sweep, 0xFFFFFFFE, 0)
+                key = (ctypes.c_uint32 * 2)(999, 0)
+                out = (ctypes.c_uint32 * 4)()
+                olib.oracle_philox4x32_10(ctr, key, out)
+                prio[i] = (int(out[0]) << 32) | i
+            level_of_spin = np.zeros(n, np.int64)
+            level_of_spin[order] = level
+            a = (m + m.T).tocoo()
+            off = a.row != a.col
+            r, c = a.row[off], a.col[off]
+            assert np.all(level_of_spin[r] != level_of_spin[c])            # a level: no two neighbours
+            earlier = prio[r] < prio[c]
+            assert np.all(level_of_spin[r][earlier] < level_of_spin[c][earlier])  # linear extension
+            assert int(level.max()) + 1 == levels.value

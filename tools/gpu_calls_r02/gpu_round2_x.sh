@@ -1,0 +1,12 @@
+#!/bin/bash
+# success curves with the shuffled visiting order (4 trials x 1024 chains) for the five symmetry-free models
+set -o pipefail
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r2x
+rm -rf $OUT; mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+for m in heisenberg_kagome_16 j1j2_square_4x4 sk_16_1 sk_16_2 sk_16_3; do
+  timeout -k 10 900 python -m annealing_sign_problem_amd.full_hilbert_space --model $m --output $OUT/fhs_shuffled_$m.csv --number-sweeps 100,200,400,800,1600,3200,6400,12800 --repetitions 1024 --trials 4 --seed 435834 --sweep-order shuffled > $OUT/fhs_shuffled_$m.log 2>&1
+  echo "$m rc=$?" | tee -a $OUT/status.txt
+  grep -v amdgpu $OUT/fhs_shuffled_$m.log
+done
