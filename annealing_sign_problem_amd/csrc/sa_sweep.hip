@@ -1291,45 +1291,67 @@ struct ShuffledArgs {
   const uint32_t *level_start;  // [chunk][cap]
   const uint32_t *num_levels;   // [chunk]
   const uint64_t *x0;           // packed original-order start configuration or nullptr
-  uint8_t *spins;               // [chains][K] 1 = s is -1 (state between chunks)
-  uint8_t *best;                // [chains][K]
-  long long *e_cur, *e_best;    // [chains] tracked energies (fixed point)
-  unsigned long long *accepted; // [chains]
+  uint8_t *spins;               // [groups][K] bit m = chain m of the group is -1 (state between chunks)
+  uint8_t *best;                // [groups * M][K] a byte per spin of every chain's best configuration
+  long long *e_cur, *e_best;    // [groups * M] tracked energies (fixed point)
+  unsigned long long *accepted; // [groups * M]
   uint64_t seed;
   double scale;
   uint32_t num_spins, cap, first_sweep, chunk_sweeps, replica_first, initialise;
 };
 
+// M chains per workgroup: the visiting order is the same for every chain, so a row
+// gathered from the CSR serves all of them (bit m of a spin's LDS byte = chain m is -1).
+// (4 when 8 would leave compute units without a workgroup.)
+template <int M>
 __global__ __launch_bounds__(1024) void k_sa_sweep_shuffled(ShuffledArgs a) {
   extern __shared__ __align__(16) uint8_t lds[];
   const uint32_t K = a.num_spins;
   uint8_t *s = lds;  // K bytes, then the bookkeeping
-  long long *book = reinterpret_cast<long long *>(lds + ((K + 15u) & ~15u));  // [0] dq, [1] dn, [2] flag
+  // book: [0..M) dq of the running sweep, [M..2M) accepted flips of it, [2M..3M) current tracked
+  // energy, [3M..4M) best, [4M..5M) accepted so far
+  long long *book = reinterpret_cast<long long *>(lds + ((K + 15u) & ~15u));
   const uint32_t tid = threadIdx.x;
-  const uint32_t chain = blockIdx.x;
-  const uint32_t r = a.replica_first + chain;
+  const uint32_t group = blockIdx.x;
+  const uint32_t r0 = a.replica_first + group * M;
   const uint32_t key0 = static_cast<uint32_t>(a.seed), key1 = static_cast<uint32_t>(a.seed >> 32);
-  uint8_t *my_spins = a.spins + static_cast<uint64_t>(chain) * K;
-  uint8_t *my_best = a.best + static_cast<uint64_t>(chain) * K;
+  uint8_t *my_spins = a.spins + static_cast<uint64_t>(group) * K;
   if (a.initialise) {
     for (uint32_t i = tid; i < K; i += blockDim.x) {
-      uint32_t up;
+      uint32_t mask = 0;
       if (a.x0 != nullptr) {
-        up = static_cast<uint32_t>((a.x0[i >> 6] >> (i & 63u)) & 1ull);
+        mask = ((a.x0[i >> 6] >> (i & 63u)) & 1ull) ? 0u : ((1u << M) - 1u);
       } else {
-        const Philox4 rnd = philox4x32_10(i, 0xFFFFFFFFu, r >> 2, 0u, key0, key1);
-        up = pick_word(rnd, r & 3u) & 1u;
+        Philox4 rnd{};
+        uint32_t have = 0xFFFFFFFFu;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          const uint32_t r = r0 + m;
+          if (m == 0 || (r >> 2) != have) {
+            have = r >> 2;
+            rnd = philox4x32_10(i, 0xFFFFFFFFu, have, 0u, key0, key1);
+          }
+          mask |= ((pick_word(rnd, r & 3u) & 1u) ^ 1u) << m;
+        }
       }
-      s[i] = static_cast<uint8_t>(up ^ 1u);
-      my_best[i] = static_cast<uint8_t>(up ^ 1u);
+      s[i] = static_cast<uint8_t>(mask);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        a.best[(static_cast<uint64_t>(group) * M + m) * K + i] = static_cast<uint8_t>((mask >> m) & 1u);
+      }
     }
   } else {
     for (uint32_t i = tid; i < K; i += blockDim.x) s[i] = my_spins[i];
   }
-  if (tid < 3) book[tid] = 0;
-  long long e_cur = a.initialise ? 0 : a.e_cur[chain];
-  long long e_best = a.initialise ? 0 : a.e_best[chain];
-  unsigned long long accepted = a.initialise ? 0ull : a.accepted[chain];
+  if (tid < 5 * M) {
+    long long v = 0;
+    if (!a.initialise && tid >= 2 * M) {
+      const uint32_t m = tid % M;
+      const uint64_t at = static_cast<uint64_t>(group) * M + m;
+      v = tid < 3 * M ? a.e_cur[at] : (tid < 4 * M ? a.e_best[at] : static_cast<long long>(a.accepted[at]));
+    }
+    book[tid] = v;
+  }
   __syncthreads();
   for (uint32_t tt = 0; tt < a.chunk_sweeps; ++tt) {
     const uint32_t t = a.first_sweep + tt;
@@ -1337,60 +1359,118 @@ __global__ __launch_bounds__(1024) void k_sa_sweep_shuffled(ShuffledArgs a) {
     const uint32_t *order = a.order + static_cast<uint64_t>(tt) * K;
     const uint32_t *starts = a.level_start + static_cast<uint64_t>(tt) * a.cap;
     const uint32_t levels = a.num_levels[tt];
-    long long q = 0;
-    uint32_t n = 0;
+    long long q[M];
+    uint32_t n[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      q[m] = 0;
+      n[m] = 0;
+    }
+    // Every level is a chain of dependent loads (its bounds -> order -> row pointers -> the row):
+    // the bounds are fetched two levels ahead and the row comes in blocks of 8 entries in flight.
+    uint32_t begin = starts[0];
+    uint32_t end = starts[levels ? 1u : 0u];
     for (uint32_t l = 0; l < levels; ++l) {
-      const uint32_t end = starts[l + 1];
-      for (uint32_t idx = starts[l] + tid; idx < end; idx += blockDim.x) {
+      const uint32_t after = starts[l + 2 <= levels ? l + 2 : levels];
+      for (uint32_t idx = begin + tid; idx < end; idx += blockDim.x) {
         const uint32_t i = order[idx];
-        double acc = 0.0;
-        for (int64_t k = a.a_ptr[i]; k < a.a_ptr[i + 1]; ++k) {
-          const double v = a.a_val[k];
-          acc = __dadd_rn(acc, s[a.a_col[k]] ? -v : v);
+        double acc[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[m] = 0.0;
+        const int64_t row_end = a.a_ptr[i + 1];
+        for (int64_t k = a.a_ptr[i]; k < row_end; k += 8) {
+          double v[8];
+          uint32_t c[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int64_t at = k + j < row_end ? k + j : row_end - 1;
+            v[j] = a.a_val[at];
+            c[j] = static_cast<uint32_t>(a.a_col[at]);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (k + j < row_end) {  // in the order of the row: the sums are those of the oracle
+              const uint32_t byte = s[c[j]];
+#pragma unroll
+              for (int m = 0; m < M; ++m) acc[m] = __dadd_rn(acc[m], ((byte >> m) & 1u) ? -v[j] : v[j]);
+            }
+          }
         }
-        const double g = __dadd_rn(acc, a.field[i]);
-        const bool negative = s[i] != 0;
-        const double de = __dmul_rn(negative ? 2.0 : -2.0, g);
-        bool accept = de <= 0.0;
-        if (!accept) {
-          const Philox4 rnd = philox4x32_10(i, t, r >> 2, 0u, key0, key1);
-          accept = metropolis_accept_word(pick_word(rnd, r & 3u), __dmul_rn(beta, de));
+        const double h = a.field[i];
+        const uint32_t own = s[i];
+        uint32_t flip = 0;
+        Philox4 rnd{};
+        uint32_t have = 0xFFFFFFFFu;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          const double g = __dadd_rn(acc[m], h);
+          const bool negative = (own >> m) & 1u;
+          const double de = __dmul_rn(negative ? 2.0 : -2.0, g);
+          bool accept = de <= 0.0;
+          if (!accept) {
+            const uint32_t r = r0 + m;
+            if ((r >> 2) != have) {
+              have = r >> 2;
+              rnd = philox4x32_10(i, t, have, 0u, key0, key1);
+            }
+            accept = metropolis_accept_word(pick_word(rnd, r & 3u), __dmul_rn(beta, de));
+          }
+          if (accept) {
+            flip |= 1u << m;
+            q[m] += __double_as_longlong(__dadd_rn(__dmul_rn(de, a.scale), 0x1.8p52)) - 0x4338000000000000ll;
+            n[m] += 1;
+          }
         }
-        if (accept) {
-          s[i] = static_cast<uint8_t>(negative ? 0 : 1);  // no neighbour of i is in this level
-          q += __double_as_longlong(__dadd_rn(__dmul_rn(de, a.scale), 0x1.8p52)) - 0x4338000000000000ll;
-          n += 1;
-        }
+        if (flip) s[i] = static_cast<uint8_t>(own ^ flip);  // no neighbour of i is in this level
       }
       __syncthreads();
+      begin = end;
+      end = after;
     }
-    // exact (integer) reduction of the sweep's energy change
-    const long long wq = wave_sum_i64(q);
-    const long long wn = wave_sum_i64(static_cast<long long>(n));
-    if ((tid & 63u) == 0 && wn != 0) {
-      atomicAdd(reinterpret_cast<unsigned long long *>(&book[0]), static_cast<unsigned long long>(wq));
-      atomicAdd(reinterpret_cast<unsigned long long *>(&book[1]), static_cast<unsigned long long>(wn));
+    // exact (integer) reduction of the sweep's energy change, per chain
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const long long wq = wave_sum_i64(q[m]);
+      const long long wn = wave_sum_i64(static_cast<long long>(n[m]));
+      if ((tid & 63u) == 0 && wn != 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&book[m]), static_cast<unsigned long long>(wq));
+        atomicAdd(reinterpret_cast<unsigned long long *>(&book[M + m]), static_cast<unsigned long long>(wn));
+      }
     }
     __syncthreads();
-    e_cur += book[0];                                   // (every thread keeps the same copies)
-    accepted += static_cast<unsigned long long>(book[1]);
-    const bool improved = e_cur < e_best;
-    if (improved) e_best = e_cur;
+    uint32_t improved = 0;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      improved |= (book[2 * M + m] + book[m] < book[3 * M + m]) ? (1u << m) : 0u;  // same in every thread
+    }
     __syncthreads();
-    if (tid == 0) {
-      book[0] = 0;
-      book[1] = 0;
+    if (tid < M) {
+      const long long e = book[2 * M + tid] + book[tid];
+      book[2 * M + tid] = e;
+      if (e < book[3 * M + tid]) book[3 * M + tid] = e;
+      book[4 * M + tid] += book[M + tid];
+      book[tid] = 0;
+      book[M + tid] = 0;
     }
     if (improved) {
-      for (uint32_t i = tid; i < K; i += blockDim.x) my_best[i] = s[i];
+      for (uint32_t i = tid; i < K; i += blockDim.x) {
+        const uint32_t byte = s[i];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          if ((improved >> m) & 1u) {
+            a.best[(static_cast<uint64_t>(group) * M + m) * K + i] = static_cast<uint8_t>((byte >> m) & 1u);
+          }
+        }
+      }
     }
     __syncthreads();
   }
   for (uint32_t i = tid; i < K; i += blockDim.x) my_spins[i] = s[i];
-  if (tid == 0) {
-    a.e_cur[chain] = e_cur;
-    a.e_best[chain] = e_best;
-    a.accepted[chain] = accepted;
+  if (tid < M) {
+    const uint64_t at = static_cast<uint64_t>(group) * M + tid;
+    a.e_cur[at] = book[2 * M + tid];
+    a.e_best[at] = book[3 * M + tid];
+    a.accepted[at] = static_cast<unsigned long long>(book[4 * M + tid]);
   }
 }
 
@@ -2247,7 +2327,8 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
     for (uint32_t r = 0; r < repetitions; ++r) out_e[r] = 0.0;
     return ASP_OK;
   }
-  const size_t lds = ((K + 15) & ~size_t{15}) + 64;
+  const uint32_t per_group = (repetitions + 7) / 8 >= static_cast<uint32_t>(p->num_cus) ? 8u : 4u;
+  const size_t lds = ((K + 15) & ~size_t{15}) + 5 * per_group * sizeof(long long);
   if (lds > p->max_lds) {
     return asp::set_error(ASP_ERR_TOO_LARGE, "the shuffled sweep keeps a byte per spin in LDS: %llu "
                                              "spins do not fit", (unsigned long long)K);
@@ -2264,24 +2345,23 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
     ASP_TRY(upload_vector(p->field_dev, field, s));
     ASP_HIP_TRY(hipStreamSynchronize(s));  // `field` dies with this scope
   }
-  // sweeps per chunk: at most 64 MiB of visiting orders at a time
+  // sweeps per chunk: at most 32 MiB of visiting orders at a time (two such buffers)
   const uint32_t chunk = static_cast<uint32_t>(std::max<uint64_t>(
-      1, std::min<uint64_t>(num_sweeps ? num_sweeps : 1, (64ull << 20) / (4 * K))));
+      1, std::min<uint64_t>(num_sweeps ? num_sweeps : 1, (32ull << 20) / (4 * K))));
   DeviceBuffer<double> d_betas, d_partial, d_e;
-  DeviceBuffer<uint32_t> d_order, d_starts, d_levels;
   DeviceBuffer<uint64_t> d_x0, d_x, d_perm;
   DeviceBuffer<uint8_t> d_spins, d_best;
   DeviceBuffer<long long> d_ecur, d_ebest;
   DeviceBuffer<unsigned long long> d_accepted;
   asp::StreamFence fence2(s);  // (declared after the buffers: waits before they are released)
   ASP_TRY(d_betas.alloc(num_sweeps));
-  ASP_TRY(d_order.alloc(static_cast<uint64_t>(chunk) * K));
-  ASP_TRY(d_levels.alloc(chunk));
-  ASP_TRY(d_spins.alloc(static_cast<uint64_t>(repetitions) * K));
-  ASP_TRY(d_best.alloc(static_cast<uint64_t>(repetitions) * K));
-  ASP_TRY(d_ecur.alloc(repetitions));
-  ASP_TRY(d_ebest.alloc(repetitions));
-  ASP_TRY(d_accepted.alloc(repetitions));
+  const uint32_t groups = (repetitions + per_group - 1) / per_group;
+  const uint64_t padded = static_cast<uint64_t>(groups) * per_group;
+  ASP_TRY(d_spins.alloc(static_cast<uint64_t>(groups) * K));
+  ASP_TRY(d_best.alloc(padded * K));
+  ASP_TRY(d_ecur.alloc(padded));
+  ASP_TRY(d_ebest.alloc(padded));
+  ASP_TRY(d_accepted.alloc(padded));
   ASP_TRY(d_x.alloc(static_cast<uint64_t>(repetitions) * words));
   ASP_TRY(d_perm.alloc(static_cast<uint64_t>(repetitions) * L.num_blocks));
   ASP_TRY(d_partial.alloc(static_cast<uint64_t>(repetitions) * L.num_blocks));
@@ -2297,9 +2377,6 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
   a.a_val = p->a_val_dev.ptr;
   a.field = p->field_dev.ptr;
   a.betas = d_betas.ptr;
-  a.order = d_order.ptr;
-  a.level_start = d_starts.ptr;
-  a.num_levels = d_levels.ptr;
   a.x0 = x0 ? d_x0.ptr : nullptr;
   a.spins = d_spins.ptr;
   a.best = d_best.ptr;
@@ -2310,32 +2387,55 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
   a.scale = std::ldexp(1.0, L.energy_scale_exp);
   a.num_spins = static_cast<uint32_t>(K);
   a.replica_first = replica_offset;
+  void (*kernel)(ShuffledArgs) = per_group == 8 ? k_sa_sweep_shuffled<8> : k_sa_sweep_shuffled<4>;
   if (lds > 64 * 1024) {
-    ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sa_sweep_shuffled),
+    ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
   }
   const unsigned threads = K >= 4096 ? 1024u : (K >= 512 ? 256u : 64u);
-  std::vector<uint32_t> h_order(static_cast<size_t>(chunk) * K), h_starts, h_levels(chunk);
+  // Two sets of order buffers: the host draws and levels chunk c + 1 while the kernel runs chunk c.
+  struct OrderSet {
+    std::vector<uint32_t> order, starts, levels;
+    DeviceBuffer<uint32_t> d_order, d_starts, d_levels;
+    hipEvent_t consumed = nullptr;
+    ~OrderSet() {
+      if (consumed) (void)hipEventDestroy(consumed);
+    }
+  } sets[2];
+  asp::StreamFence fence3(s);  // the sets outlive the work queued on them
+  for (OrderSet &o : sets) {
+    o.order.resize(static_cast<size_t>(chunk) * K);
+    o.levels.resize(chunk);
+    ASP_TRY(o.d_order.alloc(static_cast<uint64_t>(chunk) * K));
+    ASP_TRY(o.d_levels.alloc(chunk));
+    ASP_HIP_TRY(hipEventCreateWithFlags(&o.consumed, hipEventDisableTiming));
+    if (num_sweeps <= chunk) break;  // a single chunk needs one set
+  }
   ASP_HIP_TRY(hipEventRecord(p->ev[0], s));
   bool first_launch = true;
-  for (uint32_t done = 0; done < num_sweeps || first_launch; done += chunk) {
+  uint32_t turn = 0;
+  for (uint32_t done = 0; done < num_sweeps || first_launch; done += chunk, ++turn) {
     const uint32_t now = num_sweeps > done ? std::min(chunk, num_sweeps - done) : 0u;
+    OrderSet &o = sets[turn & 1u];
     if (now) {
+      if (turn >= 2) ASP_HIP_TRY(hipEventSynchronize(o.consumed));  // the kernel of two chunks ago is through
       uint32_t cap = 0;
-      asp::shuffled_orders(L, seed, done, now, h_order.data(), &h_starts, &cap, h_levels.data());
+      asp::shuffled_orders(L, seed, done, now, o.order.data(), &o.starts, &cap, o.levels.data());
       a.cap = cap;
-      ASP_TRY(d_starts.ensure(h_starts.size()));
-      a.level_start = d_starts.ptr;
-      ASP_TRY(d_order.upload(h_order.data(), static_cast<size_t>(now) * K, s));
-      ASP_TRY(d_starts.upload(h_starts.data(), h_starts.size(), s));
-      ASP_TRY(d_levels.upload(h_levels.data(), now, s));
+      ASP_TRY(o.d_starts.ensure(o.starts.size()));
+      ASP_TRY(o.d_order.upload(o.order.data(), static_cast<size_t>(now) * K, s));
+      ASP_TRY(o.d_starts.upload(o.starts.data(), o.starts.size(), s));
+      ASP_TRY(o.d_levels.upload(o.levels.data(), now, s));
     }
+    a.order = o.d_order.ptr;
+    a.level_start = o.d_starts.ptr;
+    a.num_levels = o.d_levels.ptr;
     a.first_sweep = done;
     a.chunk_sweeps = now;
     a.initialise = first_launch ? 1u : 0u;
-    hipLaunchKernelGGL(k_sa_sweep_shuffled, dim3(repetitions), dim3(threads), lds, s, a);
+    hipLaunchKernelGGL(kernel, dim3(groups), dim3(threads), lds, s, a);
     ASP_HIP_TRY(hipGetLastError());
-    ASP_HIP_TRY(hipStreamSynchronize(s));  // the host buffers are refilled for the next chunk
+    ASP_HIP_TRY(hipEventRecord(o.consumed, s));
     first_launch = false;
   }
   ASP_HIP_TRY(hipEventRecord(p->ev[2], s));
@@ -2361,10 +2461,10 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
   ASP_HIP_TRY(hipMemcpyAsync(p->last_accepted.data(), d_accepted.ptr, repetitions * sizeof(uint64_t),
                              hipMemcpyDeviceToHost, s));
   ASP_HIP_TRY(hipStreamSynchronize(s));
-  p->last_m = 1;
+  p->last_m = static_cast<int>(per_group);
   p->last_layout = 5;
   p->last_threads = static_cast<int>(threads);
-  p->last_groups = static_cast<int>(repetitions);
+  p->last_groups = static_cast<int>(groups);
   ASP_HIP_TRY(hipEventElapsedTime(&p->last_sweep_ms, p->ev[0], p->ev[2]));
   ASP_HIP_TRY(hipEventElapsedTime(&p->last_total_ms, p->ev[0], p->ev[3]));
   return ASP_OK;

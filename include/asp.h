@@ -360,9 +360,9 @@ int asp_sa_anneal_trace(asp_sa_plan *p, uint64_t seed, double const *betas, uint
  * fixed one: DESIGN.md §6.1).  Sweep t visits the spins in ascending (priority, index), priority =
  * word 0 of Philox4x32-10(counter (i, t, 0xFFFFFFFE, 0), key seed); every chain uses the same
  * order.  Proposal arithmetic, random words, energy bookkeeping, outputs and determinism are those
- * of asp_sa_anneal; only the order differs.  One workgroup per chain, a byte per spin in LDS
- * (K <= ~1.6e5), several times slower than asp_sa_anneal: it exists to reproduce the
- * reference's statistics (annealer.anneal(..., sweep_order="shuffled")).
+ * of asp_sa_anneal; only the order differs.  Eight (or four) chains per workgroup, a byte per
+ * spin in LDS (K <= ~1.6e5), about ten times slower than asp_sa_anneal: it exists to reproduce
+ * the reference's statistics (annealer.anneal(..., sweep_order="shuffled")).
  * asp_sa_last_layout reports 5. */
 int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_sweeps,
                            uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0,
