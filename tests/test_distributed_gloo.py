@@ -31,7 +31,7 @@ def _worker(rank, world, port, repetitions, out_dir):
     J, h, _ = synthetic.planted_cluster(300, seed=3, mean_degree=8.0)
     betas = np.geomspace(0.5, 100.0, 15)
 
-    def fake_anneal_raw(hamiltonian, seed, betas, count, offset=0, x0=None):
+    def fake_anneal_raw(hamiltonian, seed, betas, count, offset=0, x0=None, shuffled=False):
         xs, es, _, _ = oracle.sa_anneal(hamiltonian.exchange, hamiltonian.field, seed, betas, count,
                                         offset, x0, 40)
         return xs, es
@@ -89,7 +89,7 @@ def _cluster_worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank,
                             world_size=world)
 
-    def fake_anneal_raw(hamiltonian, seed, betas, count, offset=0, x0=None):
+    def fake_anneal_raw(hamiltonian, seed, betas, count, offset=0, x0=None, shuffled=False):
         xs, es, _, _ = oracle.sa_anneal(hamiltonian.exchange, hamiltonian.field, seed, betas, count,
                                         offset, x0, 40)
         return xs, es
@@ -157,7 +157,7 @@ def _main_worker(rank, world, port, out_path, expect_refusal):
 
     sc.generate_clusters = fake_clusters
     sc.process_cluster = fake_process
-    sc.process_clusters_batched = lambda clusters, *rest: [fake_process(c, *rest) for c in clusters]
+    sc.process_clusters_batched = lambda clusters, *rest, jobs=1: [fake_process(c, *rest) for c in clusters]
     argv = ["--model", "heisenberg_kagome_16", "--output", out_path, "--order", "1",
             "--number-samples", "5", "--seed", "3"]
     if expect_refusal:
