@@ -10,8 +10,10 @@ seeds, and requires P(accuracy > 0.995)
   * within +-0.08 of the published value: specification ASP-SA-1 is a different Markov chain
     from the library's and statistically distinguishable from it — on the symmetry-free models
     it reaches the exact sign structure as often or more often (up to +0.078, 15 standard errors),
-    on the symmetry-adapted kagome_18 basis less often at 400 sweeps (-0.033), DESIGN.md §6.1 —
-    so this band only catches gross changes;
+    DESIGN.md §6.1; the ground level of the kagome_18 basis is three-fold degenerate, so its
+    published curve belongs to ANOTHER eigenvector than the one diagonalised here and the success
+    probability moves by up to 0.09 with that choice (profiles/r02_kagome18_degeneracy_probe.txt)
+    — so this band only catches gross changes;
   * within +-0.03 of this repository's own recorded measurement (10 x 1024 chains; 4 standard
     errors of the difference are 0.03), the regression pin proper;
 and, as in every row of the published CSVs, P(residual <= 1e-12) == P(accuracy > 0.995).
