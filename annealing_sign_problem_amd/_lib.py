@@ -92,6 +92,10 @@ SIGNATURES = {
     "asp_operator_destroy": (None, [c_void_p]),
     "asp_operator_set_symmetry": (c_int, [c_void_p, c_u32, c_void_p, c_i32]),
     "asp_operator_state_info": (c_int, [c_void_p, c_u64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "asp_sector_enumerate": (c_int, [c_void_p, c_i32, c_u64, c_void_p, c_void_p, ctypes.POINTER(c_u64)]),
+    "asp_sector_width": (ctypes.c_uint32, [c_void_p]),
+    "asp_sector_rows": (c_int, [c_void_p, c_u64, c_void_p, c_void_p, c_u32, c_void_p, c_void_p, c_void_p]),
+    "asp_sector_matvec": (c_int, [c_u64, c_u32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "asp_operator_unique_targets": (c_int, [c_void_p]),
     "asp_operator_max_connections": (ctypes.c_uint32, [c_void_p]),
     "asp_operator_apply": (c_int, [c_void_p, c_u64, c_void_p, c_u64, c_void_p, c_void_p, c_void_p,

@@ -29,6 +29,7 @@ SOURCES = [
     "build_matrix.hip",
     "ising_elements.hip",
     "operator_apply.hip",
+    "sector_basis.hip",
     "sparsify.hip",
     "sa_plan.cpp",
     "greedy.cpp",

@@ -25,19 +25,16 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "asp_common.hpp"
+#include "operator_internal.hpp"
 
 namespace {
 
+using asp::Bond;
 using asp::DeviceBuffer;
+using asp::SymmetryArgs;
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-
-struct Bond {
-  double m[16];  // m[dst * 4 + src]
-  uint32_t a, b;
-  uint64_t flip[4];  // flip[x] = key bits toggled by a transition with src ^ dst == x
-};
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
   x ^= x >> 30;
@@ -460,14 +457,6 @@ __global__ __launch_bounds__(kThreads) void k_scatter_first(const uint64_t *__re
 // destination table (u8[P][64], site i -> table[g][i]) is read with scalar loads.  Spin inversion
 // needs no second walk: the flipped image is the complement of the plain one.
 
-struct SymmetryArgs {
-  const uint8_t *table;  // [num_permutations][64]
-  uint32_t num_permutations;
-  uint32_t number_spins;
-  int32_t inversion;  // 0, +1, -1
-  uint64_t mask;      // low number_spins bits
-};
-
 struct StateInfo {
   uint64_t representative;
   double character;  // of an element mapping the state onto its representative
@@ -573,23 +562,6 @@ unsigned grid_for(uint64_t items, uint64_t per_block) {
 }
 
 }  // namespace
-
-struct asp_operator {
-  uint32_t number_spins = 0;
-  uint32_t num_bonds = 0;
-  uint32_t max_connections = 1;
-  bool unique_targets = true;
-  std::vector<Bond> bonds;
-  DeviceBuffer<Bond> d_bonds;
-  // symmetry-adapted basis (asp_operator_set_symmetry); num_permutations == 0: plain basis
-  uint32_t num_permutations = 0;
-  int32_t inversion = 0;
-  DeviceBuffer<uint8_t> d_table;
-  SymmetryArgs symmetry() const {
-    return SymmetryArgs{d_table.ptr, num_permutations, number_spins, inversion,
-                        number_spins >= 64 ? ~0ull : ((1ull << number_spins) - 1ull)};
-  }
-};
 
 namespace {
 

@@ -1,0 +1,237 @@
+"""Ground states of whole symmetry sectors, diagonalised on the GPU.
+
+The reference reads its ground states from files written by SpinED (``common.py:783-803``:
+``/basis/representatives``, ``/hamiltonian/eigenvectors``; ``experiments/*.py`` take them through
+``--hdf5``).  Those files are not part of the reference tree.  For the 16- and 18-site models the
+host route (:meth:`.operators.Operator.ground_state`: numpy enumeration + scipy) regenerates them
+in seconds; for ``heisenberg_pyrochlore_2x2x2.yaml`` (32 sites, 1.6 million representatives)
+and ``heisenberg_kagome_36.yaml`` (36 sites, 31.5 million) it cannot.  This module can, on
+one MI355X:
+
+  1. ``asp_sector_enumerate``  (csrc/sector_basis.hip) lists the representatives of the sector;
+  2. ``asp_sector_rows``       builds the sector's Hamiltonian ONCE as an ELL matrix that stays in
+     HBM (kagome_36: 72 slots x 31.5 M rows x 12 B = 27 GB of the 288 GB);
+  3. Lanczos with full reorthogonalisation: one ``asp_sector_matvec`` per step, the Krylov basis
+     kept on the device too (250 MB per vector); BLAS-1/2 glue through torch.
+
+Output in the layout the reference's loaders expect (:func:`write_spined_hdf5`), so that the
+reference's own command lines (``--yaml ... --hdf5 ...``) run on it.
+
+Device memory and streams come from torch (plumbing); the kernels are the library's.  No CPU
+fallback: without a GPU these functions raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import time
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("sector_ed needs a GPU (no CPU fallback; small models: Operator.ground_state)")
+    return torch
+
+
+def _ptr(tensor) -> ctypes.c_void_p:
+    return ctypes.c_void_p(tensor.data_ptr())
+
+
+def binomial(n: int, k: int) -> int:
+    out = 1
+    for j in range(k):
+        out = out * (n - j) // (j + 1)
+    return out
+
+
+def enumerate_sector(operator, log=None) -> Tuple["torch.Tensor", "torch.Tensor"]:
+    """``(representatives int64[K] (the u64 states), norms f64[K])`` on the device, ascending:
+    the basis of ``operator`` (an :class:`.operators.Operator`; its magnetisation, lattice
+    symmetries and spin inversion)."""
+    torch = _torch()
+    lib = _lib.load()
+    device_operator = operator.device()
+    basis = operator.basis
+    weight = -1 if basis.hamming_weight is None else int(basis.hamming_weight)
+    total = (1 << basis.number_spins) if weight < 0 else binomial(basis.number_spins, weight)
+    order = basis.group.order if basis.group is not None else 1
+    capacity = int(total / order * 1.25) + 4096
+    count = ctypes.c_uint64(0)
+    tick = time.time()
+    for _ in range(2):
+        reps = torch.empty(capacity, dtype=torch.int64, device="cuda")
+        norms = torch.empty(capacity, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        rc = lib.asp_sector_enumerate(device_operator._handle, weight, capacity, _ptr(reps), _ptr(norms),
+                                      ctypes.byref(count))
+        if rc == 0:
+            break
+        if count.value <= capacity:
+            _lib.check(rc)
+        capacity = int(count.value)  # states with large stabilisers: more orbits than total / |G|
+    else:
+        _lib.check(rc)
+    if log:
+        log("sector of %d spins: %d representatives of %d states (|G| = %d) in %.2f s" % (
+            basis.number_spins, count.value, total, order, time.time() - tick))
+    return reps[: count.value], norms[: count.value]
+
+
+class SectorMatrix:
+    """The operator in its sector basis, resident in HBM (ELL, slot-major)."""
+
+    def __init__(self, operator, representatives, norms, log=None):
+        torch = _torch()
+        lib = _lib.load()
+        device_operator = operator.device()
+        self.n = int(representatives.shape[0])
+        self.width = int(lib.asp_sector_width(device_operator._handle))
+        self.idx = torch.empty((self.width, self.n), dtype=torch.int32, device="cuda")
+        self.val = torch.empty((self.width, self.n), dtype=torch.float64, device="cuda")
+        self.diag = torch.empty(self.n, dtype=torch.float64, device="cuda")
+        tick = time.time()
+        torch.cuda.synchronize()
+        _lib.check(lib.asp_sector_rows(device_operator._handle, self.n, _ptr(representatives), _ptr(norms),
+                                       self.width, _ptr(self.idx), _ptr(self.val), _ptr(self.diag)))
+        if log:
+            log("sector matrix: %d rows x %d slots = %.2f GB in HBM, built in %.2f s" % (
+                self.n, self.width, self.n * (12.0 * self.width + 8.0) / 1e9, time.time() - tick))
+
+    def matvec(self, x, out=None):
+        torch = _torch()
+        if out is None:
+            out = torch.empty_like(x)
+        if x.dtype != torch.float64 or not x.is_contiguous() or x.shape[0] != self.n:
+            raise ValueError("x must be a contiguous f64 vector of the sector's dimension")
+        torch.cuda.synchronize()  # the library runs on a stream of its own
+        _lib.check(_lib.load().asp_sector_matvec(self.n, self.width, _ptr(self.idx), _ptr(self.val),
+                                                 _ptr(self.diag), _ptr(x), _ptr(out)))
+        return out
+
+
+def lanczos_ground_state(matrix: SectorMatrix, tol: float = 1e-9, max_iterations: int = 400,
+                         seed: int = 0, log=None):
+    """Lowest eigenpair by Lanczos with full reorthogonalisation.  ``(energy, vector (device),
+    info)``; stops when the Ritz residual ``|beta_m s_m|`` falls below ``tol * max(1, |E|)``.
+    The Krylov vectors stay on the device (n * 8 bytes each)."""
+    torch = _torch()
+    import scipy.linalg
+
+    n = matrix.n
+    free, _ = torch.cuda.mem_get_info()
+    room = int((free - (2 << 30)) // (8 * n)) - 3
+    if room < 8:
+        raise RuntimeError("not enough device memory for a Krylov basis of %d-vectors" % n)
+    steps = min(max_iterations, room, n)
+    basis = torch.empty((steps, n), dtype=torch.float64, device="cuda")
+    start = np.random.default_rng(seed).standard_normal(n)
+    v = torch.from_numpy(start).cuda()
+    v /= torch.linalg.vector_norm(v)
+    w = torch.empty_like(v)
+    alphas, betas = [], []
+    energy, ritz, residual = None, None, None
+    tick = time.time()
+    used = 0
+    for j in range(steps):
+        basis[j].copy_(v)
+        matrix.matvec(v, out=w)
+        alphas.append(float(torch.dot(v, w)))
+        # full reorthogonalisation against everything so far (covers alpha and beta terms), twice
+        for _ in range(2):
+            w -= torch.mv(basis[: j + 1].t(), torch.mv(basis[: j + 1], w))
+        beta = float(torch.linalg.vector_norm(w))
+        used = j + 1
+        done = beta < 1e-13 or used == steps
+        if used % 5 == 0 or done:
+            theta, s = scipy.linalg.eigh_tridiagonal(np.asarray(alphas), np.asarray(betas), select="i",
+                                                     select_range=(0, 0))
+            energy, ritz = float(theta[0]), s[:, 0]
+            residual = abs(beta * ritz[-1])
+            if log and (used % 25 == 0 or done or residual < tol * max(1.0, abs(energy))):
+                log("  Lanczos step %d: E = %.12f, residual %.2e  [%.1f s]" % (
+                    used, energy, residual, time.time() - tick))
+            if residual < tol * max(1.0, abs(energy)) or done:
+                break
+        betas.append(beta)
+        v, w = w, v
+        v /= beta
+    vector = torch.mv(basis[:used].t(), torch.from_numpy(np.ascontiguousarray(ritz)).cuda())
+    del basis
+    vector /= torch.linalg.vector_norm(vector)
+    # the residual proper, with the matrix
+    hv = matrix.matvec(vector)
+    energy = float(torch.dot(vector, hv))
+    true_residual = float(torch.linalg.vector_norm(hv - energy * vector))
+    # sign convention of Operator.ground_state: the largest amplitude is positive
+    top = int(torch.argmax(torch.abs(vector)))
+    if float(vector[top]) < 0:
+        vector = -vector
+    info = {"iterations": used, "ritz_residual": float(residual), "residual": true_residual,
+            "seconds": time.time() - tick}
+    if log:
+        log("ground state: E = %.12f, |H psi - E psi| = %.2e, %d steps, %.1f s" % (
+            energy, true_residual, used, info["seconds"]))
+    return energy, vector, info
+
+
+def ground_state(operator, tol: float = 1e-9, max_iterations: int = 400, seed: int = 0, log=None):
+    """``(energy, psi f64[K], representatives u64[K], info)`` on the host for the basis of
+    ``operator`` — enumeration, matrix, Lanczos, all on the device."""
+    torch = _torch()
+    reps, norms = enumerate_sector(operator, log=log)
+    matrix = SectorMatrix(operator, reps, norms, log=log)
+    energy, vector, info = lanczos_ground_state(matrix, tol=tol, max_iterations=max_iterations,
+                                                seed=seed, log=log)
+    info["dimension"] = matrix.n
+    del matrix
+    psi = vector.cpu().numpy()
+    representatives = reps.cpu().numpy().view(np.uint64)
+    torch.cuda.empty_cache()
+    return energy, psi, representatives, info
+
+
+def write_spined_hdf5(filename: str, energy: float, psi: np.ndarray, representatives: np.ndarray) -> None:
+    """The three datasets the reference's loaders read (common.py:772-780,
+    experiments/full_hilbert_space.py:24-29): ``/basis/representatives`` u64[K],
+    ``/hamiltonian/eigenvalues`` f64[1], ``/hamiltonian/eigenvectors`` f64[1, K]
+    (:func:`.common.load_ground_state` reads it back)."""
+    from . import common
+
+    common.save_ground_state(filename, psi, energy, representatives)
+
+
+def main(argv=None):
+    import argparse
+
+    from . import common, operators, synthetic
+
+    parser = argparse.ArgumentParser(description="Ground state of a model's symmetry sector on the GPU "
+                                                 "-> SpinED-layout HDF5")
+    parser.add_argument("--model", help="a bundled model (models.json)")
+    parser.add_argument("--yaml", help="a physical_systems/*.yaml file of the reference")
+    parser.add_argument("--output", required=True, help="HDF5 file to write")
+    parser.add_argument("--tol", type=float, default=1e-9)
+    parser.add_argument("--max-iterations", type=int, default=400)
+    parser.add_argument("--seed", type=int, default=0)
+    args = parser.parse_args(argv)
+    if (args.model is None) == (args.yaml is None):
+        raise SystemExit("give exactly one of --model and --yaml")
+    if args.yaml:
+        operator = common.load_hamiltonian(args.yaml)
+    else:
+        operator = operators.Operator.from_config(synthetic.load_models()[args.model])
+    energy, psi, representatives, info = ground_state(operator, args.tol, args.max_iterations, args.seed,
+                                                      log=lambda s: print(s, flush=True))
+    write_spined_hdf5(args.output, energy, psi, representatives)
+    print("wrote %s: K = %d, E0 = %.12f (%.10f per spin)" % (
+        args.output, info["dimension"], energy, energy / operator.basis.number_spins), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -180,6 +180,34 @@ int asp_operator_set_symmetry(asp_operator *op, uint32_t num_permutations, uint8
 int asp_operator_state_info(asp_operator const *op, uint64_t n, uint64_t const *keys,
                             uint64_t *representatives, double *characters, double *norms);
 
+/* A whole symmetry sector on the device (csrc/sector_basis.hip) — what the reference reads from
+ * SpinED's output (common.py:783-803: /basis/representatives, /hamiltonian/eigenvectors) and
+ * what those absent files would hold for heisenberg_kagome_36.yaml: 31.5 million representatives.
+ * Every *_dev pointer is DEVICE memory of the bound device; the calls run on a stream of their
+ * own and return when the work is done (the caller synchronises ITS streams before calling).
+ *
+ * asp_sector_enumerate: all states of `number_spins` spins with `hamming_weight` bits set (all
+ * states when negative) that are the smallest member of their orbit and lie in the sector
+ * (norm > 0), ascending, with their norms (norms_dev may be NULL).  *count receives the number
+ * found; nothing is written when it exceeds `capacity` (capacity 0: sizing call), which then
+ * fails with ASP_ERR_TOO_LARGE.  Up to 48 spins; works without symmetries too (every state its
+ * own representative, norm 1). */
+int asp_sector_enumerate(asp_operator const *op, int32_t hamming_weight, uint64_t capacity,
+                         uint64_t *reps_dev, double *norms_dev, uint64_t *count);
+/* Entries per row of the sector's matrix (off-diagonal transitions a state can take). */
+uint32_t asp_sector_width(asp_operator const *op);
+/* The operator in the basis `reps_dev` (sorted representatives, their norms) as an ELL matrix:
+ * slot k of row i at [k * n + i]; idx = row index of the target's representative, val =
+ * c * chi * norm(target) / norm(source) (the coefficient asp_operator_apply returns); unused
+ * slots hold (i, 0.0); diag = the diagonal, summed bond by bond.  Targets outside `reps_dev`
+ * (another magnetisation, norm 0) are dropped.  width >= asp_sector_width(op). */
+int asp_sector_rows(asp_operator const *op, uint64_t n, uint64_t const *reps_dev,
+                    double const *norms_dev, uint32_t width, uint32_t *idx_dev, double *val_dev,
+                    double *diag_dev);
+/* y = H x over those arrays: y[i] = diag[i] x[i] + sum_k val[k n + i] x[idx[k n + i]], k ascending. */
+int asp_sector_matvec(uint64_t n, uint32_t width, uint32_t const *idx_dev, double const *val_dev,
+                      double const *diag_dev, double const *x_dev, double *y_dev);
+
 /* 1 when every row's targets are pairwise distinct for every input state (distinct flip
  * masks), which asp_operator_ising requires; 0 otherwise. */
 int asp_operator_unique_targets(asp_operator const *op);
