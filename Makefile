@@ -1,8 +1,8 @@
 # Thin wrappers around the Python entry points, with the parameters of the reference's targets
 # (reference Makefile:17-35 `small`, :101-141 `kagome_36` / `pyrochlore_32` / `sk_32_1`).  The
 # 16- and 18-site models of annealing_sign_problem_amd/models.json are diagonalised on the spot;
-# the large ones need the HDF5 ground states the reference's Makefile downloads (:143-153), given
-# as DATA=<directory holding heisenberg_kagome_36.h5 ...>.
+# the ground states of the large ones (the HDF5 files the reference's Makefile downloads, :143-153)
+# are taken from DATA=<directory> or, for kagome_36 and pyrochlore_32, computed on the GPU.
 PYTHON ?= python3
 SEED ?= 435834
 NOISE ?= 0
@@ -54,9 +54,20 @@ kagome_36: LARGE = heisenberg_kagome_36
 pyrochlore_32: LARGE = heisenberg_pyrochlore_2x2x2
 sk_32_1: LARGE = sk_32_1
 kagome_36 pyrochlore_32 sk_32_1:
-	@test -f $(DATA)/$(LARGE).h5 || { echo "$(DATA)/$(LARGE).h5 not found: the ground states of the large models are downloaded inputs (reference Makefile:143-153); set DATA=<dir>"; exit 1; }
-	@mkdir -p $(OUT)/$(LARGE)/noise_$(NOISE)/cutoff_$(CUTOFF)
+	@mkdir -p $(DATA) $(OUT)/$(LARGE)/noise_$(NOISE)/cutoff_$(CUTOFF)
+	@test -f $(DATA)/$(LARGE).h5 || $(MAKE) $(DATA)/$(LARGE).h5
 	$(PYTHON) -m annealing_sign_problem_amd.sampled_components --model $(LARGE) --hdf5 $(DATA)/$(LARGE).h5 \
 		--seed $(SEED) --output $(OUT)/$(LARGE)/noise_$(NOISE)/cutoff_$(CUTOFF)/$(LARGE).csv$(JOBID) \
 		--order $(ORDER) --noise $(NOISE) --no-annealing --global-cutoff $(CUTOFF) \
 		--number-samples $(NUMBER_SAMPLES) --jobs $(JOBS)
+
+# The ground states the reference downloads (Makefile:143-153, SpinED output) are regenerated on
+# the GPU when absent: representatives, resident Hamiltonian and Lanczos of the whole symmetry
+# sector (annealing_sign_problem_amd/sector_ed.py; heisenberg_kagome_36: 31.5 M representatives,
+# about 10 s).  sk_32_1 (3e8 states x 496 bonds) does not fit this route: its file must be given.
+$(DATA)/heisenberg_kagome_36.h5 $(DATA)/heisenberg_pyrochlore_2x2x2.h5:
+	@mkdir -p $(DATA)
+	$(PYTHON) -m annealing_sign_problem_amd.sector_ed --model $(basename $(notdir $@)) --output $@
+
+$(DATA)/sk_32_1.h5:
+	@echo "$@ not found: this ground state is a downloaded input (reference Makefile:143-153); set DATA=<dir>"; exit 1

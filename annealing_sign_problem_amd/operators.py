@@ -36,6 +36,9 @@ class SpinBasis:
     :class:`~.symmetry.SymmetryGroup` the basis states are the orbit REPRESENTATIVES of
     non-zero norm (the smallest state of each orbit)."""
 
+    #: candidate states up to which :meth:`build` enumerates on the host
+    HOST_LIMIT = 5_000_000
+
     def __init__(self, number_spins: int, hamming_weight: Optional[int] = None, group=None):
         if not 0 < number_spins <= 64:
             raise ValueError("number_spins must be in 1..64")
@@ -49,17 +52,25 @@ class SpinBasis:
             self._states = np.sort(np.asarray(representatives, dtype=np.uint64))
             return
         n, w = self.number_spins, self.hamming_weight
+        count = 1 << n
+        if w is not None:
+            count = 1
+            for k in range(w):
+                count = count * (n - k) // (k + 1)
+        if count > self.HOST_LIMIT:
+            # beyond numpy: the representatives are listed on the GPU (csrc/sector_basis.hip;
+            # no CPU fallback — 9e9 states of the 36-site kagome model take half a second there)
+            from . import sector_ed
+
+            lattice_only = Operator(self, [])
+            reps, _ = sector_ed.enumerate_sector(lattice_only)
+            self._states = reps.cpu().numpy().view(np.uint64)
+            lattice_only.release_device()
+            return
         if w is None:
-            if n > 26:
-                raise ValueError("refusing to enumerate 2^{} states".format(n))
             states = np.arange(1 << n, dtype=np.uint64)
             self._states = states if self.group is None else self.group.representatives(states)
             return
-        count = 1
-        for k in range(w):
-            count = count * (n - k) // (k + 1)
-        if count > 50_000_000:
-            raise ValueError("refusing to enumerate {} states".format(count))
         states = np.fromiter(
             (sum(1 << b for b in bits) for bits in combinations(range(n), w)),
             dtype=np.uint64, count=count)
@@ -100,6 +111,9 @@ class Term:
 
 class Operator:
     """Sum of two-site terms on a :class:`SpinBasis`."""
+
+    #: basis size up to which :meth:`ground_state` diagonalises on the host (scipy)
+    HOST_ED_LIMIT = 200_000
 
     def __init__(self, basis: SpinBasis, terms: Sequence[Term]):
         self.basis = basis
@@ -144,6 +158,11 @@ class Operator:
             self._device = DeviceOperator(self.basis.number_spins, *self.bond_table(),
                                           group=self.basis.group)
         return self._device
+
+    def release_device(self) -> None:
+        device, self._device = getattr(self, "_device", None), None
+        if device is not None:
+            device.release()
 
     # -- action on basis states ------------------------------------------------
     def batched_apply(self, spins):
@@ -231,6 +250,15 @@ class Operator:
         largest-magnitude amplitude is positive."""
         import scipy.sparse.linalg
 
+        if self.basis._states is None:
+            self.basis.build()
+        if self.basis.number_states > self.HOST_ED_LIMIT:
+            # whole sectors of the 32- and 36-site models: enumeration, matrix and Lanczos on the
+            # GPU (sector_ed.py; no CPU fallback)
+            from . import sector_ed
+
+            energy, psi, _, _ = sector_ed.ground_state(self, seed=seed, representatives=self.basis.states)
+            return energy, psi
         h = self.to_sparse()
         if abs(h.imag).max() > 1e-12:
             raise ValueError("ground_state expects a real operator")

@@ -180,11 +180,27 @@ def lanczos_ground_state(matrix: SectorMatrix, tol: float = 1e-9, max_iterations
     return energy, vector, info
 
 
-def ground_state(operator, tol: float = 1e-9, max_iterations: int = 400, seed: int = 0, log=None):
-    """``(energy, psi f64[K], representatives u64[K], info)`` on the host for the basis of
-    ``operator`` — enumeration, matrix, Lanczos, all on the device."""
+def sector_norms(operator, representatives) -> "torch.Tensor":
+    """Norms of given representatives (device f64[K]) — ``asp_operator_state_info``."""
     torch = _torch()
-    reps, norms = enumerate_sector(operator, log=log)
+    if operator.basis.group is None:
+        return torch.ones(len(representatives), dtype=torch.float64, device="cuda")
+    _, _, norms = operator.device().state_info(np.ascontiguousarray(representatives, dtype=np.uint64))
+    return torch.from_numpy(norms).cuda()
+
+
+def ground_state(operator, tol: float = 1e-9, max_iterations: int = 400, seed: int = 0, log=None,
+                 representatives: Optional[np.ndarray] = None):
+    """``(energy, psi f64[K], representatives u64[K], info)`` on the host for the basis of
+    ``operator`` — enumeration (unless the sorted ``representatives`` are given), matrix,
+    Lanczos, all on the device."""
+    torch = _torch()
+    if representatives is None:
+        reps, norms = enumerate_sector(operator, log=log)
+    else:
+        host = np.ascontiguousarray(representatives, dtype=np.uint64)
+        reps = torch.from_numpy(host.view(np.int64)).cuda()
+        norms = sector_norms(operator, host)
     matrix = SectorMatrix(operator, reps, norms, log=log)
     energy, vector, info = lanczos_ground_state(matrix, tol=tol, max_iterations=max_iterations,
                                                 seed=seed, log=log)

@@ -94,3 +94,19 @@ def test_ground_state_of_the_pyrochlore_sector_and_the_reference_file_layout(mod
     back, e_back, reps_back = common.load_ground_state(filename)
     assert e_back == energy and np.array_equal(reps_back, representatives)
     assert back.tobytes() == psi.tobytes()
+
+
+def test_kagome_36_sector_dimension_and_ground_state_energy_match_the_literature(models):
+    """The one EXTERNAL pin of the symmetry-adapted construction (representatives, characters,
+    norms, matrix elements; lattice_symmetries itself is absent): the fully symmetric, inversion-
+    even Sz = 0 sector of the 36-site kagome cluster of heisenberg_kagome_36.yaml:7-29 has
+    31 527 894 states and the ground-state energy per site is -0.43837653 J (Waldtmann et al.,
+    Eur. Phys. J. B 2, 501 (1998); Laeuchli, Sudan, Moessner, Phys. Rev. B 100, 155142 (2019),
+    table of the N = 36 cluster) — in the YAML's units, sum of sigma.sigma = 4 S.S over 72 bonds."""
+    from annealing_sign_problem_amd import operators, sector_ed
+
+    op = operators.Operator.from_config(models["heisenberg_kagome_36"])
+    energy, psi, representatives, info = sector_ed.ground_state(op, tol=1e-9)
+    assert representatives.shape[0] == 31527894
+    assert abs(energy / 36.0 / 4.0 - (-0.43837653)) < 1e-8
+    assert info["residual"] < 1e-6 and abs(np.linalg.norm(psi) - 1.0) < 1e-12
