@@ -1,9 +1,14 @@
-"""GPU parity at BASELINE.json's configurations 1 and 2 — the full 16-site Hilbert spaces
-(K = C(16,8) = 12 870) the reference's `make small` anneals (Makefile:27-35):
+"""GPU parity at BASELINE.json's configurations — the full 16-site Hilbert spaces
+(K = C(16,8) = 12 870) the reference's `make small` anneals (Makefile:27-35) and sampled clusters
+of the REAL 36- and 32-site models, whose ground states are computed on the GPU in the test
+(sector_ed.py; the reference downloads them, Makefile:143-153):
 
   config 1  j1j2_square_4x4 (physical_systems/j1j2_square_4x4.yaml:18-41, incl. the (3,3) = 1
             entry of the J2 matrix): coupling build, energy identity, 1 and few replicas
   config 2  heisenberg_kagome_16: 256 replicas, fixed seed, chains vs the oracle
+  config 3  heisenberg_kagome_36: a sampled cluster extended twice (K ~ 1e4), 1024 replicas
+  config 4  heisenberg_pyrochlore_2x2x2: cluster extension with CUTOFF = 2e-6, replicas in two
+            shards (global replica ids) equal to one call
 
 Each test goes model YAML -> exact ground state -> make_ising_model (GPU) -> sa.anneal (GPU)
 through the package's reference-named entry points and compares with the CPU oracle bit for
@@ -112,3 +117,64 @@ def test_config2_kagome16_full_space_256_replicas(models):
     acc, overlap = common.compute_accuracy_and_overlap(xs[int(np.argmin(es))], model.initial_signs,
                                                        weights)
     assert 0.5 <= acc <= 1.0 and 0.0 <= overlap <= 1.0 + 1e-12
+
+
+def _sampled_model(models, name, samples, order, cutoff, seed=435834):
+    """Ground state of the model's whole sector (GPU), `samples` clusters grown as the driver
+    grows them, each extended `order` times with the global cutoff; returns the models."""
+    from annealing_sign_problem_amd import common, operators, sampled_components
+
+    if name not in _cache:
+        op = operators.Operator.from_config(models[name])
+        op.basis.build()
+        energy, psi = op.ground_state()
+        _cache[name] = (op, energy, psi)
+    op, energy, psi = _cache[name]
+    state = np.random.get_state()
+    np.random.seed(seed)
+    try:
+        clusters = sampled_components.generate_clusters(op, psi, samples, 0.1, 50, 1000, 0.5)
+    finally:
+        np.random.set_state(state)
+    fn = common.ground_state_to_log_coeff_fn(psi, op.basis)
+    out = []
+    for cluster in clusters:
+        h = common.make_ising_model(cluster, op, log_psi_fn=fn)
+        for _ in range(order):
+            h = common.make_hamiltonian_extension(h, fn)
+            h = common.sparsify_using_global_cutoff(h, cutoff, cluster)
+        out.append((cluster, h))
+    return op, energy, psi, out
+
+
+def test_config3_kagome36_real_cluster_1024_replicas(models):
+    """BASELINE config 3 on the real model: a sampled cluster of heisenberg_kagome_36 extended
+    twice (`make kagome_36`'s order 2, cutoff 1e-6), 1024 replicas, every chain equal to the
+    oracle's; the cluster model carries the energy identity of the construction."""
+    op, energy, psi, built = _sampled_model(models, "heisenberg_kagome_36", 6, 2, 1e-6)
+    assert op.basis.number_states == 31527894 and abs(energy / 144.0 + 0.43837653) < 1e-8
+    cluster, model = min(built, key=lambda item: item[1].size)
+    assert 2000 < model.size < 60000
+    h = model.ising_hamiltonian
+    j = h.exchange
+    assert abs(j - j.T).max() == 0.0
+    _chains_vs_oracle(h, 435834, 12, 1024, 16)
+
+
+def test_config4_pyrochlore_real_cluster_cutoff_and_replica_shards(models):
+    """BASELINE config 4 on the real model: heisenberg_pyrochlore_2x2x2, extension with
+    CUTOFF = 2e-6; the chains of two shards (global replica ids 0..255 and 256..511, what two
+    ranks run) are those of one 512-replica call and of the oracle."""
+    from annealing_sign_problem_amd import annealer as sa
+
+    op, energy, psi, built = _sampled_model(models, "heisenberg_pyrochlore_2x2x2", 4, 1, 2e-6)
+    assert op.basis.number_states == 789438
+    cluster, model = min(built, key=lambda item: item[1].size)
+    h = model.ising_hamiltonian
+    xs, es = _chains_vs_oracle(h, 435834, 20, 512, 16)
+    info = h.info()
+    betas = sa.make_schedule(info.beta0_auto, info.beta1_auto, 20)
+    lo = sa.anneal_raw(h, 435834, betas, 256, 0)
+    hi = sa.anneal_raw(h, 435834, betas, 256, 256)
+    assert np.array_equal(np.concatenate([lo[0], hi[0]]), xs)
+    assert np.concatenate([lo[1], hi[1]]).tobytes() == es.tobytes()
