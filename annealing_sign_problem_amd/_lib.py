@@ -92,6 +92,9 @@ SIGNATURES = {
     "asp_operator_destroy": (None, [c_void_p]),
     "asp_operator_set_symmetry": (c_int, [c_void_p, c_u32, c_void_p, c_i32]),
     "asp_operator_state_info": (c_int, [c_void_p, c_u64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "asp_table_create": (c_int, [c_u64, c_void_p, ctypes.POINTER(c_void_p)]),
+    "asp_table_destroy": (None, [c_void_p]),
+    "asp_table_index": (c_int, [c_void_p, c_u64, c_void_p, c_void_p]),
     "asp_sector_enumerate": (c_int, [c_void_p, c_i32, c_u64, c_void_p, c_void_p, ctypes.POINTER(c_u64)]),
     "asp_sector_width": (ctypes.c_uint32, [c_void_p]),
     "asp_sector_rows": (c_int, [c_void_p, c_u64, c_void_p, c_void_p, c_u32, c_void_p, c_void_p, c_void_p]),
@@ -180,11 +183,38 @@ def library_path() -> str:
     return _build.LIB_PATH
 
 
+def _preload_torch_hip() -> None:
+    """One HIP runtime per process.  PyTorch ships its own ``libamdhip64.so``; libasp_hip.so is
+    linked against the system one (same SONAME).  Whichever is loaded first serves both — and
+    torch cannot initialise its device on the system runtime (``torch.cuda.is_available()`` turns
+    False) when this library came first.  So torch's copy is mapped before libasp_hip.so whenever
+    torch is installed, without importing torch: the order of imports then does not matter, and
+    device pointers of torch tensors (sector_ed.py, distributed.py) belong to the runtime this
+    library runs on."""
+    import importlib.util
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load() -> ctypes.CDLL:
     """Load (building first if the sources changed and hipcc is present)."""
     global _lib
     if _lib is not None:
         return _lib
+    _preload_torch_hip()
     path = _build.LIB_PATH
     try:
         path = _build.build()

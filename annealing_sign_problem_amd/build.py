@@ -30,6 +30,7 @@ SOURCES = [
     "ising_elements.hip",
     "operator_apply.hip",
     "sector_basis.hip",
+    "key_table.hip",
     "sparsify.hip",
     "sa_plan.cpp",
     "greedy.cpp",

@@ -38,6 +38,8 @@ class SpinBasis:
 
     #: candidate states up to which :meth:`build` enumerates on the host
     HOST_LIMIT = 5_000_000
+    #: basis size from which :meth:`batched_index` bisects on the GPU
+    DEVICE_INDEX_LIMIT = 2_000_000
 
     def __init__(self, number_spins: int, hamming_weight: Optional[int] = None, group=None):
         if not 0 < number_spins <= 64:
@@ -93,11 +95,52 @@ class SpinBasis:
         spins = np.asarray(spins, dtype=np.uint64)
         if spins.ndim > 1:
             spins = spins[:, 0]
+        if self.number_states > self.DEVICE_INDEX_LIMIT:
+            return self._device_index(np.ascontiguousarray(spins))
         idx = np.searchsorted(self.states, spins)
         clipped = np.minimum(idx, self.number_states - 1)
         if not np.array_equal(self.states[clipped], spins):
             raise ValueError("state does not belong to the basis")
         return idx.astype(np.uint64)
+
+    def _device_index(self, spins: np.ndarray) -> np.ndarray:
+        """The same through the list kept in HBM (csrc/key_table.hip): numpy's searchsorted over
+        tens of millions of representatives is all cache misses."""
+        import ctypes
+
+        from . import _lib
+
+        lib = _lib.load()
+        table = getattr(self, "_table", None)
+        if table is None or self._table_of is not self._states:
+            _lib.require_gpu()
+            self.release_table()
+            table = ctypes.c_void_p()
+            _lib.check(lib.asp_table_create(self.number_states, _lib.ptr(self._states), ctypes.byref(table)))
+            self._table, self._table_of, self._lib_module = table, self._states, _lib
+            _lib.track(self)
+        idx = np.empty(max(spins.shape[0], 1), dtype=np.int64)
+        _lib.check(lib.asp_table_index(table, spins.shape[0], _lib.ptr(spins), _lib.ptr(idx)))
+        idx = idx[: spins.shape[0]]
+        if np.any(idx < 0):
+            raise ValueError("state does not belong to the basis")
+        return idx.astype(np.uint64)
+
+    def release_table(self) -> None:
+        table, self._table = getattr(self, "_table", None), None
+        if table:
+            self._lib_module.load().asp_table_destroy(table)
+
+    release = release_table  # (the library's shutdown hook calls `release` on tracked objects)
+
+    def __del__(self):
+        # (no imports here: at interpreter teardown the import machinery is already gone)
+        module = getattr(self, "_lib_module", None)
+        if module is not None and getattr(self, "_table", None) and not module.closed():
+            try:
+                self.release_table()
+            except Exception:
+                pass
 
     def index(self, spin) -> int:
         return int(self.batched_index(np.array([spin], dtype=np.uint64))[0])

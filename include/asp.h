@@ -180,6 +180,14 @@ int asp_operator_set_symmetry(asp_operator *op, uint32_t num_permutations, uint8
 int asp_operator_state_info(asp_operator const *op, uint64_t n, uint64_t const *keys,
                             uint64_t *representatives, double *characters, double *norms);
 
+/* Positions of states in a long ascending list kept on the device (csrc/key_table.hip): what
+ * `basis.batched_index(spins)` (common.py:813-818) is for a basis of tens of millions of
+ * representatives.  index[q] = position of queries[q], or -1.  Host pointers; thread-safe. */
+typedef struct asp_table asp_table;
+int asp_table_create(uint64_t n, uint64_t const *sorted_keys, asp_table **out);
+void asp_table_destroy(asp_table *t);
+int asp_table_index(asp_table const *t, uint64_t m, uint64_t const *queries, int64_t *index);
+
 /* A whole symmetry sector on the device (csrc/sector_basis.hip) — what the reference reads from
  * SpinED's output (common.py:783-803: /basis/representatives, /hamiltonian/eigenvectors) and
  * what those absent files would hold for heisenberg_kagome_36.yaml: 31.5 million representatives.

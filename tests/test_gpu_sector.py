@@ -110,3 +110,33 @@ def test_kagome_36_sector_dimension_and_ground_state_energy_match_the_literature
     assert representatives.shape[0] == 31527894
     assert abs(energy / 36.0 / 4.0 - (-0.43837653)) < 1e-8
     assert info["residual"] < 1e-6 and abs(np.linalg.norm(psi) - 1.0) < 1e-12
+
+
+def test_device_index_of_a_large_basis_equals_searchsorted():
+    """csrc/key_table.hip behind SpinBasis.batched_index (common.py:813-818's index lookup)."""
+    import ctypes
+
+    from annealing_sign_problem_amd import _lib, operators
+
+    rng = np.random.default_rng(5)
+    keys = np.unique(rng.integers(0, 1 << 40, size=300_000, dtype=np.uint64))
+    basis = operators.SpinBasis(40)
+    basis.build(keys)
+    basis.DEVICE_INDEX_LIMIT = 1000            # (instance attribute: this basis only)
+    queries = keys[rng.integers(0, keys.shape[0], size=50_000)]
+    assert np.array_equal(basis.batched_index(queries), np.searchsorted(keys, queries).astype(np.uint64))
+    assert basis.index(int(keys[-1])) == keys.shape[0] - 1 and basis.index(int(keys[0])) == 0
+    assert basis.batched_index(np.zeros(0, np.uint64)).shape == (0,)
+    absent = np.setdiff1d(rng.integers(0, 1 << 40, size=100, dtype=np.uint64), keys)
+    with pytest.raises(ValueError):
+        basis.batched_index(np.concatenate([queries[:10], absent[:1]]))
+    # the C entry point itself: -1 for absent keys, ascending keys required
+    lib = _lib.load()
+    out = np.zeros(3, np.int64)
+    probe = np.array([keys[7], absent[0], keys[123]], dtype=np.uint64)
+    _lib.check(lib.asp_table_index(basis._table, 3, _lib.ptr(probe), _lib.ptr(out)))
+    assert out.tolist() == [7, -1, 123]
+    handle = ctypes.c_void_p()
+    unsorted = np.array([3, 2, 5], dtype=np.uint64)
+    assert lib.asp_table_create(3, _lib.ptr(unsorted), ctypes.byref(handle)) != 0
+    basis.release_table()
