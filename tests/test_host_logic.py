@@ -44,6 +44,30 @@ def test_fails_loudly_without_gpu():
         _build_matrix.extract_signs(np.ones(5))
 
 
+def test_large_bases_need_the_device_and_say_so(models):
+    """Beyond the host limits the representatives, the index lookup and the ground state come from
+    the GPU (sector_ed.py, csrc/sector_basis.hip, csrc/key_table.hip): no silent host fallback."""
+    from annealing_sign_problem_amd import _lib, operators, sector_ed
+
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    op = operators.Operator.from_config(models["heisenberg_kagome_36"])
+    with pytest.raises(RuntimeError, match="needs a GPU"):
+        op.basis.build()
+    with pytest.raises(RuntimeError, match="needs a GPU"):
+        sector_ed.ground_state(op)
+    big = operators.SpinBasis(40)
+    big.build(np.arange(10, dtype=np.uint64))
+    big.DEVICE_INDEX_LIMIT = 5
+    with pytest.raises(_lib.AspError):
+        big.batched_index(np.array([3], dtype=np.uint64))
+    # the small models keep the host route
+    small = operators.Operator.from_config(models["heisenberg_kagome_16"])
+    small.basis.build()
+    assert small.basis.number_states == 12870 and small.basis.index(int(small.basis.states[5])) == 5
+    assert sector_ed.binomial(36, 18) == 9075135300
+
+
 def test_bit_packing_conventions():
     from annealing_sign_problem_amd import annealer as sa
 
