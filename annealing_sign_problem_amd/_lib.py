@@ -92,6 +92,11 @@ SIGNATURES = {
     "asp_operator_destroy": (None, [c_void_p]),
     "asp_operator_set_symmetry": (c_int, [c_void_p, c_u32, c_void_p, c_i32]),
     "asp_operator_state_info": (c_int, [c_void_p, c_u64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "asp_plain_basis_create": (c_int, [c_void_p, c_i32, ctypes.POINTER(c_void_p)]),
+    "asp_plain_basis_destroy": (None, [c_void_p]),
+    "asp_plain_basis_dimension": (c_u64, [c_void_p]),
+    "asp_plain_basis_states": (c_int, [c_void_p, c_void_p]),
+    "asp_plain_matvec": (c_int, [c_void_p, c_void_p, c_void_p]),
     "asp_table_create": (c_int, [c_u64, c_void_p, ctypes.POINTER(c_void_p)]),
     "asp_table_destroy": (None, [c_void_p]),
     "asp_table_index": (c_int, [c_void_p, c_u64, c_void_p, c_void_p]),

@@ -31,6 +31,7 @@ SOURCES = [
     "operator_apply.hip",
     "sector_basis.hip",
     "key_table.hip",
+    "plain_basis.hip",
     "sparsify.hip",
     "sa_plan.cpp",
     "greedy.cpp",

@@ -51,7 +51,9 @@ class SpinBasis:
 
     def build(self, representatives: Optional[np.ndarray] = None) -> None:
         if representatives is not None:
-            self._states = np.sort(np.asarray(representatives, dtype=np.uint64))
+            states = np.asarray(representatives, dtype=np.uint64)
+            ascending = states.shape[0] < 2 or bool(np.all(states[1:] > states[:-1]))
+            self._states = states if ascending else np.sort(states)
             return
         n, w = self.number_spins, self.hamming_weight
         count = 1 << n

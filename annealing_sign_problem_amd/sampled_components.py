@@ -14,7 +14,7 @@ Same call sequence and CSV schema as the reference driver:
 Inputs: ``--yaml`` + ``--hdf5`` as in the reference (the operator of a physical_systems/*.yaml
 file, the ground state and basis representatives of the SpinED output its Makefile downloads),
 or ``--model``: a model bundled in ``models.json`` whose ground state is computed on the spot
-(16- and 18-site systems).  The operator is :mod:`.operators` instead of ``lattice_symmetries``.  Like the reference, all host-side randomness is numpy's global legacy
+(16- and 18-site systems on the host, the 32- and 36-site ones on the GPU: :mod:`.sector_ed`).  The operator is :mod:`.operators` instead of ``lattice_symmetries``.  Like the reference, all host-side randomness is numpy's global legacy
 stream seeded once with ``--seed`` (driver :776).
 """
 from __future__ import annotations
@@ -266,6 +266,10 @@ def load_input(args):
         hamiltonian = common.load_hamiltonian(args.yaml)
     hdf5 = args.hdf5 if args.hdf5 is not None else args.yaml.replace(".yaml", ".h5")
     ground_state, _, representatives = common.load_ground_state(hdf5)
+    if representatives.shape[0] < 2 or np.all(representatives[1:] > representatives[:-1]):
+        # already ascending (SpinED and sector_ed write them so): no 6e8-element argsort for sk_32_1
+        hamiltonian.basis.build(representatives)
+        return hamiltonian, np.ascontiguousarray(ground_state)
     order = np.argsort(representatives, kind="stable")  # the basis keeps its states sorted
     hamiltonian.basis.build(representatives[order])
     return hamiltonian, np.ascontiguousarray(ground_state[order])

@@ -14,6 +14,11 @@ one MI355X:
   3. Lanczos with full reorthogonalisation: one ``asp_sector_matvec`` per step, the Krylov basis
      kept on the device too (250 MB per vector); BLAS-1/2 glue through torch.
 
+``sk_32_1.yaml`` — 6.0e8 states without lattice symmetries, 496 bonds — takes another route: its
+matrix does not fit, but its basis has a closed-form index, so ``asp_plain_matvec``
+(csrc/plain_basis.hip) regenerates the product on the fly and :func:`lanczos_two_pass` keeps
+three vectors of 4.8 GB (about four minutes in all).
+
 Output in the layout the reference's loaders expect (:func:`write_spined_hdf5`), so that the
 reference's own command lines (``--yaml ... --hdf5 ...``) run on it.
 
@@ -180,6 +185,128 @@ def lanczos_ground_state(matrix: SectorMatrix, tol: float = 1e-9, max_iterations
     return energy, vector, info
 
 
+class PlainBasisMatrix:
+    """Matrix-free ``y = Hx`` in a fixed-magnetisation basis without lattice symmetries
+    (csrc/plain_basis.hip): sk_32_1.yaml's 6.0e8 states x 496 bonds."""
+
+    def __init__(self, operator, log=None):
+        _torch()
+        basis = operator.basis
+        if basis.group is not None or basis.hamming_weight is None:
+            raise ValueError("the matrix-free product needs a magnetisation sector without symmetries")
+        lib = _lib.load()
+        self._lib_module = _lib
+        handle = ctypes.c_void_p()
+        _lib.check(lib.asp_plain_basis_create(operator.device()._handle, int(basis.hamming_weight),
+                                              ctypes.byref(handle)))
+        self._handle = handle
+        self.n = int(lib.asp_plain_basis_dimension(handle))
+        _lib.track(self)
+        if log:
+            log("plain basis of %d spins at hamming weight %d: %d states, matrix-free" % (
+                basis.number_spins, basis.hamming_weight, self.n))
+
+    def states(self):
+        """The basis states, ascending (device int64 tensor holding the u64 values)."""
+        torch = _torch()
+        out = torch.empty(self.n, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        _lib.check(_lib.load().asp_plain_basis_states(self._handle, _ptr(out)))
+        return out
+
+    def matvec(self, x, out=None):
+        torch = _torch()
+        if out is None:
+            out = torch.empty_like(x)
+        if x.dtype != torch.float64 or not x.is_contiguous() or x.shape[0] != self.n:
+            raise ValueError("x must be a contiguous f64 vector of the basis dimension")
+        torch.cuda.synchronize()
+        _lib.check(_lib.load().asp_plain_matvec(self._handle, _ptr(x), _ptr(out)))
+        return out
+
+    def release(self) -> None:
+        handle, self._handle = getattr(self, "_handle", None), None
+        if handle:
+            self._lib_module.load().asp_plain_basis_destroy(handle)
+
+    def __del__(self):
+        module = getattr(self, "_lib_module", None)
+        if module is not None and getattr(self, "_handle", None) and not module.closed():
+            try:
+                self.release()
+            except Exception:
+                pass
+
+
+def lanczos_two_pass(matrix, tol: float = 1e-9, max_iterations: int = 1000, seed: int = 0, log=None):
+    """Lowest eigenpair with THREE vectors of device memory: the plain three-term recurrence
+    (no reorthogonalisation — copies of converged Ritz values appear, the lowest one and its
+    vector are not affected), then the same recurrence again to assemble the eigenvector from
+    the tridiagonal matrix's.  For bases whose Krylov vectors cannot all be kept (sk_32_1:
+    4.8 GB each).  Same return value as :func:`lanczos_ground_state`."""
+    torch = _torch()
+    import scipy.linalg
+
+    n = matrix.n
+    start = torch.from_numpy(np.random.default_rng(seed).standard_normal(n)).cuda()
+    start /= torch.linalg.vector_norm(start)
+    tick = time.time()
+
+    def recurrence(steps, combine=None):
+        """alphas, betas of `steps` steps; with `combine` (Ritz coefficients) also sum_j c_j v_j."""
+        v = start.clone()
+        previous = torch.zeros_like(v)
+        w = torch.empty_like(v)
+        total = torch.zeros_like(v) if combine is not None else None
+        alphas, betas = [], []
+        beta = 0.0
+        for j in range(steps):
+            if total is not None:
+                total.add_(v, alpha=float(combine[j]))
+                if j + 1 == steps:
+                    break
+            matrix.matvec(v, out=w)
+            alpha = float(torch.dot(v, w))
+            w.add_(v, alpha=-alpha)
+            if j > 0:
+                w.add_(previous, alpha=-beta)
+            alphas.append(alpha)
+            beta = float(torch.linalg.vector_norm(w))
+            if combine is None:
+                done = beta < 1e-13 or j + 1 == steps
+                if (j + 1) % 10 == 0 or done:
+                    theta, s = scipy.linalg.eigh_tridiagonal(np.asarray(alphas), np.asarray(betas),
+                                                             select="i", select_range=(0, 0))
+                    residual = abs(beta * s[-1, 0])
+                    if log and ((j + 1) % 50 == 0 or done or residual < tol * max(1.0, abs(theta[0]))):
+                        log("  Lanczos step %d: E = %.12f, residual %.2e  [%.1f s]" % (
+                            j + 1, theta[0], residual, time.time() - tick))
+                    if residual < tol * max(1.0, abs(theta[0])) or done:
+                        return alphas, betas, float(theta[0]), s[:, 0], float(residual)
+            betas.append(beta)
+            previous, v, w = v, w, previous
+            v /= beta
+        return total
+
+    alphas, betas, energy, ritz, residual = recurrence(min(max_iterations, n))
+    vector = recurrence(len(alphas), combine=ritz)
+    vector /= torch.linalg.vector_norm(vector)
+    hv = matrix.matvec(vector)
+    energy = float(torch.dot(vector, hv))
+    hv.add_(vector, alpha=-energy)
+    true_residual = float(torch.linalg.vector_norm(hv))
+    del hv
+    top = int(torch.argmax(torch.abs(vector)))
+    if float(vector[top]) < 0:
+        vector.neg_()
+    info = {"iterations": len(alphas), "ritz_residual": residual, "residual": true_residual,
+            "seconds": time.time() - tick}
+    if log:
+        log("ground state: E = %.12f, |H psi - E psi| = %.2e, %d steps (two passes), %.1f s" % (
+            energy, true_residual, len(alphas), info["seconds"]))
+    return energy, vector, info
+
+
 def sector_norms(operator, representatives) -> "torch.Tensor":
     """Norms of given representatives (device f64[K]) — ``asp_operator_state_info``."""
     torch = _torch()
@@ -195,6 +322,24 @@ def ground_state(operator, tol: float = 1e-9, max_iterations: int = 400, seed: i
     ``operator`` — enumeration (unless the sorted ``representatives`` are given), matrix,
     Lanczos, all on the device."""
     torch = _torch()
+    basis = operator.basis
+    if basis.group is None and basis.hamming_weight is not None:
+        # without symmetries the states have a closed-form index: when the resident matrix would
+        # not fit in half of the free memory, the product is regenerated on the fly instead
+        dimension = binomial(basis.number_spins, int(basis.hamming_weight))
+        width = int(_lib.load().asp_sector_width(operator.device()._handle))
+        free, _ = torch.cuda.mem_get_info()
+        if dimension * (12.0 * width + 24.0) > 0.5 * free:
+            matrix = PlainBasisMatrix(operator, log=log)
+            energy, vector, info = lanczos_two_pass(matrix, tol=tol, max_iterations=max(max_iterations, 1000),
+                                                    seed=seed, log=log)
+            info["dimension"] = matrix.n
+            psi = vector.cpu().numpy()
+            del vector
+            states = matrix.states().cpu().numpy().view(np.uint64)
+            matrix.release()
+            torch.cuda.empty_cache()
+            return energy, psi, states, info
     if representatives is None:
         reps, norms = enumerate_sector(operator, log=log)
     else:

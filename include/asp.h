@@ -180,6 +180,18 @@ int asp_operator_set_symmetry(asp_operator *op, uint32_t num_permutations, uint8
 int asp_operator_state_info(asp_operator const *op, uint64_t n, uint64_t const *keys,
                             uint64_t *representatives, double *characters, double *norms);
 
+/* y = H x, matrix-free, in a fixed-magnetisation basis without lattice symmetries
+ * (csrc/plain_basis.hip): sk_32_1.yaml's C(32,16) = 6.0e8 states x 496 bonds are too many matrix
+ * elements to keep resident (asp_sector_rows) but have a closed-form index.  States ascending;
+ * asp_plain_basis_states writes them (device pointer, `dimension` entries).  Bonds must conserve
+ * the magnetisation (off-diagonal weight on 01 <-> 10 only); 2..36 spins. */
+typedef struct asp_plain_basis asp_plain_basis;
+int asp_plain_basis_create(asp_operator const *op, int32_t hamming_weight, asp_plain_basis **out);
+void asp_plain_basis_destroy(asp_plain_basis *pb);
+uint64_t asp_plain_basis_dimension(asp_plain_basis const *pb);
+int asp_plain_basis_states(asp_plain_basis const *pb, uint64_t *states_dev);
+int asp_plain_matvec(asp_plain_basis const *pb, double const *x_dev, double *y_dev);
+
 /* Positions of states in a long ascending list kept on the device (csrc/key_table.hip): what
  * `basis.batched_index(spins)` (common.py:813-818) is for a basis of tens of millions of
  * representatives.  index[q] = position of queries[q], or -1.  Host pointers; thread-safe. */

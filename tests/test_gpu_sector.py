@@ -140,3 +140,36 @@ def test_device_index_of_a_large_basis_equals_searchsorted():
     unsorted = np.array([3, 2, 5], dtype=np.uint64)
     assert lib.asp_table_create(3, _lib.ptr(unsorted), ctypes.byref(handle)) != 0
     basis.release_table()
+
+
+def test_matrix_free_product_of_plain_bases_equals_the_host_route(models):
+    """csrc/plain_basis.hip (the route sk_32_1.yaml's 6.0e8 states take): states, y = Hx and the
+    three-vector Lanczos against numpy / scipy on the 16-site models and an 18-site chain whose
+    sites straddle the two index words unevenly."""
+    import scipy.sparse.linalg
+    import torch
+
+    from annealing_sign_problem_amd import operators, sector_ed
+
+    chain = operators.Operator(operators.SpinBasis(18, 7), [
+        operators.Term(operators.SIGMA_DOT_SIGMA, [(i, (i + 1) % 18) for i in range(18)]),
+        operators.Term(0.37 * operators.SIGMA_DOT_SIGMA, [(i, (i + 5) % 18) for i in range(18)])])
+    cases = [(name, operators.Operator.from_config(models[name]))
+             for name in ("heisenberg_kagome_16", "j1j2_square_4x4", "sk_16_1")] + [("chain18", chain)]
+    for name, op in cases:
+        op.basis.build()
+        matrix = sector_ed.PlainBasisMatrix(op)
+        assert matrix.n == op.basis.number_states, name
+        assert np.array_equal(matrix.states().cpu().numpy().view(np.uint64), op.basis.states), name
+        h = op.to_sparse().real.tocsr()
+        x = np.random.default_rng(2).standard_normal(matrix.n)
+        y = matrix.matvec(torch.from_numpy(x).cuda()).cpu().numpy()
+        assert np.allclose(y, h @ x, rtol=0, atol=1e-11 * abs(h).sum(axis=1).max()), name
+        energy, vector, info = sector_ed.lanczos_two_pass(matrix, tol=1e-10)
+        want = scipy.sparse.linalg.eigsh(h, k=1, which="SA", tol=1e-13)[0][0]
+        assert abs(energy - want) < 1e-8 * abs(want), (name, energy, want, info)
+        assert info["residual"] < 1e-6, (name, info)
+        matrix.release()
+    # lattice symmetries and unconstrained magnetisation are other routes
+    with pytest.raises(ValueError):
+        sector_ed.PlainBasisMatrix(operators.Operator.from_config(models["heisenberg_kagome_18"]))
