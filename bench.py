@@ -399,25 +399,36 @@ def bench_real_kagome_36(replicas, sweeps, targets=(10_000, 30_000, 100_000), se
     for target in targets:
         rest = [m for m in models if all(m is not c for c in chosen)]
         chosen.append(min(rest, key=lambda m: abs(np.log(m.size / target))))
-    flips, seconds, shapes = 0, 0.0, []
+    from annealing_sign_problem_amd import _lib
+
+    lib = _lib.load()
+    flips, seconds, kernel_ms, shapes = 0, 0.0, 0.0, []
     for m in chosen:
         ham = m.ising_hamiltonian
         hinfo = ham.info()
         betas = sa.make_schedule(hinfo.beta0_auto, hinfo.beta1_auto, sweeps)
-        sa.anneal_raw(ham, 12345, betas, replicas)  # warm-up (plan upload)
-        t0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(2):
+            sa.anneal_raw(ham, 12345, betas, replicas)  # warm-up (plan upload, clocks)
+        calls = []
+        for _ in range(5):
+            t0 = time.perf_counter()
             sa.anneal_raw(ham, 12345, betas, replicas)
-        seconds += time.perf_counter() - t0
-        flips += 3 * m.size * replicas * sweeps
+            calls.append((time.perf_counter() - t0, lib.asp_sa_last_sweep_ms(ham.plan())))
+        # medians: an occasional host-side stall (50 ms once in ten calls) is not the workload
+        seconds += float(np.median([c[0] for c in calls]))
+        kernel_ms += float(np.median([c[1] for c in calls]))
+        flips += m.size * replicas * sweeps
         j = ham.exchange
         shapes.append({"K": int(m.size), "dbar": float(j.nnz / j.shape[0]),
-                       "colors": int(hinfo.num_colors), "max_degree": int(hinfo.max_degree)})
+                       "colors": int(hinfo.num_colors), "max_degree": int(hinfo.max_degree),
+                       "call_ms": [round(c[0] * 1e3, 2) for c in calls],
+                       "sweep_kernel_ms": [round(c[1], 2) for c in calls]})
     return {
         "workload": "real heisenberg_kagome_36 clusters (order-2 extension, cutoff 1e-6) closest to "
-                    "K = %s, %d chains x %d sweeps per call" % ("/".join(str(t) for t in targets),
-                                                                  replicas, sweeps),
+                    "K = %s, %d chains x %d sweeps per call (median of 5 calls each)" % (
+                        "/".join(str(t) for t in targets), replicas, sweeps),
         "flips_per_s": flips / seconds,
+        "kernel_flips_per_s": flips / (kernel_ms * 1e-3),
         "clusters": shapes,
         "sector_dimension": int(info["dimension"]),
         "ground_state_energy": energy,

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 state check: full suite, smoke, bench as the driver runs it, kagome_36 pipeline vs host threads
+# Round-2 state check: full suite, smoke, bench as the driver runs it, then the rocprofv3 passes
 set -o pipefail
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r2final
@@ -12,12 +12,8 @@ timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smok
 [ $rc -eq 0 ] || exit $rc
 timeout -k 10 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.log 2>&1; rc=$?; echo "bench rc=$rc" | tee -a $OUT/status.txt
 [ $rc -eq 0 ] || exit $rc
-timeout -k 10 300 python -m annealing_sign_problem_amd.sector_ed --model heisenberg_kagome_36 --output /tmp/k36.h5 > $OUT/ed.log 2>&1 || exit 5
-for jobs in 1 4 8 16; do
-  t0=$(date +%s%N)
-  timeout -k 10 300 python -m annealing_sign_problem_amd.sampled_components --model heisenberg_kagome_36 --hdf5 /tmp/k36.h5 --seed 435834 \
-    --output $OUT/k36_jobs$jobs.csv --order 2 --no-annealing --global-cutoff 1e-6 --number-samples 256 --jobs $jobs > $OUT/k36_jobs$jobs.log 2>&1 || exit 6
-  echo "kagome_36 256 clusters x 3 orders greedy, --jobs $jobs: $(( ($(date +%s%N) - t0) / 1000000 )) ms (incl. reading the 504 MB ground-state file)" | tee -a $OUT/pipeline_jobs.txt
-done
-cmp $OUT/k36_jobs1.csv $OUT/k36_jobs8.csv && echo "outputs identical" | tee -a $OUT/pipeline_jobs.txt
-tail -c 1200 $OUT/bench.log
+timeout -k 10 300 python bench.py > $OUT/bench_default.log 2>&1; rc=$?; echo "bench (default flags) rc=$rc" | tee -a $OUT/status.txt
+[ $rc -eq 0 ] || exit $rc
+bash tools/gpu_profile.sh r02 > $OUT/profile.log 2>&1; echo "profile rc=$?" | tee -a $OUT/status.txt
+cp profiles/r02_bench_kernel_stats.csv profiles/r02_build_kernel_stats.csv profiles/r02_batch_kernel_stats.csv profiles/r02_summary.json profiles/traffic.json profiles/sweep_counters.json $OUT/ 2>/dev/null
+tail -c 700 $OUT/bench.log
