@@ -71,3 +71,51 @@ def test_plan_rejects_bad_matrices_and_oversized_problems():
     rc = lib.asp_sa_anneal(ok.plan(), 1, _lib.ptr(bad_betas), 2, 1, 0, None, _lib.ptr(out_x),
                            _lib.ptr(out_e))
     assert rc == -3 and b"betas" in lib.asp_last_error()
+
+
+def test_sector_and_table_entry_points_report_violated_preconditions(models):
+    """csrc/sector_basis.hip, plain_basis.hip, key_table.hip: capacity, null pointers, wrong kind
+    of basis — an error code and a message, and the library keeps working afterwards."""
+    import torch
+
+    from annealing_sign_problem_amd import _lib, operators, sector_ed
+
+    lib = _lib.load()
+    ring = operators.Operator.from_config(models["heisenberg_kagome_18"])
+    handle = ring.device()._handle
+    count = ctypes.c_uint64(0)
+    # sizing call: nothing written, the count returned
+    _lib.check(lib.asp_sector_enumerate(handle, 9, 0, None, None, ctypes.byref(count)))
+    assert count.value == 24310
+    small = torch.zeros(100, dtype=torch.int64, device="cuda")
+    rc = lib.asp_sector_enumerate(handle, 9, 100, ctypes.c_void_p(small.data_ptr()), None, ctypes.byref(count))
+    assert rc == -4 and count.value == 24310 and "capacity" in _lib.last_error()
+    assert int(small.abs().sum()) == 0                       # untouched
+    assert lib.asp_sector_enumerate(handle, 19, 0, None, None, ctypes.byref(count)) == -3   # weight > n
+    assert lib.asp_sector_enumerate(None, 9, 0, None, None, ctypes.byref(count)) == -3
+    assert lib.asp_sector_enumerate(handle, 9, 0, None, None, None) == -3
+    # rows: width below the operator's, null arrays
+    reps, norms = sector_ed.enumerate_sector(ring)
+    n = reps.shape[0]
+    idx = torch.zeros((4, n), dtype=torch.int32, device="cuda")
+    val = torch.zeros((4, n), dtype=torch.float64, device="cuda")
+    diag = torch.zeros(n, dtype=torch.float64, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    assert lib.asp_sector_rows(handle, n, p(reps), p(norms), 4, p(idx), p(val), p(diag)) == -3
+    assert "width" in _lib.last_error()
+    assert lib.asp_sector_rows(handle, n, p(reps), None, 36, p(idx), p(val), p(diag)) == -3
+    assert lib.asp_sector_matvec(n, 4, p(idx), p(val), p(diag), p(diag), p(diag)) == -3      # x aliases y
+    # the matrix-free product: symmetric bases and magnetisation-violating bonds are refused
+    out = ctypes.c_void_p()
+    assert lib.asp_plain_basis_create(handle, 9, ctypes.byref(out)) == -3 and "symmetries" in _lib.last_error()
+    flip = np.zeros((4, 4))
+    flip[0, 1] = flip[1, 0] = 1.0                      # sigma^x on the second site: changes Sz
+    bad = operators.Operator(operators.SpinBasis(6, 3), [operators.Term(flip, [(0, 1)])])
+    assert lib.asp_plain_basis_create(bad.device()._handle, 3, ctypes.byref(out)) == -3
+    assert "magnetisation" in _lib.last_error()
+    plain = operators.Operator.from_config(models["heisenberg_kagome_16"])
+    assert lib.asp_plain_basis_create(plain.device()._handle, -1, ctypes.byref(out)) == -3
+    # and everything still works
+    matrix = sector_ed.SectorMatrix(ring, reps, norms)
+    energy, _, info = sector_ed.lanczos_ground_state(matrix, tol=1e-10)
+    assert abs(energy + 31.054814383595) < 1e-8 and info["residual"] < 1e-6
