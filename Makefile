@@ -64,7 +64,7 @@ kagome_36 pyrochlore_32 sk_32_1:
 # The ground states the reference downloads (Makefile:143-153, SpinED output) are regenerated on
 # the GPU when absent: representatives, resident Hamiltonian and Lanczos of the whole symmetry
 # sector (annealing_sign_problem_amd/sector_ed.py; heisenberg_kagome_36: 31.5 M representatives,
-# about 10 s; sk_32_1: 6.0e8 states, matrix-free product, about 4 minutes and 10 GB of file).
+# about 10 s; sk_32_1: 6.0e8 states, matrix-free product, about 3 minutes and 10 GB of file).
 $(DATA)/heisenberg_kagome_36.h5 $(DATA)/heisenberg_pyrochlore_2x2x2.h5 $(DATA)/sk_32_1.h5:
 	@mkdir -p $(DATA)
 	$(PYTHON) -m annealing_sign_problem_amd.sector_ed --model $(basename $(notdir $@)) --output $@ --tol 1e-8

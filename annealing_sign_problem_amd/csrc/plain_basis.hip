@@ -7,9 +7,11 @@
 //
 //   state = (high word, low word);  index = offset[high] + rank[low]
 //
-// with rank[low] = position of the low word among the low words of its population count.  One
-// workgroup owns one high word: its states are consecutive, rank[] (2^16 x u16 = 128 KB) sits in
-// LDS, and a bond falls in one of three classes handled without per-lane address arithmetic:
+// with rank[low] = position of the low word among the low words of its population count — itself
+// two-level: rank = before[low >> 8][popcount] + rank8[low & 255], 9 KB of LDS instead of a
+// 128 KB table, so that two workgroups of 1024 threads share a CU (the product is bound by the
+// latency of its gathers).  One workgroup owns one high word: its states are consecutive, and a
+// bond falls in one of three classes handled without per-lane address arithmetic:
 //
 //   both sites in the high word   the flip is uniform: x is read at the SAME ranks of another
 //                                 high word's block — a coalesced stream
@@ -52,7 +54,9 @@ struct PlainArgs {
   uint32_t lo_bits;
   int32_t weight;
   const uint64_t *offset;       // [2^hi_bits + 1]
-  const uint16_t *rank;         // [2^lo_bits]
+  const uint16_t *before;       // [2^(lo_bits - 8)][lo_bits + 1]: low words of that class with a smaller top part
+  const uint16_t *rank8;        // [256]: rank of the bottom byte among the bytes of its population count
+  uint32_t before_entries;
   const uint32_t *words;        // low words grouped by population count
   const uint32_t *class_start;  // [lo_bits + 2]
   const double *x;
@@ -61,16 +65,20 @@ struct PlainArgs {
 };
 
 __global__ __launch_bounds__(kThreads) void k_plain_matvec(PlainArgs a) {
-  extern __shared__ uint16_t rank_lds[];
+  extern __shared__ uint16_t tables[];  // before[...], then rank8[256]
   const uint32_t hi = blockIdx.x;
   const int32_t k = a.weight - __popc(hi);
   if (k < 0 || k > static_cast<int32_t>(a.lo_bits)) return;  // whole workgroup
-  {
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(a.rank);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(rank_lds);
-    for (uint32_t i = threadIdx.x; i < (1u << a.lo_bits) / 2u; i += kThreads) dst[i] = src[i];
-  }
+  uint16_t *rank8 = tables + a.before_entries;
+  for (uint32_t i = threadIdx.x; i < a.before_entries; i += kThreads) tables[i] = a.before[i];
+  for (uint32_t i = threadIdx.x; i < 256u; i += kThreads) rank8[i] = a.rank8[i];
   __syncthreads();
+  const uint32_t classes = a.lo_bits + 1u;
+  // position of a low word among the low words of its population count
+  auto rank_of = [&](uint32_t low) -> uint32_t {
+    return static_cast<uint32_t>(tables[(low >> 8) * classes + static_cast<uint32_t>(__popc(low))]) +
+           rank8[low & 255u];
+  };
   const uint32_t begin = a.class_start[k];
   const uint32_t size = a.class_start[k + 1] - begin;
   const uint64_t base = a.offset[hi];
@@ -100,7 +108,7 @@ __global__ __launch_bounds__(kThreads) void k_plain_matvec(PlainArgs a) {
         if (live) {
           if (bp != bq) {
             const uint32_t target = lo ^ ((1u << bond.p) | (1u << bond.q));
-            acc = __fma_rn(bp ? bond.row2 : bond.row1, a.x[base + rank_lds[target]], acc);
+            acc = __fma_rn(bp ? bond.row2 : bond.row1, a.x[base + rank_of(target)], acc);
           }
         }
       } else {
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(kThreads) void k_plain_matvec(PlainArgs a) {
             // row state: first site's bit * 2 + second site's bit; 10 -> row2, 01 -> row1
             const uint32_t first_bit = first_high ? bh : bl;
             acc = __fma_rn(first_bit ? bond.row2 : bond.row1,
-                           a.x[other + rank_lds[lo ^ (1u << lbit)]], acc);
+                           a.x[other + rank_of(lo ^ (1u << lbit))], acc);
           }
         }
       }
@@ -148,7 +156,8 @@ struct asp_plain_basis {
   uint32_t num_bonds = 0;
   DeviceBuffer<PlainBond> d_bonds;
   DeviceBuffer<uint64_t> d_offset;
-  DeviceBuffer<uint16_t> d_rank;
+  DeviceBuffer<uint16_t> d_before, d_rank8;
+  uint32_t before_entries = 0;
   DeviceBuffer<uint32_t> d_words, d_class_start;
   PlainArgs args() const {
     PlainArgs a{};
@@ -157,7 +166,9 @@ struct asp_plain_basis {
     a.lo_bits = lo_bits;
     a.weight = weight;
     a.offset = d_offset.ptr;
-    a.rank = d_rank.ptr;
+    a.before = d_before.ptr;
+    a.rank8 = d_rank8.ptr;
+    a.before_entries = before_entries;
     a.words = d_words.ptr;
     a.class_start = d_class_start.ptr;
     return a;
@@ -209,15 +220,27 @@ int asp_plain_basis_create(asp_operator const *op, int32_t hamming_weight, asp_p
     return key(l.kind) < key(r.kind);
   });
   std::vector<uint32_t> class_start(lo_bits + 2, 0), words(size_t{1} << lo_bits);
-  std::vector<uint16_t> rank(size_t{1} << lo_bits);
   for (uint32_t w = 0; w < (1u << lo_bits); ++w) ++class_start[static_cast<uint32_t>(__builtin_popcount(w)) + 1];
   for (uint32_t p = 0; p <= lo_bits; ++p) class_start[p + 1] += class_start[p];
   {
     std::vector<uint32_t> fill(class_start.begin(), class_start.end() - 1);
-    for (uint32_t w = 0; w < (1u << lo_bits); ++w) {
-      const uint32_t c = static_cast<uint32_t>(__builtin_popcount(w));
-      rank[w] = static_cast<uint16_t>(fill[c] - class_start[c]);
-      words[fill[c]++] = w;
+    for (uint32_t w = 0; w < (1u << lo_bits); ++w) words[fill[static_cast<uint32_t>(__builtin_popcount(w))]++] = w;
+  }
+  // rank of a low word inside its class = (words of the class with a smaller top part) + (rank
+  // of its bottom byte among the bytes of the same population count): ascending order is
+  // top-part major
+  const uint32_t bottom_bits = std::min(lo_bits, 8u), top_values = 1u << (lo_bits - bottom_bits);
+  std::vector<uint16_t> rank8(256, 0), before(static_cast<size_t>(top_values) * (lo_bits + 1), 0);
+  {
+    uint32_t seen[9] = {0};
+    for (uint32_t v = 0; v < (1u << bottom_bits); ++v) rank8[v] = static_cast<uint16_t>(seen[__builtin_popcount(v)]++);
+    for (uint32_t c = 0; c <= lo_bits; ++c) {
+      uint32_t running = 0;
+      for (uint32_t t = 0; t < top_values; ++t) {
+        before[static_cast<size_t>(t) * (lo_bits + 1) + c] = static_cast<uint16_t>(running);
+        const int32_t rest = static_cast<int32_t>(c) - __builtin_popcount(t);
+        if (rest >= 0 && rest <= static_cast<int32_t>(bottom_bits)) running += seen[rest];  // C(bottom_bits, rest)
+      }
     }
   }
   std::vector<uint64_t> offset((size_t{1} << hi_bits) + 1, 0);
@@ -236,24 +259,20 @@ int asp_plain_basis_create(asp_operator const *op, int32_t hamming_weight, asp_p
   pb->num_bonds = op->num_bonds;
   int rc = pb->d_bonds.alloc(bonds.size());
   if (rc == ASP_OK) rc = pb->d_offset.alloc(offset.size());
-  if (rc == ASP_OK) rc = pb->d_rank.alloc(rank.size());
+  if (rc == ASP_OK) rc = pb->d_before.alloc(before.size());
+  if (rc == ASP_OK) rc = pb->d_rank8.alloc(rank8.size());
   if (rc == ASP_OK) rc = pb->d_words.alloc(words.size());
   if (rc == ASP_OK) rc = pb->d_class_start.alloc(class_start.size());
   if (rc == ASP_OK) rc = pb->d_bonds.upload(bonds.data(), bonds.size(), nullptr);
   if (rc == ASP_OK) rc = pb->d_offset.upload(offset.data(), offset.size(), nullptr);
-  if (rc == ASP_OK) rc = pb->d_rank.upload(rank.data(), rank.size(), nullptr);
+  if (rc == ASP_OK) rc = pb->d_before.upload(before.data(), before.size(), nullptr);
+  if (rc == ASP_OK) rc = pb->d_rank8.upload(rank8.data(), rank8.size(), nullptr);
   if (rc == ASP_OK) rc = pb->d_words.upload(words.data(), words.size(), nullptr);
   if (rc == ASP_OK) rc = pb->d_class_start.upload(class_start.data(), class_start.size(), nullptr);
   if (rc == ASP_OK && hipStreamSynchronize(nullptr) != hipSuccess) {
     rc = asp::set_error(ASP_ERR_HIP, "upload of the basis tables failed");
   }
-  if (rc == ASP_OK && (sizeof(uint16_t) << lo_bits) > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_plain_matvec),
-                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                            static_cast<int>(sizeof(uint16_t) << lo_bits)) != hipSuccess) {
-      rc = asp::set_error(ASP_ERR_HIP, "cannot reserve %zu bytes of LDS", sizeof(uint16_t) << lo_bits);
-    }
-  }
+  pb->before_entries = static_cast<uint32_t>(before.size());
   if (rc != ASP_OK) {
     delete pb;
     return rc;
@@ -295,7 +314,7 @@ int asp_plain_matvec(asp_plain_basis const *pb, double const *x_dev, double *y_d
   a.x = x_dev;
   a.y = y_dev;
   hipLaunchKernelGGL(k_plain_matvec, dim3(1u << pb->hi_bits), dim3(kThreads),
-                     sizeof(uint16_t) << pb->lo_bits, scoped.stream, a);
+                     sizeof(uint16_t) * (pb->before_entries + 256u), scoped.stream, a);
   ASP_HIP_TRY(hipGetLastError());
   ASP_HIP_TRY(hipStreamSynchronize(scoped.stream));
   return ASP_OK;

@@ -17,7 +17,7 @@ one MI355X:
 ``sk_32_1.yaml`` — 6.0e8 states without lattice symmetries, 496 bonds — takes another route: its
 matrix does not fit, but its basis has a closed-form index, so ``asp_plain_matvec``
 (csrc/plain_basis.hip) regenerates the product on the fly and :func:`lanczos_two_pass` keeps
-three vectors of 4.8 GB (about four minutes in all).
+three vectors of 4.8 GB (about three minutes in all).
 
 Output in the layout the reference's loaders expect (:func:`write_spined_hdf5`), so that the
 reference's own command lines (``--yaml ... --hdf5 ...``) run on it.
