@@ -464,6 +464,6 @@ int asp_shutdown(void) {
   return asp::shutdown_pools();
 }
 
-const char *asp_version(void) { return "0.2.0"; }
+const char *asp_version(void) { return "0.3.0"; }
 
 }  // extern "C"
