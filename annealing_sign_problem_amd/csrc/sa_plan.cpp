@@ -211,50 +211,72 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
     const size_t words = (static_cast<size_t>(max_deg) + 2 + 63) / 64;  // colours <= max_deg + 1
     std::vector<uint64_t> seen(n * words, 0);
     std::vector<uint32_t> saturation(n, 0);
-    // Priority = (saturation, degree) with the smallest index first among equals.  Both are
-    // small integers, so the queue is an array of buckets keyed saturation * (max_deg + 1) +
-    // degree, each a min-heap of indices with lazy deletion, plus a two-level bitmap of the
-    // non-empty buckets (find-last-set gives the best bucket).
-    const uint32_t stride = max_deg + 1;
-    const size_t num_buckets = static_cast<size_t>(max_deg + 2) * stride;
-    using MinHeap = std::priority_queue<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>>;
-    std::vector<MinHeap> buckets(num_buckets);
-    std::vector<uint64_t> level0((num_buckets + 63) / 64, 0);
-    std::vector<uint64_t> level1((level0.size() + 63) / 64, 0);
-    auto mark = [&](size_t key) {
-      level0[key >> 6] |= 1ull << (key & 63);
-      level1[key >> 12] |= 1ull << ((key >> 6) & 63);
-    };
-    auto unmark = [&](size_t key) {
-      level0[key >> 6] &= ~(1ull << (key & 63));
-      if (level0[key >> 6] == 0) level1[key >> 12] &= ~(1ull << ((key >> 6) & 63));
-    };
+    // Priority = (saturation desc, degree desc, index asc).  The last two never change: every
+    // spin gets its RANK in (degree desc, index asc) once (a counting sort), and the queue is one
+    // set of ranks per saturation value — a bit set with 64-ary summary levels, so "smallest
+    // rank" is a few count-trailing-zeros and moving a spin up one saturation level a few word
+    // operations on arrays that stay in cache (n / 8 bytes per level).
     auto degree_of = [&](uint32_t i) { return static_cast<uint32_t>(L.a_ptr[i + 1] - L.a_ptr[i]); };
-    for (uint64_t i = 0; i < n; ++i) {
-      const size_t key = degree_of(static_cast<uint32_t>(i));
-      buckets[key].push(static_cast<uint32_t>(i));
-      mark(key);
-    }
-    uint32_t ncol = 0;
-    uint64_t remaining = n;
-    while (remaining > 0) {
-      size_t top1 = level1.size();
-      while (top1 > 0 && level1[top1 - 1] == 0) --top1;
-      const size_t w1 = top1 - 1;  // remaining > 0: some bucket is marked
-      const size_t w0 = w1 * 64 + (63 - static_cast<size_t>(__builtin_clzll(level1[w1])));
-      const size_t key = w0 * 64 + (63 - static_cast<size_t>(__builtin_clzll(level0[w0])));
-      MinHeap &bucket = buckets[key];
-      const uint32_t v = bucket.top();
-      bucket.pop();
-      if (bucket.empty()) unmark(key);
-      if (L.color[v] >= 0 || key != static_cast<size_t>(saturation[v]) * stride + degree_of(v)) {
-        continue;  // stale entry
+    std::vector<uint32_t> rank_of(n), spin_at(n);
+    {
+      std::vector<uint64_t> start(static_cast<size_t>(max_deg) + 2, 0);
+      for (uint64_t i = 0; i < n; ++i) ++start[max_deg - degree_of(static_cast<uint32_t>(i)) + 1];
+      for (size_t d = 0; d + 1 < start.size(); ++d) start[d + 1] += start[d];
+      for (uint64_t i = 0; i < n; ++i) {  // ascending index inside a degree class
+        const uint64_t r = start[max_deg - degree_of(static_cast<uint32_t>(i))]++;
+        rank_of[i] = static_cast<uint32_t>(r);
+        spin_at[r] = static_cast<uint32_t>(i);
       }
+    }
+    struct RankSet {
+      std::vector<std::vector<uint64_t>> level;  // level[0]: members; level[k + 1]: non-empty words of level[k]
+      uint64_t count = 0;
+      void init(uint64_t size) {
+        uint64_t m = size;
+        do {
+          m = (m + 63) / 64;
+          level.emplace_back(m, 0);
+        } while (m > 1);
+      }
+      void insert(uint64_t i) {
+        ++count;
+        for (auto &l : level) {
+          uint64_t &w = l[i >> 6];
+          const bool was_empty = w == 0;
+          w |= 1ull << (i & 63);
+          if (!was_empty) return;
+          i >>= 6;
+        }
+      }
+      void erase(uint64_t i) {
+        --count;
+        for (auto &l : level) {
+          uint64_t &w = l[i >> 6];
+          w &= ~(1ull << (i & 63));
+          if (w != 0) return;
+          i >>= 6;
+        }
+      }
+      uint64_t smallest() const {  // count > 0
+        uint64_t i = 0;
+        for (size_t k = level.size(); k-- > 0;) i = i * 64 + static_cast<uint64_t>(__builtin_ctzll(level[k][i]));
+        return i;
+      }
+    };
+    std::vector<RankSet> waiting(1);
+    waiting[0].init(n);
+    for (uint64_t r = 0; r < n; ++r) waiting[0].insert(r);
+    size_t highest = 0;
+    uint32_t ncol = 0;
+    for (uint64_t remaining = n; remaining > 0; --remaining) {
+      while (waiting[highest].count == 0) --highest;  // remaining > 0: some level holds a spin
+      const uint64_t r = waiting[highest].smallest();
+      waiting[highest].erase(r);
+      const uint32_t v = spin_at[r];
       const uint64_t *mine = &seen[static_cast<size_t>(v) * words];
       uint32_t c = 0;
       while ((mine[c >> 6] >> (c & 63)) & 1ull) ++c;
       L.color[v] = static_cast<int32_t>(c);
-      --remaining;
       ncol = std::max(ncol, c + 1);
       for (int64_t k = L.a_ptr[v]; k < L.a_ptr[v + 1]; ++k) {
         const uint32_t u = static_cast<uint32_t>(L.a_col[k]);
@@ -262,10 +284,14 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
         uint64_t &word = seen[static_cast<size_t>(u) * words + (c >> 6)];
         if ((word >> (c & 63)) & 1ull) continue;
         word |= 1ull << (c & 63);
-        saturation[u] += 1;
-        const size_t moved = static_cast<size_t>(saturation[u]) * stride + degree_of(u);
-        buckets[moved].push(u);
-        mark(moved);
+        const size_t from = saturation[u]++;
+        if (waiting.size() <= from + 1) {
+          waiting.emplace_back();
+          waiting.back().init(n);
+        }
+        waiting[from].erase(rank_of[u]);
+        waiting[from + 1].insert(rank_of[u]);
+        highest = std::max(highest, from + 1);
       }
     }
     L.num_colors = ncol;
