@@ -312,6 +312,23 @@ class Operator:
         v0 = rng.standard_normal(h.shape[0])
         values, vectors = scipy.sparse.linalg.eigsh(h, k=1, which="SA", v0=v0, tol=1e-13)
         psi = vectors[:, 0]
+        if self.basis.group is not None and h.shape[0] > 8:
+            # A symmetry sector can have a DEGENERATE lowest level (heisenberg_kagome_18.yaml: three
+            # times -31.0548143836).  Which vector of that eigenspace an eigensolver returns
+            # depends on its arithmetic — another BLAS, another vector, another sign problem
+            # (DESIGN.md §6.1).  The vector is therefore fixed by construction: the projection of
+            # the start vector v0 onto the eigenspace.
+            k = min(6, h.shape[0] - 2)
+            several, basis = scipy.sparse.linalg.eigsh(h, k=k, which="SA", v0=v0, tol=1e-13)
+            order = np.argsort(several)
+            several, basis = several[order], basis[:, order]
+            level = np.abs(several - several[0]) <= 1e-8 * max(1.0, abs(several[0]))
+            if level.sum() > 1:
+                if level.all():
+                    raise ValueError("the lowest level is at least {}-fold degenerate".format(k))
+                space = np.linalg.qr(basis[:, level])[0]
+                psi = space @ (space.T @ v0)
+                values = several[:1]
         psi = psi * np.sign(psi[np.argmax(np.abs(psi))])
         return float(values[0]), np.ascontiguousarray(psi / np.linalg.norm(psi))
 

@@ -11,8 +11,9 @@ seeds, and requires P(accuracy > 0.995)
     from the library's and statistically distinguishable from it — on the symmetry-free models
     it reaches the exact sign structure as often or more often (up to +0.078, 15 standard errors),
     DESIGN.md §6.1; the ground level of the kagome_18 basis is three-fold degenerate, so its
-    published curve belongs to ANOTHER eigenvector than the one diagonalised here and the success
-    probability moves by up to 0.09 with that choice (profiles/r02_kagome18_degeneracy_probe.txt)
+    published curve belongs to ANOTHER eigenvector than the one used here (Operator.ground_state
+    fixes it by construction) and the success probability moves by up to 0.09 with that choice
+    (profiles/r02_kagome18_degeneracy_probe.txt): +-0.12 for that model
     — so this band only catches gross changes;
   * within +-0.03 of this repository's own recorded measurement (10 x 1024 chains; 4 standard
     errors of the difference are 0.03), the regression pin proper;
@@ -54,7 +55,8 @@ def test_success_probability_matches_published_curve(name, sweeps):
     acc, residual = results[:, 0].mean(), results[:, 2].mean()
     assert residual == acc, "P(residual <= 1e-12) and P(accuracy > 0.995) differ"
     published, own = row["acc_prob_mean"], row.get("mi355x_acc_prob_mean")
-    assert abs(acc - published) <= 0.08, \
+    band = 0.12 if name == "heisenberg_kagome_18" else 0.08   # degenerate ground level, see above
+    assert abs(acc - published) <= band, \
         "%s @ %d sweeps: %.4f vs published %.4f (%s)" % (name, sweeps, acc, published,
                                                         row["reference_line"])
     if own is not None:
