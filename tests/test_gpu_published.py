@@ -70,7 +70,7 @@ def test_success_probability_matches_published_curve(name, sweeps):
 # (three standard errors of the difference are 0.03) of the published mean.
 SHUFFLED_POINTS = [("sk_16_3", 200), ("j1j2_square_4x4", 100), ("heisenberg_kagome_16", 3200),
                    ("sk_16_2", 400), ("sk_16_1", 1600),
-                   # (more of the 41 points of DESIGN.md §6.1, the cheap ones)
+                   # (more of the 46 points of DESIGN.md §6.1, the cheap ones)
                    ("heisenberg_kagome_16", 100), ("heisenberg_kagome_16", 800),
                    ("j1j2_square_4x4", 400), ("j1j2_square_4x4", 1600),
                    ("sk_16_1", 100), ("sk_16_1", 400), ("sk_16_2", 100), ("sk_16_3", 800)]
