@@ -154,8 +154,11 @@ def lanczos_ground_state(matrix: SectorMatrix, tol: float = 1e-9, max_iterations
         used = j + 1
         done = beta < 1e-13 or used == steps
         if used % 5 == 0 or done:
-            theta, s = scipy.linalg.eigh_tridiagonal(np.asarray(alphas), np.asarray(betas), select="i",
-                                                     select_range=(0, 0))
+            if used == 1:  # a one-dimensional Krylov space (n = 1, or the start vector is an eigenvector)
+                theta, s = np.asarray(alphas), np.ones((1, 1))
+            else:
+                theta, s = scipy.linalg.eigh_tridiagonal(np.asarray(alphas), np.asarray(betas), select="i",
+                                                         select_range=(0, 0))
             energy, ritz = float(theta[0]), s[:, 0]
             residual = abs(beta * ritz[-1])
             if log and (used % 25 == 0 or done or residual < tol * max(1.0, abs(energy))):
