@@ -36,6 +36,7 @@ SOURCES = [
     "sa_plan.cpp",
     "greedy.cpp",
     "sa_sweep.hip",
+    "sa_shuffled.hip",
 ]
 
 # -ffp-contract=off: the parity contract needs every multiply/add rounded on its
@@ -54,21 +55,106 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found; libasp_hip.so cannot be built")
 
 
-def _fingerprint(sources: list[str]) -> str:
-    h = hashlib.sha256()
-    h.update(" ".join(HIPCC_FLAGS + EXTRA_FLAGS).encode())
-    deps = list(sources)
+def _header_deps() -> list[str]:
+    deps = []
     for d in (CSRC, INCLUDE):
         for name in sorted(os.listdir(d)):
             if name.endswith((".h", ".hpp")):
                 deps.append(os.path.join(d, name))
-    for path in deps:
+    return deps
+
+
+def _included_headers(source: str) -> list[str]:
+    """The repository headers `source` includes, transitively (quoted includes only)."""
+    import re
+
+    seen: dict[str, None] = {}
+    todo = [source]
+    while todo:
+        path = todo.pop()
+        with open(path, errors="replace") as f:
+            names = re.findall(r'^\s*#\s*include\s*"([^"]+)"', f.read(), flags=re.M)
+        for name in names:
+            for d in (os.path.dirname(path), CSRC, INCLUDE):
+                cand = os.path.join(d, name)
+                if os.path.exists(cand):
+                    if cand not in seen:
+                        seen[cand] = None
+                        todo.append(cand)
+                    break
+    return sorted(seen)
+
+
+def _fingerprint(sources: list[str], headers: list[str] | None = None) -> str:
+    h = hashlib.sha256()
+    h.update(" ".join(HIPCC_FLAGS + EXTRA_FLAGS).encode())
+    for path in list(sources) + (_header_deps() if headers is None else headers):
         # names relative to the repository: the same tree must give the same stamp wherever it
         # is mounted (the GPU box runs a copy under a scratch path)
         h.update(os.path.relpath(path, os.path.dirname(HERE)).encode())
         with open(path, "rb") as f:
             h.update(f.read())
     return h.hexdigest()
+
+
+def fingerprint() -> str:
+    """Fingerprint of the sources and flags libasp_hip.so is built from (what the stamp file next
+    to the library holds).  bench.py ties committed profiler counters to it."""
+    return _fingerprint([os.path.join(CSRC, s) for s in SOURCES])
+
+
+def built_fingerprint() -> str | None:
+    """Fingerprint recorded when the library on disk was built, or None."""
+    try:
+        with open(STAMP_PATH) as f:
+            return f.read().strip() or None
+    except OSError:
+        return None
+
+
+def _compile_objects(sources: list[str], verbose: bool) -> list[str]:
+    """One object per source, compiled in parallel and kept under build/obj keyed by the hash
+    of (source, headers, flags): a change to one kernel file recompiles that file only."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    obj_dir = os.path.join(ROOT, "build", "obj" + ("_" + _TAG if _TAG else ""))
+    os.makedirs(obj_dir, exist_ok=True)
+    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"] + EXTRA_FLAGS
+    jobs = []
+    for src in sources:
+        key = _fingerprint([src], _included_headers(src))[:20]
+        base = os.path.splitext(os.path.basename(src))[0]
+        obj = os.path.join(obj_dir, "%s.%s.o" % (base, key))
+        jobs.append((src, base, obj))
+
+    def one(job):
+        src, base, obj = job
+        if os.path.exists(obj):
+            return None
+        for stale in os.listdir(obj_dir):
+            if stale.startswith(base + ".") and stale.endswith(".o"):
+                os.remove(os.path.join(obj_dir, stale))
+        tmp = "%s.%d.tmp" % (obj, os.getpid())
+        cmd = [hipcc(), *compile_flags, "-I", INCLUDE, "-I", CSRC, "-x", "hip", "-c", src, "-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+        if proc.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            return proc.stdout + proc.stderr
+        if verbose and proc.stderr:
+            sys.stderr.write(proc.stderr)
+        os.replace(tmp, obj)
+        return None
+
+    workers = max(1, min(len(jobs), os.cpu_count() or 1, 8))
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        errors = [e for e in pool.map(one, jobs) if e]
+    if errors:
+        sys.stderr.write("\n".join(errors))
+        raise RuntimeError("hipcc failed building " + LIB_NAME)
+    return [obj for _, _, obj in jobs]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -100,9 +186,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and current():  # somebody else built it while we waited
             return LIB_PATH
+        if force:
+            import shutil as _sh
+
+            _sh.rmtree(os.path.join(ROOT, "build", "obj" + ("_" + _TAG if _TAG else "")),
+                       ignore_errors=True)
+        objects = _compile_objects(sources, verbose)
         tmp = "%s.%d.tmp" % (LIB_PATH, os.getpid())
-        cmd = [hipcc(), *HIPCC_FLAGS, *EXTRA_FLAGS, "-I", INCLUDE, "-I", CSRC, "-x", "hip",
-               *sources, "-o", tmp]
+        cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", *objects, "-o", tmp]
         if verbose:
             print(" ".join(cmd))
         proc = subprocess.run(cmd, capture_output=True, text=True)
@@ -110,9 +201,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             sys.stderr.write(proc.stdout + proc.stderr)
             if os.path.exists(tmp):
                 os.remove(tmp)
-            raise RuntimeError("hipcc failed building " + LIB_NAME)
-        if verbose and proc.stderr:
-            sys.stderr.write(proc.stderr)
+            raise RuntimeError("hipcc failed linking " + LIB_NAME)
         os.replace(tmp, LIB_PATH)
         with open(STAMP_PATH, "w") as f:
             f.write(fp)

@@ -498,6 +498,39 @@ void shuffled_orders(const SaHostLayout &L, uint64_t seed, uint32_t first, uint3
   *cap_out = cap;
 }
 
+int build_row_quads(const SaHostLayout &L, RowQuads *out) {
+  const uint64_t K = L.num_spins;
+  RowQuads &R = *out;
+  R = RowQuads();
+  R.quad_ptr.assign(K + 1, 0);
+  uint64_t quads = 0;
+  for (uint64_t i = 0; i < K; ++i) {
+    const uint64_t q = static_cast<uint64_t>(L.a_ptr[i + 1] - L.a_ptr[i] + 3) / 4;
+    R.max_quads = std::max<uint32_t>(R.max_quads, static_cast<uint32_t>(q));
+    quads += q;
+    if (quads >= (1ull << 30)) {
+      return set_error(ASP_ERR_TOO_LARGE, "%llu row quads exceed the 32-bit quad index",
+                       (unsigned long long)quads);
+    }
+    R.quad_ptr[i + 1] = static_cast<uint32_t>(quads);
+  }
+  R.col.resize(quads * 4);
+  R.val.resize(quads * 4);
+  parallel_ranges(K, host_threads(K), [&](uint64_t begin, uint64_t end, unsigned) {
+    for (uint64_t i = begin; i < end; ++i) {
+      const int64_t row = L.a_ptr[i], deg = L.a_ptr[i + 1] - row;
+      const uint64_t first = static_cast<uint64_t>(R.quad_ptr[i]) * 4;
+      const uint64_t padded = static_cast<uint64_t>(R.quad_ptr[i + 1] - R.quad_ptr[i]) * 4;
+      for (uint64_t k = 0; k < padded; ++k) {
+        const bool real = static_cast<int64_t>(k) < deg;
+        R.col[first + k] = real ? static_cast<uint32_t>(L.a_col[row + k]) : static_cast<uint32_t>(i);
+        R.val[first + k] = real ? L.a_val[row + k] : 0.0;
+      }
+    }
+  });
+  return ASP_OK;
+}
+
 }  // namespace asp
 
 extern "C" int asp_sa_shuffled_order_host(uint64_t num_spins, int64_t const *indptr,

@@ -63,6 +63,18 @@ void shuffled_orders(const SaHostLayout &layout, uint64_t seed, uint32_t first, 
                      uint32_t *order, std::vector<uint32_t> *level_start, uint32_t *cap,
                      uint32_t *num_levels);
 
+// Rows of A over ORIGINAL indices padded to whole quads, for the shuffled sweep's order kernel
+// (csrc/sa_shuffled.hip): row i is quads quad_ptr[i] .. quad_ptr[i + 1], entry k of the row is
+// col[(quad_ptr[i] + k / 4) * 4 + k % 4] / val[same]; padding entries carry the row's own index
+// and +0.0 (A has no diagonal, so "column == row" identifies padding).
+struct RowQuads {
+  std::vector<uint32_t> quad_ptr;  // num_spins + 1
+  std::vector<uint32_t> col;       // quads * 4
+  std::vector<double> val;         // quads * 4
+  uint32_t max_quads = 0;          // longest row
+};
+int build_row_quads(const SaHostLayout &layout, RowQuads *out);
+
 // Greedy sign assignment before relaxation (specification DESIGN.md §4.8): packed
 // configuration (bit = +1), ceil(K/64) words.
 int greedy_tree_signs(const SaHostLayout &layout, uint64_t *x);

@@ -1,0 +1,962 @@
+// Shuffled sweep "ASP-SA-1S" on gfx950: Metropolis annealing with a FRESH
+// RANDOM VISITING ORDER EVERY SWEEP — the order the reference's annealer uses
+// (ising_glass_annealer behind annealing_sign_problem/common.py:242-248 and
+// experiments/full_hilbert_space.py:212-218; DESIGN.md §6.1: its published success
+// probabilities are reproduced by this order and by no fixed one).
+//
+// Sweep t visits the spins in ascending (priority, index), priority_t(i) = word 0 of
+// Philox4x32-10(counter (i, t, 0xFFFFFFFE, 0), key seed); the same order for every chain.  A
+// sequential sweep in that order equals visiting the LEVELS of the priority graph one after
+// another: level(i) = 1 + max level(j) over the neighbours j that come before i.  Spins of a
+// level are pairwise non-adjacent, so a level is updated in parallel, and any order inside a
+// level gives the same bits.
+//
+// Mapping to the machine — two kernels in a pipeline, a chunk of sweeps at a time:
+//   * k_shuffled_orders (one workgroup per SWEEP): priorities, then the levels by a topological
+//     peel (every spin counts its earlier neighbours; spins at zero form level 0; a finished
+//     level decrements the counters of its later neighbours, those reaching zero form the next
+//     level — 2 nnz edge visits per sweep, not levels x nnz), a counting sort of every level by
+//     row length, and the sweep's couplings written as a LEVEL-MAJOR SLICED ELL in exactly the
+//     quad-interleaved layout the colour-ordered kernel streams (csrc/sa_plan.cpp): a block of
+//     64 same-level spins, width = its longest row, columns = LDS addresses of the neighbours.
+//     The order depends on (seed, t) only, so this is done ONCE per sweep for all chains and
+//     all workgroups of the call;
+//   * k_sa_sweep_shuffled (one workgroup per group of M chains): spins in LDS in ORIGINAL
+//     order (a word per spin, byte m = chain m, for M <= 4 — the one-instruction SDWA sign — or a
+//     byte per spin, bit m = chain m, for M = 8); a wavefront per block of the current level,
+//     lane = spin, three coalesced 16-byte loads per four couplings shared by the M chains, the
+//     proposal arithmetic, random words and exact integer energy bookkeeping of ASP-SA-1
+//     (csrc/sa_sweep.hip), one workgroup barrier per level.
+//   The order kernel of chunk c + 1 runs on a second stream beside the sweep kernel of chunk c;
+//   chain state waits in HBM between chunks.  Integer + f64 work bound by per-level latency
+//   and VALU issue: no MFMA.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "asp_common.hpp"
+#include "sa_device.hpp"
+#include "sa_internal.hpp"
+#include "sa_plan.hpp"
+
+namespace {
+
+using asp::DeviceBuffer;
+using asp::kDummySpin;
+using namespace asp::dev;
+
+constexpr uint32_t kPriorityCounter = 0xFFFFFFFEu;  // counter word 2 of the priority draw
+constexpr uint32_t kOrderThreads = 1024;            // threads of an order workgroup (large K)
+constexpr uint32_t kClassCap = 63;                  // rows of >= 63 quads share the last class
+
+// status words shared by the kernels of a call (device memory, zeroed per attempt)
+enum : uint32_t { kStatBad = 0, kStatLevels = 1, kStatBlocks = 2, kStatQuads = 3, kStatWords = 4 };
+
+// ---------------------------------------------------------------------------
+// Order kernel
+// ---------------------------------------------------------------------------
+
+struct OrderArgs {
+  // static: rows of A padded to quads (sa_plan.hpp RowQuads)
+  const uint32_t *rq_ptr;  // [K + 1]
+  const uint4 *rq_col;     // [quads]
+  const double2 *rq_val;   // [quads][2]
+  uint64_t seed;
+  uint32_t num_spins, first_sweep, count;
+  uint32_t level_cap, block_cap, quad_cap;  // capacities per sweep of the outputs below
+  uint32_t quad_stride;                     // quads between the ELLs of consecutive sweeps (> quad_cap)
+  uint32_t lanes_per_row;                   // power of two <= 64: lanes sharing a row in the graph passes
+  uint32_t col_shift;                       // columns are written as (neighbour << col_shift): LDS addresses
+  // scratch, [count][K] each
+  uint32_t *prio, *indeg, *order;
+  // outputs, per sweep of the chunk
+  uint32_t *level_block;  // [count][level_cap + 1] first block of level l; entry [levels] = blocks
+  uint32_t *num_levels;   // [count]
+  uint2 *block_meta;      // [count][block_cap] {first quad relative to the sweep's ELL, quads}
+  uint32_t *spin_of_pos;  // [count][block_cap * 64], kDummySpin = padding lane
+  uint4 *ell_col;         // [count][quad_cap][64]
+  double2 *ell_val;       // [count][quad_cap][2][64]
+  uint32_t *status;
+};
+
+// Exclusive prefix sum of a[0..n) in LDS, in place; returns the total.  All threads call it;
+// `carry` is one LDS word of scratch, `wave_tot` 16.
+__device__ uint32_t block_exclusive_scan(uint32_t *a, uint32_t n, uint32_t *wave_tot, uint32_t *carry) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, waves = blockDim.x >> 6;
+  if (tid == 0) *carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n; base += blockDim.x) {
+    const uint32_t i = base + tid;
+    const uint32_t v = i < n ? a[i] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int step = 1; step < 64; step <<= 1) {
+      const uint32_t o = __shfl_up(inc, step, 64);
+      if (lane >= static_cast<uint32_t>(step)) inc += o;
+    }
+    if (lane == 63u) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t before = *carry;
+    for (uint32_t w = 0; w < wave; ++w) before += wave_tot[w];
+    if (i < n) a[i] = before + inc - v;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t total = *carry;
+      for (uint32_t w = 0; w < waves; ++w) total += wave_tot[w];
+      *carry = total;
+    }
+    __syncthreads();
+  }
+  return *carry;
+}
+
+__device__ __forceinline__ bool comes_before(uint32_t pa, uint32_t a, uint32_t pb, uint32_t b) {
+  return pa < pb || (pa == pb && a < b);
+}
+
+__global__ __launch_bounds__(kOrderThreads) void k_shuffled_orders(OrderArgs a) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const uint32_t K = a.num_spins;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), waves = blockDim.x >> 6;
+  const uint32_t s = blockIdx.x;
+  const uint32_t t = a.first_sweep + s;
+  // ctl: [0] tail of the order, [1..2] level ends (ping-pong), [3] carry of the scans
+  uint32_t *ctl = reinterpret_cast<uint32_t *>(lds);
+  uint32_t *wave_tot = ctl + 8;                         // 16
+  uint32_t *level_start = wave_tot + 16;                // level_cap + 2
+  uint32_t *level_block = level_start + a.level_cap + 2;  // level_cap + 2
+  uint32_t *block_quads = level_block + a.level_cap + 2;  // block_cap + 1
+  uint32_t *block_first = block_quads + a.block_cap + 1;  // block_cap + 1
+  uint32_t *hist = block_first + a.block_cap + 1;         // waves * 64
+  uint32_t *cursor = hist + waves * 64u;                  // waves * 64
+  uint32_t *prio = a.prio + static_cast<uint64_t>(s) * K;
+  uint32_t *indeg = a.indeg + static_cast<uint64_t>(s) * K;
+  uint32_t *order = a.order + static_cast<uint64_t>(s) * K;
+  const uint32_t key0 = static_cast<uint32_t>(a.seed), key1 = static_cast<uint32_t>(a.seed >> 32);
+
+  // ---- 1. priorities ----
+  for (uint32_t i = tid; i < K; i += blockDim.x) {
+    prio[i] = philox4x32_10(i, t, kPriorityCounter, 0u, key0, key1).w[0];
+  }
+  if (tid == 0) ctl[0] = 0;
+  __syncthreads();
+
+  // ---- 2. number of earlier neighbours; spins without any open level 0 ----
+  // G lanes share a row: one quad of four neighbours per lane and trip
+  const uint32_t G = a.lanes_per_row;
+  const uint32_t sub = tid & (G - 1u), gid = tid / G, groups = blockDim.x / G;
+  for (uint32_t i = gid; i < K; i += groups) {
+    const uint32_t pi = prio[i];
+    const uint32_t q1 = a.rq_ptr[i + 1];
+    uint32_t count = 0;
+    for (uint32_t q = a.rq_ptr[i] + sub; q < q1; q += G) {
+      const uint4 c = a.rq_col[q];
+      const uint32_t cs[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (cs[j] != i && comes_before(prio[cs[j]], cs[j], pi, i)) ++count;
+      }
+    }
+    for (uint32_t step = G >> 1; step > 0; step >>= 1) count += __shfl_xor(count, step, 64);
+    if (sub == 0) {
+      // (relaxed device-scope store: the decrements below are device-scope atomics)
+      __hip_atomic_store(indeg + i, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (count == 0) order[atomicAdd(&ctl[0], 1u)] = i;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    ctl[1] = ctl[0];
+    level_start[0] = 0;
+    level_start[1] = ctl[0];
+  }
+  __syncthreads();
+
+  // ---- 3. peel the levels ----
+  uint32_t begin = 0, end = ctl[1], levels = 0;
+  while (begin < end) {
+    ++levels;
+    for (uint32_t m = begin + gid; m < end; m += groups) {
+      const uint32_t i = order[m];
+      const uint32_t pi = prio[i];
+      const uint32_t q1 = a.rq_ptr[i + 1];
+      for (uint32_t q = a.rq_ptr[i] + sub; q < q1; q += G) {
+        const uint4 c = a.rq_col[q];
+        const uint32_t cs[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t n = cs[j];
+          if (n != i && comes_before(pi, i, prio[n], n)) {
+            if (atomicSub(indeg + n, 1u) == 1u) order[atomicAdd(&ctl[0], 1u)] = n;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      ctl[1 + (levels & 1u)] = ctl[0];
+      if (levels + 1u <= a.level_cap + 1u) level_start[levels + 1u] = ctl[0];
+    }
+    __syncthreads();
+    begin = end;
+    end = ctl[1 + (levels & 1u)];
+  }
+  // (begin == K here: the priority order is a total order, so the peel reaches every spin)
+  const uint32_t L = levels;
+  bool bad = L > a.level_cap;
+
+  // ---- 4. blocks of the levels ----
+  if (!bad) {
+    for (uint32_t l = tid; l < L; l += blockDim.x) {
+      level_block[l] = (level_start[l + 1] - level_start[l] + 63u) >> 6;
+    }
+    __syncthreads();
+  }
+  uint32_t B = 0;
+  if (!bad) {
+    B = block_exclusive_scan(level_block, L, wave_tot, ctl + 3);
+    if (tid == 0) level_block[L] = B;
+    __syncthreads();
+    bad = B > a.block_cap;
+  }
+  if (bad) {
+    if (tid == 0) {
+      atomicMax(a.status + kStatLevels, L);
+      atomicMax(a.status + kStatBlocks, B);
+      atomicOr(a.status + kStatBad, 1u);
+      a.num_levels[s] = 0;
+    }
+    return;
+  }
+
+  // ---- 5. every level sorted by descending row length (counting sort, a wavefront per level) ----
+  uint32_t *sop = a.spin_of_pos + static_cast<uint64_t>(s) * a.block_cap * 64u;
+  for (uint32_t base = 0; base < L; base += waves) {
+    const uint32_t l = base + wave;
+    uint32_t lo = 0, n = 0, pos0 = 0;
+    if (l < L) {
+      lo = level_start[l];
+      n = level_start[l + 1] - lo;
+      pos0 = level_block[l] * 64u;
+    }
+    hist[wave * 64u + lane] = 0;
+    __syncthreads();
+    for (uint32_t m = lane; m < n; m += 64u) {
+      const uint32_t i = order[lo + m];
+      const uint32_t cls = min(a.rq_ptr[i + 1] - a.rq_ptr[i], kClassCap);
+      atomicAdd(&hist[wave * 64u + cls], 1u);
+    }
+    __syncthreads();
+    {
+      const uint32_t own = hist[wave * 64u + lane];
+      uint32_t suffix = own;  // members of this class and of the longer ones
+#pragma unroll
+      for (int step = 1; step < 64; step <<= 1) {
+        const uint32_t o = __shfl_down(suffix, step, 64);
+        if (lane + static_cast<uint32_t>(step) < 64u) suffix += o;
+      }
+      cursor[wave * 64u + lane] = suffix - own;
+    }
+    __syncthreads();
+    for (uint32_t m = lane; m < n; m += 64u) {
+      const uint32_t i = order[lo + m];
+      const uint32_t cls = min(a.rq_ptr[i + 1] - a.rq_ptr[i], kClassCap);
+      sop[pos0 + atomicAdd(&cursor[wave * 64u + cls], 1u)] = i;
+    }
+    for (uint32_t m = n + lane; m < ((n + 63u) & ~63u); m += 64u) sop[pos0 + m] = kDummySpin;
+    __syncthreads();
+  }
+
+  // ---- 6. block widths and their prefix sum ----
+  for (uint32_t b = wave; b < B; b += waves) {
+    const uint32_t i = sop[b * 64u + lane];
+    uint32_t w = i == kDummySpin ? 0u : a.rq_ptr[i + 1] - a.rq_ptr[i];
+#pragma unroll
+    for (int step = 1; step < 64; step <<= 1) w = max(w, static_cast<uint32_t>(__shfl_xor(w, step, 64)));
+    if (lane == 0) {
+      block_quads[b] = w;
+      block_first[b] = w;
+    }
+  }
+  __syncthreads();
+  const uint32_t Q = block_exclusive_scan(block_first, B, wave_tot, ctl + 3);
+  if (Q > a.quad_cap) {
+    if (tid == 0) {
+      atomicMax(a.status + kStatQuads, Q);
+      atomicOr(a.status + kStatBad, 1u);
+      a.num_levels[s] = 0;
+    }
+    return;
+  }
+
+  // ---- 7. the sweep's level-major sliced ELL ----
+  uint4 *ell_col = a.ell_col + static_cast<uint64_t>(s) * a.quad_stride * 64u;
+  double2 *ell_val = a.ell_val + static_cast<uint64_t>(s) * a.quad_stride * 128u;
+  for (uint32_t b = wave; b < B; b += waves) {
+    const uint32_t i = sop[b * 64u + lane];
+    const bool real = i != kDummySpin;
+    const uint32_t row = real ? a.rq_ptr[i] : 0u;
+    const uint32_t mine = real ? a.rq_ptr[i + 1] - row : 0u;
+    const uint32_t own = real ? i << a.col_shift : 0u;  // padding reads the lane's own spin (x +0.0)
+    const uint32_t quads = block_quads[b];
+    const uint64_t first = block_first[b];
+    for (uint32_t q = 0; q < quads; ++q) {
+      uint4 c = make_uint4(own, own, own, own);
+      double2 v01 = make_double2(0.0, 0.0), v23 = make_double2(0.0, 0.0);
+      if (q < mine) {
+        c = a.rq_col[row + q];
+        c.x <<= a.col_shift;
+        c.y <<= a.col_shift;
+        c.z <<= a.col_shift;
+        c.w <<= a.col_shift;
+        v01 = a.rq_val[static_cast<uint64_t>(row + q) * 2u];
+        v23 = a.rq_val[static_cast<uint64_t>(row + q) * 2u + 1u];
+      }
+      ell_col[(first + q) * 64u + lane] = c;
+      ell_val[(first + q) * 128u + lane] = v01;
+      ell_val[(first + q) * 128u + 64u + lane] = v23;
+    }
+  }
+  // padding quads of a row carry the row's own column with +0.0; in the static rows the own
+  // column is the spin INDEX, so it is shifted like every other column above
+
+  // ---- 8. the sweep's tables ----
+  uint32_t *out_lb = a.level_block + static_cast<uint64_t>(s) * (a.level_cap + 1u);
+  for (uint32_t l = tid; l <= L; l += blockDim.x) out_lb[l] = level_block[l];
+  uint2 *out_meta = a.block_meta + static_cast<uint64_t>(s) * a.block_cap;
+  for (uint32_t b = tid; b < B; b += blockDim.x) out_meta[b] = make_uint2(block_first[b], block_quads[b]);
+  if (tid == 0) {
+    a.num_levels[s] = L;
+    atomicMax(a.status + kStatLevels, L);
+    atomicMax(a.status + kStatBlocks, B);
+    atomicMax(a.status + kStatQuads, Q);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Sweep kernel
+// ---------------------------------------------------------------------------
+
+struct ShuffledArgs {
+  // the chunk's visiting orders (k_shuffled_orders)
+  const uint32_t *level_block;
+  const uint32_t *num_levels;
+  const uint2 *block_meta;
+  const uint32_t *spin_of_pos;
+  const uint32_t *ell_col;
+  const double *ell_val;
+  const uint32_t *status;
+  const double *field;  // [K] original order
+  const double *betas;  // all sweeps of the call
+  const uint64_t *x0;   // packed original-order start configuration or nullptr
+  uint8_t *state;       // [groups][K] bit m = chain m of the group is -1 (between chunks)
+  uint64_t *best;       // [groups * M][words] best configurations, packed original order (bit = +1)
+  long long *e_cur, *e_best;     // [groups * M] tracked energies (fixed point)
+  unsigned long long *accepted;  // [groups * M]
+  uint64_t seed;
+  double scale;
+  uint32_t num_spins, words, level_cap, block_cap, quad_stride;
+  uint32_t first_sweep, chunk_sweeps, replica_first, initialise;
+};
+
+// Negative-spin mask of the M chains (bit m) <-> the LDS representation of one spin.
+template <int LAYOUT>
+__device__ __forceinline__ uint32_t to_lds(uint32_t mask) {
+  return LAYOUT == kWide ? spread_mask(mask) : mask;
+}
+template <int LAYOUT>
+__device__ __forceinline__ uint32_t from_lds(uint32_t v) {
+  if constexpr (LAYOUT == kWide) {
+    return ((v >> 7) & 1u) | ((v >> 14) & 2u) | ((v >> 21) & 4u) | ((v >> 28) & 8u);
+  } else {
+    return v;
+  }
+}
+
+template <int M, int LAYOUT>
+__device__ __forceinline__ void snapshot_original(const uint8_t *spins, const ShuffledArgs &a,
+                                                  uint32_t group, uint32_t mask) {
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t w = threadIdx.x >> 6; w < a.words; w += blockDim.x >> 6) {
+    const uint32_t i = w * 64u + lane;
+    uint32_t neg = (1u << M) - 1u;
+    if (i < a.num_spins) {
+      neg = from_lds<LAYOUT>(LAYOUT == kWide ? reinterpret_cast<const uint32_t *>(spins)[i]
+                                             : static_cast<uint32_t>(spins[i]));
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      if (!((mask >> m) & 1u)) continue;  // workgroup-uniform
+      const uint64_t word = __ballot(i < a.num_spins && !((neg >> m) & 1u));
+      if (lane == 0) a.best[(static_cast<uint64_t>(group) * M + m) * a.words + w] = word;
+    }
+  }
+}
+
+template <int M, int LAYOUT>
+__global__ __launch_bounds__(1024) void k_sa_sweep_shuffled(ShuffledArgs a) {
+  constexpr bool WIDE = LAYOUT == kWide;
+  static_assert(LAYOUT == kWide || LAYOUT == kBytes, "spins are LDS words or LDS bytes");
+  static_assert(!WIDE || M <= 4, "the wide layout holds up to four chains");
+  extern __shared__ __align__(16) uint8_t lds[];
+  if (a.status[kStatBad] != 0u) return;  // an order kernel ran out of room: the host repeats the call
+#if ASP_ABS_LDS
+  if (reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t *)lds) != 0) {
+    __builtin_trap();
+  }
+#endif
+  const uint32_t K = a.num_spins;
+  uint8_t *spins = lds;  // original order: K words (byte m = 0x80 * chain m is -1) or K bytes
+  uint32_t *wide = reinterpret_cast<uint32_t *>(lds);
+  const uint32_t P = ((WIDE ? K * 4u : K) + 15u) & ~15u;
+  long long *delta = reinterpret_cast<long long *>(lds + P);  // [8] energy change of the running sweep
+  long long *book = delta + 8;  // [m] current tracked energy, [8 + m] best, [16 + m] accepted flips
+  uint32_t *improved_flag = reinterpret_cast<uint32_t *>(book + 24);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), waves = blockDim.x >> 6;
+  const uint32_t group = blockIdx.x;
+  const uint32_t r0 = a.replica_first + group * M;
+  const uint32_t key0 = static_cast<uint32_t>(a.seed), key1 = static_cast<uint32_t>(a.seed >> 32);
+  uint8_t *state = a.state + static_cast<uint64_t>(group) * K;
+
+  // ---- chain state: fresh, or where the previous chunk left it ----
+  for (uint32_t i = tid; i < K; i += blockDim.x) {
+    uint32_t mask;
+    if (!a.initialise) {
+      mask = state[i];
+    } else if (a.x0 != nullptr) {
+      mask = ((a.x0[i >> 6] >> (i & 63u)) & 1ull) ? 0u : ((1u << M) - 1u);
+    } else {
+      mask = 0;
+      Philox4 rnd{};
+      uint32_t have = 0xFFFFFFFFu;
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const uint32_t r = r0 + m;
+        if (m == 0 || (r >> 2) != have) {
+          have = r >> 2;
+          rnd = philox4x32_10(i, 0xFFFFFFFFu, have, 0u, key0, key1);
+        }
+        mask |= ((pick_word(rnd, r & 3u) & 1u) ^ 1u) << m;  // bit 0 of the word: 1 -> s = +1
+      }
+    }
+    if constexpr (WIDE) {
+      wide[i] = spread_mask(mask);
+    } else {
+      spins[i] = static_cast<uint8_t>(mask);
+    }
+  }
+  if (tid < 32) {
+    long long v = 0;
+    if (!a.initialise && tid >= 8) {
+      const uint32_t m = tid & 7u;
+      if (m < M) {
+        const uint64_t at = static_cast<uint64_t>(group) * M + m;
+        v = tid < 16 ? a.e_cur[at] : (tid < 24 ? a.e_best[at] : static_cast<long long>(a.accepted[at]));
+      }
+    }
+    delta[tid] = v;  // delta[8] | book[24]
+  }
+  if (tid == 0) *improved_flag = 0;
+  __syncthreads();
+  if (a.initialise) {
+    snapshot_original<M, LAYOUT>(spins, a, group, (1u << M) - 1u);
+    __syncthreads();
+  }
+
+  uint32_t one_hi[4] = {0x3FF00000u, 0x3FF00000u, 0x3FF00000u, 0x3FF00000u};
+  for (uint32_t tt = 0; tt < a.chunk_sweeps; ++tt) {
+    const uint32_t t = a.first_sweep + tt;
+    const double beta = a.betas[t];
+    const uint32_t *level_block = a.level_block + static_cast<uint64_t>(tt) * (a.level_cap + 1u);
+    const uint2 *meta = a.block_meta + static_cast<uint64_t>(tt) * a.block_cap;
+    const uint32_t *sop = a.spin_of_pos + static_cast<uint64_t>(tt) * a.block_cap * 64u;
+    const uint4 *ell_col = reinterpret_cast<const uint4 *>(a.ell_col) + static_cast<uint64_t>(tt) * a.quad_stride * 64u;
+    const double2 *ell_val = reinterpret_cast<const double2 *>(a.ell_val) + static_cast<uint64_t>(tt) * a.quad_stride * 128u;
+    const uint32_t levels = a.num_levels[tt];
+    long long q_acc[M];
+    uint32_t n_acc[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      q_acc[m] = 0;
+      n_acc[m] = 0;
+    }
+    uint32_t b_end = level_block[0];
+    for (uint32_t l = 0; l < levels; ++l) {
+      const uint32_t b_begin = b_end;
+      b_end = level_block[l + 1];
+      for (uint32_t b = b_begin + wave; b < b_end; b += waves) {
+        const uint2 info = meta[b];
+        const uint32_t quads = __builtin_amdgcn_readfirstlane(info.y);
+        const uint64_t first_quad = __builtin_amdgcn_readfirstlane(info.x);
+        const uint4 *cptr = ell_col + first_quad * 64u + lane;
+        const double2 *vptr = ell_val + first_quad * 128u + lane;
+        const uint32_t spin = sop[b * 64u + lane];
+        const bool valid = spin != kDummySpin;
+        const uint32_t me = valid ? spin : 0u;
+        const double h = a.field[me];
+        double acc[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[m] = 0.0;
+        // k-loop of csrc/sa_sweep.hip: the next quad's three 16-byte loads in flight while the
+        // current one is gathered from LDS and accumulated, in the order k = 0, 1, 2, ... of
+        // the row (= ascending column: the oracle's order); the last prefetch reads one quad past
+        // the block (the next block, or the slack behind the sweep's last one) and is never used
+        Quad qa, qb;
+        load_quad(qa, cptr, vptr, 0);
+        uint32_t i = 0;
+        for (; i + 2 <= quads; i += 2) {
+          load_quad(qb, cptr, vptr, i + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          accumulate_quad<M, LAYOUT>(qa, spins, acc, one_hi);
+          __builtin_amdgcn_sched_barrier(0);
+          load_quad(qa, cptr, vptr, i + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          accumulate_quad<M, LAYOUT>(qb, spins, acc, one_hi);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (i < quads) accumulate_quad<M, LAYOUT>(qa, spins, acc, one_hi);
+
+        const uint32_t own = WIDE ? wide[me] : static_cast<uint32_t>(spins[me]);
+        bool need = false;  // some proposal of this lane needs a random number
+        double de[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          const double g = __dadd_rn(acc[m], h);
+          const bool negative = (own >> (WIDE ? 8 * m + 7 : m)) & 1u;  // s = -1
+          de[m] = __dmul_rn(negative ? 2.0 : -2.0, g);
+          // dE <= 0 is accepted and beta * dE >= 23 rejected whatever the draw
+          need = need || (valid && !(de[m] <= 0.0) && !(__dmul_rn(beta, de[m]) >= 23.0));
+        }
+        uint32_t flip = 0;
+        if (__ballot(need) != 0ull) {
+          Philox4 rnd{};
+          uint32_t have = 0xFFFFFFFFu;
+#pragma unroll
+          for (int m = 0; m < M; ++m) {
+            const uint32_t r = r0 + m;
+            if (m == 0 || (r >> 2) != have) {
+              have = r >> 2;
+              rnd = philox4x32_10(spin, t, have, 0u, key0, key1);
+            }
+            const bool accept = valid && (de[m] <= 0.0 || metropolis_accept_word(pick_word(rnd, r & 3u),
+                                                                                 __dmul_rn(beta, de[m])));
+            flip |= (accept ? 1u : 0u) << m;
+          }
+        } else {
+#pragma unroll
+          for (int m = 0; m < M; ++m) flip |= ((valid && de[m] <= 0.0) ? 1u : 0u) << m;
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          if ((flip >> m) & 1u) {
+            // rint(dE * 2^S): |dE * 2^S| < 2^51 by the plan's S
+            q_acc[m] += __double_as_longlong(__dadd_rn(__dmul_rn(de[m], a.scale), 0x1.8p52)) -
+                        0x4338000000000000ll;
+            n_acc[m] += 1;
+          }
+        }
+        if (flip) {  // no neighbour of this spin is in the level: nobody reads it before the barrier
+          if constexpr (WIDE) {
+            wide[me] = own ^ spread_mask(flip);
+          } else {
+            spins[me] = static_cast<uint8_t>(own ^ flip);
+          }
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- exact (integer) reduction of the sweep's energy change ----
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const long long v = wave_sum_i64(q_acc[m]);
+      const long long n = wave_sum_i64(static_cast<long long>(n_acc[m]));
+      if (lane == 0 && n != 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&delta[m]), static_cast<unsigned long long>(v));
+        atomicAdd(reinterpret_cast<unsigned long long *>(&book[16 + m]), static_cast<unsigned long long>(n));
+      }
+    }
+    __syncthreads();
+    if (tid < M) {
+      const long long e = book[tid] + delta[tid];
+      book[tid] = e;
+      delta[tid] = 0;
+      if (e < book[8 + tid]) {
+        book[8 + tid] = e;
+        atomicOr(improved_flag, 1u << tid);
+      }
+    }
+    __syncthreads();
+    const uint32_t improved = *improved_flag;
+    if (improved) snapshot_original<M, LAYOUT>(spins, a, group, improved);
+    __syncthreads();
+    if (tid == 0) *improved_flag = 0;  // next write to it is two barriers away
+  }
+
+  for (uint32_t i = tid; i < K; i += blockDim.x) {
+    state[i] = static_cast<uint8_t>(from_lds<LAYOUT>(WIDE ? wide[i] : static_cast<uint32_t>(spins[i])));
+  }
+  if (tid < M) {
+    const uint64_t at = static_cast<uint64_t>(group) * M + tid;
+    a.e_cur[at] = book[tid];
+    a.e_best[at] = book[8 + tid];
+    a.accepted[at] = static_cast<unsigned long long>(book[16 + tid]);
+  }
+}
+
+using ShuffledKernel = void (*)(ShuffledArgs);
+
+ShuffledKernel shuffled_kernel_for(int m, bool wide) {
+  if (wide) {
+    switch (m) {
+      case 1: return k_sa_sweep_shuffled<1, kWide>;
+      case 2: return k_sa_sweep_shuffled<2, kWide>;
+      case 4: return k_sa_sweep_shuffled<4, kWide>;
+      default: return nullptr;
+    }
+  }
+  switch (m) {
+    case 1: return k_sa_sweep_shuffled<1, kBytes>;
+    case 2: return k_sa_sweep_shuffled<2, kBytes>;
+    case 4: return k_sa_sweep_shuffled<4, kBytes>;
+    case 8: return k_sa_sweep_shuffled<8, kBytes>;
+    default: return nullptr;
+  }
+}
+
+size_t sweep_lds_bytes(uint64_t K, bool wide) {
+  return (((wide ? K * 4 : K) + 15) & ~size_t{15}) + 32 * sizeof(long long) + 16;
+}
+
+size_t order_lds_bytes(uint32_t level_cap, uint32_t block_cap, uint32_t waves) {
+  return sizeof(uint32_t) * (8 + 16 + 2 * (static_cast<size_t>(level_cap) + 2) +
+                             2 * (static_cast<size_t>(block_cap) + 1) + 2 * static_cast<size_t>(waves) * 64);
+}
+
+uint32_t next_pow2(uint32_t v) {
+  uint32_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+// Static device data of the shuffled sweep: uploaded once per plan.
+int ensure_static(asp_sa_plan *p) {
+  if (p->rq_ptr.ptr) return ASP_OK;
+  const asp::SaHostLayout &L = p->host;
+  asp::RowQuads rows;
+  ASP_TRY(asp::build_row_quads(L, &rows));
+  std::vector<double> field(L.num_spins);
+  for (uint64_t i = 0; i < L.num_spins; ++i) field[i] = L.field_pos[L.pos_of_spin[i]];
+  hipStream_t s = p->stream;
+  ASP_TRY(asp::upload_vector(p->rq_col, rows.col, s));
+  ASP_TRY(asp::upload_vector(p->rq_val, rows.val, s));
+  ASP_TRY(asp::upload_vector(p->field_dev, field, s));
+  ASP_TRY(asp::upload_vector(p->rq_ptr, rows.quad_ptr, s));
+  ASP_HIP_TRY(hipStreamSynchronize(s));  // the host vectors die with this scope
+  p->rq_quads = rows.quad_ptr.back();
+  p->rq_max_quads = rows.max_quads;
+  return ASP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int asp_sa_set_shuffled_launch(asp_sa_plan *p, int chains_per_group, int wavefronts) {
+  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  if (chains_per_group != 0 && !shuffled_kernel_for(chains_per_group, false)) {
+    return asp::set_error(ASP_ERR_INVALID, "chains_per_group must be 0, 1, 2, 4 or 8");
+  }
+  if (wavefronts < 0 || wavefronts > 16) return asp::set_error(ASP_ERR_INVALID, "wavefronts must be 0..16");
+  p->shuffled_m = chains_per_group;
+  p->shuffled_waves = wavefronts;
+  return ASP_OK;
+}
+
+int asp_sa_last_shuffled(asp_sa_plan const *p, uint32_t *levels, float *order_ms) {
+  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  if (levels) *levels = static_cast<uint32_t>(p->last_shuffled_levels);
+  if (order_ms) *order_ms = p->last_order_ms;
+  return ASP_OK;
+}
+
+int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_sweeps,
+                           uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0,
+                           uint64_t *out_x, double *out_e) {
+  asp_clear_error();
+  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  ASP_TRY(asp::bind_device());
+  if (repetitions == 0) return ASP_OK;
+  if (!out_x || !out_e || (num_sweeps && !betas)) return asp::set_error(ASP_ERR_INVALID, "null argument");
+  if (num_sweeps >= 0xFFFFFFFEu) return asp::set_error(ASP_ERR_INVALID, "num_sweeps too large");
+  if (static_cast<uint64_t>(replica_offset) + repetitions + 8 > 0xFFFFFFFFull) {
+    return asp::set_error(ASP_ERR_INVALID, "replica ids exceed 32 bits");
+  }
+  for (uint32_t t = 0; t < num_sweeps; ++t) {
+    if (!(betas[t] >= 0.0)) return asp::set_error(ASP_ERR_INVALID, "betas[%u] is not >= 0", t);
+  }
+  const asp::SaHostLayout &L = p->host;
+  const uint64_t K = L.num_spins;
+  const uint32_t words = static_cast<uint32_t>((K + 63) / 64);
+  p->last_sweep_ms = p->last_total_ms = p->last_order_ms = 0.0f;
+  if (K == 0) {
+    for (uint32_t r = 0; r < repetitions; ++r) out_e[r] = 0.0;
+    return ASP_OK;
+  }
+  if (sweep_lds_bytes(K, false) > p->max_lds) {
+    return asp::set_error(ASP_ERR_TOO_LARGE, "the shuffled sweep keeps a byte per spin in LDS: %llu "
+                                             "spins do not fit", (unsigned long long)K);
+  }
+  ASP_TRY(ensure_static(p));
+
+  // ---- launch geometry ----
+  // chains per workgroup: as many as still leave a workgroup per compute unit
+  int m = 1;
+  if (p->shuffled_m) {
+    m = p->shuffled_m;
+  } else {
+    for (int cand : {8, 4, 2}) {
+      if ((repetitions + cand - 1) / cand >= static_cast<uint32_t>(p->num_cus)) {
+        m = cand;
+        break;
+      }
+    }
+  }
+  const bool wide = m <= 4 && sweep_lds_bytes(K, true) <= p->max_lds;
+  const double mean_degree = std::max(1.0, static_cast<double>(L.a_col.size()) / static_cast<double>(K));
+  // levels of a sweep: the longest descending-priority path, about 2.5 x the mean degree on the
+  // clusters of this problem (measured: 15 at degree 8, 51 at degree 20); the last call's count
+  // when there is one
+  const double levels_guess = p->last_shuffled_levels > 0 ? p->last_shuffled_levels : 2.5 * mean_degree + 4.0;
+  uint32_t waves = static_cast<uint32_t>(p->shuffled_waves);
+  if (!waves) {
+    // a wavefront per block of an average level
+    waves = static_cast<uint32_t>(std::ceil(static_cast<double>(K) / levels_guess / 64.0));
+    waves = std::max(1u, std::min(16u, waves));
+  }
+  const uint32_t groups = (repetitions + m - 1) / m;
+  const uint64_t padded = static_cast<uint64_t>(groups) * m;
+  const size_t lds = sweep_lds_bytes(K, wide);
+  ShuffledKernel kernel = shuffled_kernel_for(m, wide);
+  if (lds > 64 * 1024) {
+    ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+  }
+
+  // ---- capacities of one sweep's order (grown and the call repeated if an order kernel says so) ----
+  uint32_t level_cap = static_cast<uint32_t>(std::min<double>(static_cast<double>(K), 2.0 * levels_guess + 32.0));
+  const uint32_t max_quads = p->rq_max_quads;
+  uint32_t quad_cap = 0;  // 0: derive from level_cap
+  const uint32_t order_threads = K >= 4096 ? kOrderThreads : (K >= 512 ? 256u : 64u);
+  const uint32_t lanes_per_row = std::min(64u, std::min(order_threads, next_pow2(std::max(
+      1u, static_cast<uint32_t>(std::ceil(mean_degree / 4.0))))));
+
+  hipStream_t s = p->stream;
+  asp::ScopedStream order_stream;
+  ASP_TRY(order_stream.acquire());
+  struct Events {
+    hipEvent_t ordered[2] = {nullptr, nullptr}, swept[2] = {nullptr, nullptr};
+    ~Events() {
+      for (hipEvent_t e : ordered) if (e) (void)hipEventDestroy(e);
+      for (hipEvent_t e : swept) if (e) (void)hipEventDestroy(e);
+    }
+  } ev;
+  for (int i = 0; i < 2; ++i) {
+    ASP_HIP_TRY(hipEventCreateWithFlags(&ev.ordered[i], hipEventDisableTiming));
+    ASP_HIP_TRY(hipEventCreateWithFlags(&ev.swept[i], hipEventDisableTiming));
+  }
+
+  DeviceBuffer<double> d_betas, d_partial, d_e;
+  DeviceBuffer<uint64_t> d_x0, d_best, d_perm;
+  DeviceBuffer<uint8_t> d_state;
+  DeviceBuffer<long long> d_ecur, d_ebest;
+  DeviceBuffer<unsigned long long> d_accepted;
+  DeviceBuffer<uint32_t> d_status, d_prio, d_indeg, d_order;
+  struct OrderSet {
+    DeviceBuffer<uint32_t> level_block, num_levels, spin_of_pos;
+    DeviceBuffer<uint2> block_meta;
+    DeviceBuffer<uint4> ell_col;
+    DeviceBuffer<double2> ell_val;
+  } sets[2];
+  asp::StreamFence fence_orders(order_stream.stream);  // (declared after the buffers: waits first)
+  asp::StreamFence fence(s);
+  ASP_TRY(d_betas.alloc(num_sweeps));
+  ASP_TRY(d_state.alloc(static_cast<uint64_t>(groups) * K));
+  ASP_TRY(d_best.alloc(padded * words));
+  ASP_TRY(d_ecur.alloc(padded));
+  ASP_TRY(d_ebest.alloc(padded));
+  ASP_TRY(d_accepted.alloc(padded));
+  ASP_TRY(d_perm.alloc(static_cast<uint64_t>(repetitions) * L.num_blocks));
+  ASP_TRY(d_partial.alloc(static_cast<uint64_t>(repetitions) * L.num_blocks));
+  ASP_TRY(d_e.alloc(repetitions));
+  ASP_TRY(d_status.alloc(kStatWords));
+  ASP_TRY(d_betas.upload(betas, num_sweeps, s));
+  if (x0) {
+    ASP_TRY(d_x0.alloc(words));
+    ASP_TRY(d_x0.upload(x0, words, s));
+  }
+  uint64_t budget = 3ull << 30;  // bytes of visiting orders per buffer set
+  if (const char *env = std::getenv("ASP_SHUFFLED_BYTES")) budget = std::strtoull(env, nullptr, 10);
+
+  uint32_t status[kStatWords] = {0, 0, 0, 0};
+  for (int attempt = 0;; ++attempt) {
+    const uint32_t block_cap = words + level_cap;
+    if (!quad_cap) {
+      // exact class sort (rows below 63 quads): a block is no wider than every row of the block
+      // before it in its level, so the blocks hold at most (sum of the row quads) / 64 + one
+      // widest block per level; otherwise every block may be as wide as the longest row
+      const uint64_t tight = (static_cast<uint64_t>(p->rq_quads) + 63) / 64 +
+                             static_cast<uint64_t>(level_cap) * max_quads;
+      const uint64_t loose = static_cast<uint64_t>(block_cap) * max_quads;
+      quad_cap = static_cast<uint32_t>(std::min<uint64_t>(max_quads < kClassCap ? tight : loose, 0x7FFFFFFFull));
+    }
+    const uint32_t quad_alloc = quad_cap + 2;  // slack: the sweep kernel's prefetch reads one quad too far
+    const uint64_t per_sweep = static_cast<uint64_t>(quad_alloc) * 64 * 48 + static_cast<uint64_t>(block_cap) * (256 + 8) +
+                               (level_cap + 1ull) * 4 + 12ull * K;
+    uint32_t chunk = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(256, budget / per_sweep)));
+    chunk = std::max(1u, std::min(chunk, (num_sweeps + 3) / 4));  // at least four chunks: the pipeline needs them
+    const size_t order_lds = order_lds_bytes(level_cap, block_cap, order_threads / 64);
+    if (order_lds > p->max_lds) {
+      return asp::set_error(ASP_ERR_TOO_LARGE, "%u levels x %u blocks do not fit the order kernel's LDS",
+                            level_cap, block_cap);
+    }
+    if (order_lds > 64 * 1024) {
+      ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shuffled_orders),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(order_lds)));
+    }
+    ASP_TRY(d_prio.ensure(static_cast<uint64_t>(chunk) * K));
+    ASP_TRY(d_indeg.ensure(static_cast<uint64_t>(chunk) * K));
+    ASP_TRY(d_order.ensure(static_cast<uint64_t>(chunk) * K));
+    const int nsets = num_sweeps > chunk ? 2 : 1;
+    for (int i = 0; i < nsets; ++i) {
+      OrderSet &o = sets[i];
+      ASP_TRY(o.level_block.ensure(static_cast<uint64_t>(chunk) * (level_cap + 1)));
+      ASP_TRY(o.num_levels.ensure(chunk));
+      ASP_TRY(o.block_meta.ensure(static_cast<uint64_t>(chunk) * block_cap));
+      ASP_TRY(o.spin_of_pos.ensure(static_cast<uint64_t>(chunk) * block_cap * 64));
+      ASP_TRY(o.ell_col.ensure(static_cast<uint64_t>(chunk) * quad_alloc * 64));
+      ASP_TRY(o.ell_val.ensure(static_cast<uint64_t>(chunk) * quad_alloc * 128));
+    }
+    ASP_HIP_TRY(hipMemsetAsync(d_status.ptr, 0, kStatWords * sizeof(uint32_t), s));
+    ASP_HIP_TRY(hipEventRecord(p->ev[0], s));
+    ASP_HIP_TRY(hipStreamWaitEvent(order_stream.stream, p->ev[0], 0));  // status zeroed, buffers ours
+
+    OrderArgs oa{};
+    oa.rq_ptr = p->rq_ptr.ptr;
+    oa.rq_col = reinterpret_cast<const uint4 *>(p->rq_col.ptr);
+    oa.rq_val = reinterpret_cast<const double2 *>(p->rq_val.ptr);
+    oa.seed = seed;
+    oa.num_spins = static_cast<uint32_t>(K);
+    oa.level_cap = level_cap;
+    oa.block_cap = block_cap;
+    oa.quad_cap = quad_cap;
+    oa.quad_stride = quad_alloc;
+    oa.lanes_per_row = lanes_per_row;
+    oa.col_shift = wide ? 2u : 0u;
+    oa.prio = d_prio.ptr;
+    oa.indeg = d_indeg.ptr;
+    oa.order = d_order.ptr;
+    oa.status = d_status.ptr;
+    ShuffledArgs a{};
+    a.status = d_status.ptr;
+    a.field = p->field_dev.ptr;
+    a.betas = d_betas.ptr;
+    a.x0 = x0 ? d_x0.ptr : nullptr;
+    a.state = d_state.ptr;
+    a.best = d_best.ptr;
+    a.e_cur = d_ecur.ptr;
+    a.e_best = d_ebest.ptr;
+    a.accepted = d_accepted.ptr;
+    a.seed = seed;
+    a.scale = std::ldexp(1.0, L.energy_scale_exp);
+    a.num_spins = static_cast<uint32_t>(K);
+    a.words = words;
+    a.level_cap = level_cap;
+    a.block_cap = block_cap;
+    a.quad_stride = quad_alloc;
+    a.replica_first = replica_offset;
+
+    bool first_launch = true;
+    uint32_t turn = 0;
+    for (uint32_t done = 0; done < num_sweeps || first_launch; done += chunk, ++turn) {
+      const uint32_t now = num_sweeps > done ? std::min(chunk, num_sweeps - done) : 0u;
+      const int which = static_cast<int>(turn & 1u);
+      OrderSet &o = sets[nsets == 2 ? which : 0];
+      if (now) {
+        // the orders of this chunk: after the sweep kernel of two chunks ago has let go of the set
+        if (turn >= 2) ASP_HIP_TRY(hipStreamWaitEvent(order_stream.stream, ev.swept[which], 0));
+        // (one scratch area: order kernels of consecutive chunks run one after the other anyway)
+        oa.first_sweep = done;
+        oa.count = now;
+        oa.level_block = o.level_block.ptr;
+        oa.num_levels = o.num_levels.ptr;
+        oa.block_meta = o.block_meta.ptr;
+        oa.spin_of_pos = o.spin_of_pos.ptr;
+        oa.ell_col = o.ell_col.ptr;
+        oa.ell_val = o.ell_val.ptr;
+        hipLaunchKernelGGL(k_shuffled_orders, dim3(now), dim3(order_threads), order_lds, order_stream.stream, oa);
+        ASP_HIP_TRY(hipGetLastError());
+        ASP_HIP_TRY(hipEventRecord(ev.ordered[which], order_stream.stream));
+        ASP_HIP_TRY(hipStreamWaitEvent(s, ev.ordered[which], 0));
+      }
+      a.level_block = o.level_block.ptr;
+      a.num_levels = o.num_levels.ptr;
+      a.block_meta = o.block_meta.ptr;
+      a.spin_of_pos = o.spin_of_pos.ptr;
+      a.ell_col = reinterpret_cast<const uint32_t *>(o.ell_col.ptr);
+      a.ell_val = reinterpret_cast<const double *>(o.ell_val.ptr);
+      a.first_sweep = done;
+      a.chunk_sweeps = now;
+      a.initialise = first_launch ? 1u : 0u;
+      hipLaunchKernelGGL(kernel, dim3(groups), dim3(waves * 64), lds, s, a);
+      ASP_HIP_TRY(hipGetLastError());
+      ASP_HIP_TRY(hipEventRecord(ev.swept[which], s));
+      first_launch = false;
+    }
+    ASP_HIP_TRY(hipEventRecord(p->ev[2], s));
+    ASP_HIP_TRY(hipMemcpyAsync(status, d_status.ptr, sizeof status, hipMemcpyDeviceToHost, s));
+    ASP_HIP_TRY(hipStreamSynchronize(s));
+    ASP_HIP_TRY(hipStreamSynchronize(order_stream.stream));
+    if (status[kStatBad] == 0) break;
+    if (attempt >= 4) {
+      return asp::set_error(ASP_ERR_TOO_LARGE, "visiting orders of %u levels / %u quads per sweep do not fit",
+                            status[kStatLevels], status[kStatQuads]);
+    }
+    // an order kernel needed more levels or quads than provided: grow and run the call again
+    // (chains restart from their initial configuration; results do not depend on the capacities)
+    if (status[kStatLevels] > level_cap) {
+      level_cap = static_cast<uint32_t>(std::min<uint64_t>(K, 2ull * status[kStatLevels] + 16));
+      quad_cap = 0;
+    } else {
+      quad_cap = static_cast<uint32_t>(std::min<uint64_t>(0x7FFFFFFFull, 2ull * std::max(status[kStatQuads], quad_cap)));
+    }
+  }
+  p->last_shuffled_levels = static_cast<int>(status[kStatLevels]);
+
+  // energies of §4.6 from the packed best configurations
+  ASP_TRY(asp::sa_permute_bits(p, d_best.ptr, repetitions, d_perm.ptr));
+  ASP_TRY(asp::sa_energies_of_perm(p, d_perm.ptr, repetitions, d_partial.ptr, d_e.ptr));
+  ASP_HIP_TRY(hipEventRecord(p->ev[3], s));
+  ASP_HIP_TRY(hipMemcpyAsync(out_x, d_best.ptr, static_cast<uint64_t>(repetitions) * words * sizeof(uint64_t),
+                             hipMemcpyDefault, s));
+  ASP_HIP_TRY(hipMemcpyAsync(out_e, d_e.ptr, repetitions * sizeof(double), hipMemcpyDefault, s));
+  p->last_tracked.assign(repetitions, 0);
+  p->last_accepted.assign(repetitions, 0);
+  ASP_HIP_TRY(hipMemcpyAsync(p->last_tracked.data(), d_ebest.ptr, repetitions * sizeof(int64_t),
+                             hipMemcpyDeviceToHost, s));
+  ASP_HIP_TRY(hipMemcpyAsync(p->last_accepted.data(), d_accepted.ptr, repetitions * sizeof(uint64_t),
+                             hipMemcpyDeviceToHost, s));
+  ASP_HIP_TRY(hipStreamSynchronize(s));
+  p->last_m = m;
+  p->last_layout = 5;
+  p->last_threads = static_cast<int>(waves * 64);
+  p->last_groups = static_cast<int>(groups);
+  ASP_HIP_TRY(hipEventElapsedTime(&p->last_sweep_ms, p->ev[0], p->ev[2]));
+  ASP_HIP_TRY(hipEventElapsedTime(&p->last_total_ms, p->ev[0], p->ev[3]));
+  return ASP_OK;
+}
+
+}  // extern "C"

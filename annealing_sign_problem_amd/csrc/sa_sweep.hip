@@ -42,379 +42,16 @@
 #include <vector>
 
 #include "asp_common.hpp"
+#include "sa_device.hpp"
+#include "sa_internal.hpp"
 #include "sa_plan.hpp"
-
-// Experiment switches (tools/ab_sweep.sh builds tagged variants with -D...=0/1).
-#ifndef ASP_SERPENTINE
-#define ASP_SERPENTINE 0
-#endif
-#ifndef ASP_MAGIC_RINT
-#define ASP_MAGIC_RINT 1
-#endif
-#ifndef ASP_EXP_FILTER
-#define ASP_EXP_FILTER 2  // 0 exact rule only, 1 f64 filter on u, 2 integer filter on the word
-#endif
-#ifndef ASP_INERT_SKIP
-#define ASP_INERT_SKIP 1
-#endif
-#ifndef ASP_TEAM_SLEEP
-#define ASP_TEAM_SLEEP 4  // s_sleep argument between two polls of the team barrier (0/1/4/16/64 scanned)
-#endif
-#ifndef ASP_J_MAJOR
-#define ASP_J_MAJOR 1
-#endif
-#ifndef ASP_ABS_LDS
-#define ASP_ABS_LDS 1
-#endif
-#ifndef ASP_SIGN_SHR
-#define ASP_SIGN_SHR 1  // byte layout: v_lshrrev (fast VOP2) + v_lshl_or instead of v_lshlrev + v_bfi
-#endif
-#ifndef ASP_PHILOX_SKIP
-#define ASP_PHILOX_SKIP 1  // no random numbers for a block none of whose proposals needs one
-#endif
-#ifndef ASP_EXPERIMENT_GLAUBER
-#define ASP_EXPERIMENT_GLAUBER 0  // analysis only (tools/schedule_probe.py): heat-bath acceptance
-#endif                            // 1 / (1 + exp(beta dE)) instead of Metropolis; NOT the specification
-#ifndef ASP_MAX_THREADS
-#define ASP_MAX_THREADS 1024  // launch bound of the sweep kernel (VGPR budget = 512 / waves per SIMD)
-#endif
-// Timing-only ablations (results are WRONG when any is set; never set in the product build).
-#ifndef ASP_ABL_NO_ACCEPT
-#define ASP_ABL_NO_ACCEPT 0
-#endif
-#ifndef ASP_ABL_NO_KLOOP
-#define ASP_ABL_NO_KLOOP 0
-#endif
-#ifndef ASP_ABL_NO_BARRIER
-#define ASP_ABL_NO_BARRIER 0
-#endif
-#ifndef ASP_ABL_NO_LDS
-#define ASP_ABL_NO_LDS 0
-#endif
-#ifndef ASP_ABL_NO_GLOAD
-#define ASP_ABL_NO_GLOAD 0
-#endif
-#ifndef ASP_ABL_NO_PHILOX
-#define ASP_ABL_NO_PHILOX 0
-#endif
-#ifndef ASP_ABL_NO_EXP
-#define ASP_ABL_NO_EXP 0
-#endif
-#ifndef ASP_ABL_HALF_BYTES
-#define ASP_ABL_HALF_BYTES 0
-#endif
-#ifndef ASP_ABL_NO_FMA
-#define ASP_ABL_NO_FMA 0
-#endif
 
 namespace {
 
 using asp::DeviceBuffer;
 using asp::kDummySpin;
-
-// ---------------------------------------------------------------------------
-// Device arithmetic shared by the kernels
-// ---------------------------------------------------------------------------
-
-struct Philox4 {
-  uint32_t w[4];
-};
-
-__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
-                                                 uint32_t c3, uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int round = 0; round < 10; ++round) {
-    const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c0;
-    const uint64_t p1 = static_cast<uint64_t>(0xCD9E8D57u) * c2;
-    const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n1 = static_cast<uint32_t>(p1);
-    const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
-    const uint32_t n3 = static_cast<uint32_t>(p0);
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  return Philox4{{c0, c1, c2, c3}};
-}
-
-__device__ __forceinline__ uint32_t pick_word(const Philox4 &p, uint32_t which) {
-  const uint32_t lo = (which & 1u) ? p.w[1] : p.w[0];
-  const uint32_t hi = (which & 1u) ? p.w[3] : p.w[2];
-  return (which & 2u) ? hi : lo;
-}
-
-// exp(-x), x >= 0: a fixed sequence of IEEE operations (v_rndne_f64, v_fma_f64,
-// v_mul_f64) so that the result is bit-identical to the CPU restatement.
-__device__ __forceinline__ double expneg(double x) {
-  if (!(x < 23.0)) return 0.0;
-  const double y = -x;
-  const double kf = __builtin_rint(__dmul_rn(y, 0x1.71547652b82fep+0));
-  double r = __builtin_fma(kf, -0x1.62e42fee00000p-1, y);
-  r = __builtin_fma(kf, -0x1.a39ef35793c76p-33, r);
-  double p = 0x1.6124613a86d09p-33;
-  p = __builtin_fma(p, r, 0x1.1eed8eff8d898p-29);
-  p = __builtin_fma(p, r, 0x1.ae64567f544e4p-26);
-  p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);
-  p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);
-  p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);
-  p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);
-  p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);
-  p = __builtin_fma(p, r, 0x1.1111111111111p-7);
-  p = __builtin_fma(p, r, 0x1.5555555555555p-5);
-  p = __builtin_fma(p, r, 0x1.5555555555555p-3);
-  p = __builtin_fma(p, r, 0x1.0000000000000p-1);
-  p = __builtin_fma(p, r, 1.0);
-  p = __builtin_fma(p, r, 1.0);
-  const long long k = static_cast<long long>(kf);
-  const double scale = __longlong_as_double((1023ll + k) << 52);
-  return __dmul_rn(p, scale);
-}
-
-// +-1.0 with the sign taken from bit `m` of the neighbour's spin byte (1 -> -1.0).
-// acc = fma(v, +-1.0, acc) is bit-identical to acc + (+-v): the product is exact, so
-// the only rounding is the add's.  Three VALU ops per (term, replica) and no
-// register-pair shuffling: the low dword of the multiplier is a constant zero.
-__device__ __forceinline__ double spin_factor(uint32_t spin_byte, int m) {
-  uint32_t hi;
-  if (m == 0) {
-    hi = (spin_byte << 31) | 0x3FF00000u;  // v_lshl_or_b32: nothing but bit 0 survives the shift
-  } else {
-#if ASP_SIGN_SHR
-    // replica m's bit to bit 0 with a RIGHT shift — a plain VOP2, 2.5 SIMD cycles per wave64 on
-    // this chip, where every left shift and every VOP3 costs 4.3-4.4
-    // (profiles/r02_issue_rate_probe.txt) — then the m = 0 instruction: 12.1 cycles per term
-    // and replica with the FMA instead of 13.3
-    const uint32_t down = spin_byte >> m;
-    asm("v_lshl_or_b32 %0, %1, 31, %2" : "=v"(hi) : "v"(down), "s"(0x3FF00000u));
-#else
-    // bit 31 from the shifted byte, everything else from 1.0's high word: one v_bfi_b32
-    // (hipcc folds the constant mask and emits v_and + v_or instead)
-    const uint32_t shifted = spin_byte << (31 - m);
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hi) : "s"(0x80000000u), "v"(shifted), "v"(0x3FF00000u));
-#endif
-  }
-  return __hiloint2double(static_cast<int>(hi), 0);
-}
-
-// u < expneg(x), decided through a hardware-exp filter.  v_exp_f32 of the f32-rounded
-// argument is within ~2e-6 (relative) of expneg(x) for 0 < x < 23: 1 ulp of the instruction
-// plus |x| * log2(e) * 2^-24 * ln 2 from rounding x to f32.  Outside a +-1e-5 band around that
-// estimate the comparison is settled; inside it (probability ~2e-5 per proposal, so a wavefront
-// takes the branch about once per thousand blocks) the exact sequence of §4.4 decides.  The
-// result therefore ALWAYS equals `u < expneg(x)` — same bits as the oracle — at a fraction of
-// the sixteen dependent f64 FMAs.
-__device__ __forceinline__ bool metropolis_accept(double u, double x) {
-  if (!(x < 23.0)) return false;  // expneg(x) = 0 < u; also NaN
-  const float estimate = __builtin_amdgcn_exp2f(static_cast<float>(x) * -1.44269504f);
-  const double p = static_cast<double>(estimate);
-  if (u < p * (1.0 - 1e-5)) return true;
-  if (u > p * (1.0 + 1e-5)) return false;
-  return u < expneg(x);
-}
-
-// The same decision taken on the random WORD: u = (word + 0.5) * 2^-32 < p  <=>  word + 0.5 <
-// p * 2^32.  With est = v_exp_f32 estimate of p (|est / p - 1| <= 2.63e-6, measured) and the two
-// f32 products lo = est * 2^32 (1 - 2e-5), hi = est * 2^32 (1 + 2e-5) (constant and product
-// rounding <= 1.3e-7 together): word < trunc(lo) implies word + 0.5 < lo < p * 2^32 (accept),
-// word > trunc(hi) implies word + 0.5 > hi > p * 2^32 (reject); in between (~4e-5 of the
-// proposals) the exact rule decides.  Integer compares and f32 products replace the f64
-// conversions, products and compares of metropolis_accept.
-__device__ __forceinline__ bool metropolis_accept_word(uint32_t word, double x) {
-  if (!(x < 23.0)) return false;  // expneg(x) = 0 < u; also NaN
-  const float estimate = __builtin_amdgcn_exp2f(static_cast<float>(x) * -1.44269504f);
-  const float lo = estimate * (4294967296.0f * (1.0f - 2e-5f));  // < 2^32: conversion in range
-  if (word < static_cast<uint32_t>(lo)) return true;
-  const float hi = estimate * (4294967296.0f * (1.0f + 2e-5f));
-  if (hi < 4294967040.0f && word > static_cast<uint32_t>(hi)) return false;
-  const double u = __dmul_rn(__dadd_rn(static_cast<double>(word), 0.5), 0x1p-32);
-  return u < expneg(x);
-}
-
-// v with its sign flipped when bit 0 of `neg` is set (energy kernel, not hot).
-__device__ __forceinline__ double signed_coupling(double v, uint32_t neg, int m) {
-  const unsigned long long flip = static_cast<unsigned long long>((neg >> m) & 1u) << 63;
-  return __longlong_as_double(__double_as_longlong(v) ^ static_cast<long long>(flip));
-}
-
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-  for (int step = 1; step < 64; step <<= 1) v += __shfl_xor(v, step, 64);
-  return v;
-}
-
-// Butterfly sum over the 64 lanes; every lane ends with the balanced-tree total
-// ((v0+v1)+(v2+v3))+... (f64 addition commutes, so all lanes agree bitwise).
-__device__ __forceinline__ double wave_tree_sum_f64(double v) {
-#pragma unroll
-  for (int step = 1; step < 64; step <<= 1) v = __dadd_rn(v, __shfl_xor(v, step, 64));
-  return v;
-}
-
-// Replica mask (bit m) -> wide spin word (byte m = 0x80): bits 0..3 to bits 7, 15, 23, 31.
-__device__ __forceinline__ uint32_t spread_mask(uint32_t mask) {
-  return ((mask & 0xFu) * 0x00204081u & 0x01010101u) << 7;
-}
-
-// Collect bit m of each of the four bytes of d into a nibble (byte 0 -> bit 0).
-__device__ __forceinline__ uint32_t gather_bit4(uint32_t d, int m) {
-  const uint32_t t = (d >> m) & 0x01010101u;
-  return ((t * 0x00204081u) >> 21) & 0xFu;
-}
-
-// ---------------------------------------------------------------------------
-// Sweep kernel
-// ---------------------------------------------------------------------------
-
-// Four consecutive ELL entries of one lane (one row), k = 4q .. 4q+3.
-struct Quad {
-  uint4 c;
-  double2 v01, v23;
-};
-
-// Three 16-byte loads per lane; quad index `q` is relative to the block's first quad.
-__device__ __forceinline__ void load_quad(Quad &q, const uint4 *__restrict__ cptr,
-                                          const double2 *__restrict__ vptr, uint32_t quad) {
-#if ASP_ABL_NO_GLOAD
-  const uint32_t l = (threadIdx.x * 37u + quad * 101u) & 0x3FFFu;
-  q.c = make_uint4(l, l + 1u, l + 2u, l + 3u);
-  q.v01 = make_double2(1.0 + quad, 2.0);
-  q.v23 = make_double2(3.0, 4.0 + quad);
-#else
-  q.c = cptr[quad * 64u];
-  q.v01 = vptr[quad * 128u];
-#if ASP_ABL_HALF_BYTES
-  q.v23 = make_double2(q.v01.y, q.v01.x);  // timing only: skip one of the two value loads
-#else
-  q.v23 = vptr[quad * 128u + 64u];
-#endif
-#endif
-}
-
-// PACKED = false: one LDS byte per position, bit m = replica m.  PACKED = true (M = 1 only):
-// one LDS bit per position, 64 positions (= one block) per u64 word.
-using LdsByte = __attribute__((address_space(3))) const uint8_t;
-using LdsWord = __attribute__((address_space(3))) const uint32_t;
-
-// How a workgroup keeps its spins in LDS.
-//   kBytes: one byte per position, bit m = sign bit of replica m (M <= 8);
-//   kBits:  one bit per position, one replica (8x the capacity);
-//   kWide:  one 32-bit word per position, byte m = 0x80 * sign bit of replica m (M <= 4; fits
-//           up to ~4e4 spins): the +-1.0 multiplier of a term is then ONE SDWA instruction.
-//   kGlobal: the bit words of kBits kept in HBM (one replica): no LDS limit on the size, every
-//           neighbour gather is an L2 access — the slow path for clusters beyond ~1.3e6 spins.
-constexpr int kBytes = 0, kBits = 1, kWide = 2, kGlobal = 3;
-
-// kWide: byte m of `word` (0x00 / 0x80) OR 0x3F becomes byte 3 of `hi`, whose lower three bytes
-// keep 0xF00000 — i.e. hi = high word of +1.0 or -1.0 — in one v_or_b32_sdwa (byte select on
-// the source, byte-3 write with the rest preserved).  Two VALU ops per (term, replica)
-// instead of three.
-__device__ __forceinline__ double wide_factor(uint32_t word, int m, uint32_t &hi) {
-  const uint32_t top = 0x3Fu;
-  switch (m) {
-    case 0:
-      asm("v_or_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD "
-          "src1_sel:BYTE_0" : "+v"(hi) : "v"(top), "v"(word));
-      break;
-    case 1:
-      asm("v_or_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD "
-          "src1_sel:BYTE_1" : "+v"(hi) : "v"(top), "v"(word));
-      break;
-    case 2:
-      asm("v_or_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD "
-          "src1_sel:BYTE_2" : "+v"(hi) : "v"(top), "v"(word));
-      break;
-    default:
-      asm("v_or_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD "
-          "src1_sel:BYTE_3" : "+v"(hi) : "v"(top), "v"(word));
-      break;
-  }
-  return __hiloint2double(static_cast<int>(hi), 0);
-}
-
-// `one_hi`: four registers holding the high word of 1.0 (kWide rewrites their top byte).
-template <int M, int LAYOUT>
-__device__ __forceinline__ void accumulate_quad(const Quad &q, const uint8_t *spins,
-                                                double (&acc)[M], uint32_t (&one_hi)[4]) {
-  constexpr bool PACKED = LAYOUT == kBits;
-  uint32_t s[4];
-  const uint32_t cs[4] = {q.c.x, q.c.y, q.c.z, q.c.w};
-#if ASP_ABL_NO_LDS
-#pragma unroll
-  for (int j = 0; j < 4; ++j) s[j] = cs[j] & 15u;
-#else
-  if constexpr (LAYOUT == kGlobal) {
-    // words written by other wavefronts of the workgroup during earlier colour steps: read at
-    // device scope (past the CU's vector L1)
-    const uint32_t *words = reinterpret_cast<const uint32_t *>(spins);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t w = __hip_atomic_load(words + (cs[j] >> 5), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-      s[j] = (w >> (cs[j] & 31u)) & 1u;
-    }
-  } else if constexpr (LAYOUT == kWide) {
-    // columns of the wide plan are LDS byte addresses (position * 4)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      s[j] = *reinterpret_cast<LdsWord *>(static_cast<uintptr_t>(cs[j]));
-    }
-  } else if constexpr (PACKED) {
-    const uint32_t *words = reinterpret_cast<const uint32_t *>(spins);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] = (words[cs[j] >> 5] >> (cs[j] & 31u)) & 1u;
-  } else {
-#if ASP_ABS_LDS
-    // the spin bytes start at LDS address 0 (checked in the kernel prologue), so a position IS
-    // its LDS address: no base add in front of every ds_read_u8
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      s[j] = *reinterpret_cast<LdsByte *>(static_cast<uintptr_t>(cs[j]));
-    }
-#else
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] = spins[cs[j]];
-#endif
-  }
-#endif
-#if ASP_ABL_NO_FMA
-  asm volatile("" ::"v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(q.v01.x), "v"(q.v01.y),
-               "v"(q.v23.x), "v"(q.v23.y));
-  return;
-#endif
-#if ASP_J_MAJOR
-  // neighbour-major: consecutive FMAs go to different accumulators (each acc[m] still receives
-  // its terms in ascending k)
-  const double vs[4] = {q.v01.x, q.v01.y, q.v23.x, q.v23.y};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      if constexpr (LAYOUT == kWide) {
-        acc[m] = __builtin_fma(vs[j], wide_factor(s[j], m, one_hi[m & 3]), acc[m]);
-      } else {
-        acc[m] = __builtin_fma(vs[j], spin_factor(s[j], m), acc[m]);
-      }
-    }
-  }
-  return;
-#endif
-#pragma unroll
-  for (int m = 0; m < M; ++m) {
-    double x = acc[m];
-    if constexpr (LAYOUT == kWide) {
-      x = __builtin_fma(q.v01.x, wide_factor(s[0], m, one_hi[0]), x);
-      x = __builtin_fma(q.v01.y, wide_factor(s[1], m, one_hi[1]), x);
-      x = __builtin_fma(q.v23.x, wide_factor(s[2], m, one_hi[2]), x);
-      x = __builtin_fma(q.v23.y, wide_factor(s[3], m, one_hi[3]), x);
-    } else {
-      x = __builtin_fma(q.v01.x, spin_factor(s[0], m), x);
-      x = __builtin_fma(q.v01.y, spin_factor(s[1], m), x);
-      x = __builtin_fma(q.v23.x, spin_factor(s[2], m), x);
-      x = __builtin_fma(q.v23.y, spin_factor(s[3], m), x);
-    }
-    acc[m] = x;
-  }
-}
+using asp::upload_vector;
+using namespace asp::dev;  // Philox, expneg, the accept filters, coupling quads (sa_device.hpp)
 
 struct SweepArgs {
   const uint32_t *color_block_start;  // num_colors + 1
@@ -1267,228 +904,6 @@ __global__ __launch_bounds__(1024) void k_sa_sweep_team(TeamArgs ta) {
 }
 
 // ---------------------------------------------------------------------------
-// Shuffled sweep: a fresh visiting order every sweep
-// ---------------------------------------------------------------------------
-// The reference's annealer visits the spins in a fresh random permutation every sweep
-// (that order, not the ladder or the acceptance rule, reproduces its published
-// success probabilities).  A sequential sweep in the order of random priorities equals visiting the
-// LEVELS of the priority graph one after another (csrc/sa_plan.cpp: shuffled_orders); spins of a
-// level are pairwise non-adjacent, so a level is updated in parallel.  The levels change every
-// sweep, so the static colour-block layout of k_sa_sweep is of no use here: one workgroup per
-// chain, spins as LDS bytes in ORIGINAL order, a thread per spin of the level, rows gathered
-// from the CSR of A.  Same proposal arithmetic, random words and energy bookkeeping as §4.4-4.5;
-// several times slower than the colour-ordered sweep — it exists to reproduce the reference's
-// statistics, not for speed.  Long ladders run in chunks (the orders of a chunk are built on the
-// host while the chain state stays in HBM).
-
-struct ShuffledArgs {
-  const int64_t *a_ptr;  // CSR of A over original indices
-  const int32_t *a_col;
-  const double *a_val;
-  const double *field;
-  const double *betas;          // all sweeps of the call
-  const uint32_t *order;        // [chunk][K] level-major visiting order
-  const uint32_t *level_start;  // [chunk][cap]
-  const uint32_t *num_levels;   // [chunk]
-  const uint64_t *x0;           // packed original-order start configuration or nullptr
-  uint8_t *spins;               // [groups][K] bit m = chain m of the group is -1 (state between chunks)
-  uint8_t *best;                // [groups * M][K] a byte per spin of every chain's best configuration
-  long long *e_cur, *e_best;    // [groups * M] tracked energies (fixed point)
-  unsigned long long *accepted; // [groups * M]
-  uint64_t seed;
-  double scale;
-  uint32_t num_spins, cap, first_sweep, chunk_sweeps, replica_first, initialise;
-};
-
-// M chains per workgroup: the visiting order is the same for every chain, so a row
-// gathered from the CSR serves all of them (bit m of a spin's LDS byte = chain m is -1).
-// (4 when 8 would leave compute units without a workgroup.)
-template <int M>
-__global__ __launch_bounds__(1024) void k_sa_sweep_shuffled(ShuffledArgs a) {
-  extern __shared__ __align__(16) uint8_t lds[];
-  const uint32_t K = a.num_spins;
-  uint8_t *s = lds;  // K bytes, then the bookkeeping
-  // book: [0..M) dq of the running sweep, [M..2M) accepted flips of it, [2M..3M) current tracked
-  // energy, [3M..4M) best, [4M..5M) accepted so far
-  long long *book = reinterpret_cast<long long *>(lds + ((K + 15u) & ~15u));
-  const uint32_t tid = threadIdx.x;
-  const uint32_t group = blockIdx.x;
-  const uint32_t r0 = a.replica_first + group * M;
-  const uint32_t key0 = static_cast<uint32_t>(a.seed), key1 = static_cast<uint32_t>(a.seed >> 32);
-  uint8_t *my_spins = a.spins + static_cast<uint64_t>(group) * K;
-  if (a.initialise) {
-    for (uint32_t i = tid; i < K; i += blockDim.x) {
-      uint32_t mask = 0;
-      if (a.x0 != nullptr) {
-        mask = ((a.x0[i >> 6] >> (i & 63u)) & 1ull) ? 0u : ((1u << M) - 1u);
-      } else {
-        Philox4 rnd{};
-        uint32_t have = 0xFFFFFFFFu;
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-          const uint32_t r = r0 + m;
-          if (m == 0 || (r >> 2) != have) {
-            have = r >> 2;
-            rnd = philox4x32_10(i, 0xFFFFFFFFu, have, 0u, key0, key1);
-          }
-          mask |= ((pick_word(rnd, r & 3u) & 1u) ^ 1u) << m;
-        }
-      }
-      s[i] = static_cast<uint8_t>(mask);
-#pragma unroll
-      for (int m = 0; m < M; ++m) {
-        a.best[(static_cast<uint64_t>(group) * M + m) * K + i] = static_cast<uint8_t>((mask >> m) & 1u);
-      }
-    }
-  } else {
-    for (uint32_t i = tid; i < K; i += blockDim.x) s[i] = my_spins[i];
-  }
-  if (tid < 5 * M) {
-    long long v = 0;
-    if (!a.initialise && tid >= 2 * M) {
-      const uint32_t m = tid % M;
-      const uint64_t at = static_cast<uint64_t>(group) * M + m;
-      v = tid < 3 * M ? a.e_cur[at] : (tid < 4 * M ? a.e_best[at] : static_cast<long long>(a.accepted[at]));
-    }
-    book[tid] = v;
-  }
-  __syncthreads();
-  for (uint32_t tt = 0; tt < a.chunk_sweeps; ++tt) {
-    const uint32_t t = a.first_sweep + tt;
-    const double beta = a.betas[t];
-    const uint32_t *order = a.order + static_cast<uint64_t>(tt) * K;
-    const uint32_t *starts = a.level_start + static_cast<uint64_t>(tt) * a.cap;
-    const uint32_t levels = a.num_levels[tt];
-    long long q[M];
-    uint32_t n[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      q[m] = 0;
-      n[m] = 0;
-    }
-    // Every level is a chain of dependent loads (its bounds -> order -> row pointers -> the row):
-    // the bounds are fetched two levels ahead and the row comes in blocks of 8 entries in flight.
-    uint32_t begin = starts[0];
-    uint32_t end = starts[levels ? 1u : 0u];
-    for (uint32_t l = 0; l < levels; ++l) {
-      const uint32_t after = starts[l + 2 <= levels ? l + 2 : levels];
-      for (uint32_t idx = begin + tid; idx < end; idx += blockDim.x) {
-        const uint32_t i = order[idx];
-        double acc[M];
-#pragma unroll
-        for (int m = 0; m < M; ++m) acc[m] = 0.0;
-        const int64_t row_end = a.a_ptr[i + 1];
-        for (int64_t k = a.a_ptr[i]; k < row_end; k += 8) {
-          double v[8];
-          uint32_t c[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int64_t at = k + j < row_end ? k + j : row_end - 1;
-            v[j] = a.a_val[at];
-            c[j] = static_cast<uint32_t>(a.a_col[at]);
-          }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if (k + j < row_end) {  // in the order of the row: the sums are those of the oracle
-              const uint32_t byte = s[c[j]];
-#pragma unroll
-              for (int m = 0; m < M; ++m) acc[m] = __dadd_rn(acc[m], ((byte >> m) & 1u) ? -v[j] : v[j]);
-            }
-          }
-        }
-        const double h = a.field[i];
-        const uint32_t own = s[i];
-        uint32_t flip = 0;
-        Philox4 rnd{};
-        uint32_t have = 0xFFFFFFFFu;
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-          const double g = __dadd_rn(acc[m], h);
-          const bool negative = (own >> m) & 1u;
-          const double de = __dmul_rn(negative ? 2.0 : -2.0, g);
-          bool accept = de <= 0.0;
-          if (!accept) {
-            const uint32_t r = r0 + m;
-            if ((r >> 2) != have) {
-              have = r >> 2;
-              rnd = philox4x32_10(i, t, have, 0u, key0, key1);
-            }
-            accept = metropolis_accept_word(pick_word(rnd, r & 3u), __dmul_rn(beta, de));
-          }
-          if (accept) {
-            flip |= 1u << m;
-            q[m] += __double_as_longlong(__dadd_rn(__dmul_rn(de, a.scale), 0x1.8p52)) - 0x4338000000000000ll;
-            n[m] += 1;
-          }
-        }
-        if (flip) s[i] = static_cast<uint8_t>(own ^ flip);  // no neighbour of i is in this level
-      }
-      __syncthreads();
-      begin = end;
-      end = after;
-    }
-    // exact (integer) reduction of the sweep's energy change, per chain
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      const long long wq = wave_sum_i64(q[m]);
-      const long long wn = wave_sum_i64(static_cast<long long>(n[m]));
-      if ((tid & 63u) == 0 && wn != 0) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(&book[m]), static_cast<unsigned long long>(wq));
-        atomicAdd(reinterpret_cast<unsigned long long *>(&book[M + m]), static_cast<unsigned long long>(wn));
-      }
-    }
-    __syncthreads();
-    uint32_t improved = 0;
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      improved |= (book[2 * M + m] + book[m] < book[3 * M + m]) ? (1u << m) : 0u;  // same in every thread
-    }
-    __syncthreads();
-    if (tid < M) {
-      const long long e = book[2 * M + tid] + book[tid];
-      book[2 * M + tid] = e;
-      if (e < book[3 * M + tid]) book[3 * M + tid] = e;
-      book[4 * M + tid] += book[M + tid];
-      book[tid] = 0;
-      book[M + tid] = 0;
-    }
-    if (improved) {
-      for (uint32_t i = tid; i < K; i += blockDim.x) {
-        const uint32_t byte = s[i];
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-          if ((improved >> m) & 1u) {
-            a.best[(static_cast<uint64_t>(group) * M + m) * K + i] = static_cast<uint8_t>((byte >> m) & 1u);
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  for (uint32_t i = tid; i < K; i += blockDim.x) my_spins[i] = s[i];
-  if (tid < M) {
-    const uint64_t at = static_cast<uint64_t>(group) * M + tid;
-    a.e_cur[at] = book[2 * M + tid];
-    a.e_best[at] = book[3 * M + tid];
-    a.accepted[at] = static_cast<unsigned long long>(book[4 * M + tid]);
-  }
-}
-
-// Best configurations (a byte per spin, 1 = -1) -> packed original-order words (bit = +1).
-__global__ __launch_bounds__(256) void k_pack_spin_bytes(const uint8_t *__restrict__ bytes,
-                                                        uint64_t num_spins, uint32_t words,
-                                                        uint32_t count, uint64_t *__restrict__ x) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint64_t idx = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (idx >= static_cast<uint64_t>(count) * words) return;  // whole wavefront
-  const uint32_t rr = static_cast<uint32_t>(idx / words), w = static_cast<uint32_t>(idx % words);
-  const uint64_t spin = static_cast<uint64_t>(w) * 64u + lane;
-  const bool up = spin < num_spins && bytes[static_cast<uint64_t>(rr) * num_spins + spin] == 0;
-  const uint64_t word = __ballot(up);
-  if (lane == 0) x[idx] = word;
-}
-
-// ---------------------------------------------------------------------------
 // Energy of packed configurations: E = D + T, T = radix-64
 // pairwise tree over the blocks of t_p = s_p (A_p . s / 2 + h_p).
 // ---------------------------------------------------------------------------
@@ -1722,55 +1137,7 @@ __global__ __launch_bounds__(256) void k_unpermute_bits_batch(const PostProblem 
 // Plan object and C ABI
 // ---------------------------------------------------------------------------
 
-struct asp_sa_plan {
-  asp::SaHostLayout host;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  float last_sweep_ms = 0.0f, last_total_ms = 0.0f;
-  int force_m = 0, force_threads = 0;
-  int force_packed = 0;  // asp_sa_set_packed: 0 auto, 1 bits in LDS, 2 bits in HBM
-  bool allow_wide = true;  // asp_sa_set_wide
-  int last_m = 0, last_threads = 0, last_groups = 0;
-  std::vector<int64_t> last_tracked;
-  std::vector<uint64_t> last_accepted;
-  int num_cus = 256;
-  size_t max_lds = 160 * 1024;
-  DeviceBuffer<uint32_t> color_block_start, block_width, ell_col, spin_of_pos, pos_of_spin;
-  DeviceBuffer<uint32_t> ell_col4;  // columns as LDS byte addresses of the wide layout (if it fits)
-  int last_layout = 0;
-  DeviceBuffer<uint64_t> ell_off;
-  DeviceBuffer<double> ell_val, field_pos;
-  // per-call work buffers, grown on demand and kept (a plan is used by one thread at a time)
-  DeviceBuffer<double> w_betas, w_partial, w_e;
-  DeviceBuffer<uint64_t> w_best, w_x0, w_x0_perm, w_x;
-  DeviceBuffer<long long> w_tracked;
-  DeviceBuffer<unsigned long long> w_accepted;
-  DeviceBuffer<double> w_field_cache;  // [groups][blocks][M][64], see SweepArgs::field_cache
-  DeviceBuffer<uint64_t> w_spins;      // [groups][blocks] sign words of the HBM-resident layout
-  DeviceBuffer<long long> w_trace;     // [groups * M][sweeps + 1] tracked energies (asp_sa_anneal_trace)
-  // team sweep exchange area, FINE-GRAINED device memory (coherent across XCDs without cache
-  // maintenance): arrivals u64[teams] | sums i64[teams][6] | abort u32 (+pad) | flips u64[teams][blocks]
-  void *team_area = nullptr;
-  size_t team_area_bytes = 0;
-  ~asp_sa_plan() {
-    if (team_area) (void)hipFree(team_area);
-  }
-  int team_mode = -1;  // asp_sa_set_team: -1 auto, 0 off, G >= 2 forced
-  bool use_field_cache = true;
-  uint32_t team_abort_host = 0;  // landing place of the watchdog flag's asynchronous read-back
-  // CSR of A over original indices + field (shuffled sweep only; uploaded on first use)
-  DeviceBuffer<int64_t> a_ptr_dev;
-  DeviceBuffer<int32_t> a_col_dev;
-  DeviceBuffer<double> a_val_dev, field_dev;
-};
-
 namespace {
-
-template <typename T>
-int upload_vector(DeviceBuffer<T> &dst, const std::vector<T> &src, hipStream_t stream) {
-  ASP_TRY(dst.alloc(src.size()));
-  return dst.upload(src.data(), src.size(), stream);
-}
 
 using SweepKernel = void (*)(SweepArgs);
 
@@ -1880,6 +1247,26 @@ int energies_of_perm(asp_sa_plan *p, const uint64_t *perm_words, uint32_t count,
 }
 
 }  // namespace
+
+namespace asp {
+
+int sa_permute_bits(asp_sa_plan *p, const uint64_t *x, uint32_t count, uint64_t *perm) {
+  const SaHostLayout &L = p->host;
+  const uint64_t total = static_cast<uint64_t>(count) * L.num_blocks;
+  if (total == 0) return ASP_OK;
+  const uint32_t words = static_cast<uint32_t>((L.num_spins + 63) / 64);
+  hipLaunchKernelGGL(k_permute_bits, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+                     p->stream, x, words, p->spin_of_pos.ptr, L.num_blocks, count, perm);
+  ASP_HIP_TRY(hipGetLastError());
+  return ASP_OK;
+}
+
+int sa_energies_of_perm(asp_sa_plan *p, const uint64_t *perm, uint32_t count, double *partial,
+                        double *out_e) {
+  return energies_of_perm(p, perm, count, partial, out_e);
+}
+
+}  // namespace asp
 
 extern "C" {
 
@@ -2302,172 +1689,6 @@ int asp_sa_anneal_trace(asp_sa_plan *p, uint64_t seed, double const *betas, uint
   if (!out_trace) return asp::set_error(ASP_ERR_INVALID, "null trace pointer");
   return run_chains(p, seed, betas, num_sweeps, repetitions, replica_offset, x0, false, out_x,
                     out_e, out_trace);
-}
-
-int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_sweeps,
-                           uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0,
-                           uint64_t *out_x, double *out_e) {
-  asp_clear_error();
-  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
-  ASP_TRY(asp::bind_device());
-  if (repetitions == 0) return ASP_OK;
-  if (!out_x || !out_e || (num_sweeps && !betas)) return asp::set_error(ASP_ERR_INVALID, "null argument");
-  if (num_sweeps >= 0xFFFFFFFEu) return asp::set_error(ASP_ERR_INVALID, "num_sweeps too large");
-  if (static_cast<uint64_t>(replica_offset) + repetitions + 8 > 0xFFFFFFFFull) {
-    return asp::set_error(ASP_ERR_INVALID, "replica ids exceed 32 bits");
-  }
-  for (uint32_t t = 0; t < num_sweeps; ++t) {
-    if (!(betas[t] >= 0.0)) return asp::set_error(ASP_ERR_INVALID, "betas[%u] is not >= 0", t);
-  }
-  const asp::SaHostLayout &L = p->host;
-  const uint64_t K = L.num_spins;
-  const uint32_t words = static_cast<uint32_t>((K + 63) / 64);
-  p->last_sweep_ms = p->last_total_ms = 0.0f;
-  if (K == 0) {
-    for (uint32_t r = 0; r < repetitions; ++r) out_e[r] = 0.0;
-    return ASP_OK;
-  }
-  const uint32_t per_group = (repetitions + 7) / 8 >= static_cast<uint32_t>(p->num_cus) ? 8u : 4u;
-  const size_t lds = ((K + 15) & ~size_t{15}) + 5 * per_group * sizeof(long long);
-  if (lds > p->max_lds) {
-    return asp::set_error(ASP_ERR_TOO_LARGE, "the shuffled sweep keeps a byte per spin in LDS: %llu "
-                                             "spins do not fit", (unsigned long long)K);
-  }
-  hipStream_t s = p->stream;
-  asp::StreamFence fence(s);
-  // CSR of A and the field in original order: resident with the plan from the first call on
-  if (!p->a_ptr_dev.ptr) {
-    std::vector<double> field(K);
-    for (uint64_t i = 0; i < K; ++i) field[i] = L.field_pos[L.pos_of_spin[i]];
-    ASP_TRY(upload_vector(p->a_ptr_dev, L.a_ptr, s));
-    ASP_TRY(upload_vector(p->a_col_dev, L.a_col, s));
-    ASP_TRY(upload_vector(p->a_val_dev, L.a_val, s));
-    ASP_TRY(upload_vector(p->field_dev, field, s));
-    ASP_HIP_TRY(hipStreamSynchronize(s));  // `field` dies with this scope
-  }
-  // sweeps per chunk: at most 32 MiB of visiting orders at a time (two such buffers)
-  const uint32_t chunk = static_cast<uint32_t>(std::max<uint64_t>(
-      1, std::min<uint64_t>(num_sweeps ? num_sweeps : 1, (32ull << 20) / (4 * K))));
-  DeviceBuffer<double> d_betas, d_partial, d_e;
-  DeviceBuffer<uint64_t> d_x0, d_x, d_perm;
-  DeviceBuffer<uint8_t> d_spins, d_best;
-  DeviceBuffer<long long> d_ecur, d_ebest;
-  DeviceBuffer<unsigned long long> d_accepted;
-  asp::StreamFence fence2(s);  // (declared after the buffers: waits before they are released)
-  ASP_TRY(d_betas.alloc(num_sweeps));
-  const uint32_t groups = (repetitions + per_group - 1) / per_group;
-  const uint64_t padded = static_cast<uint64_t>(groups) * per_group;
-  ASP_TRY(d_spins.alloc(static_cast<uint64_t>(groups) * K));
-  ASP_TRY(d_best.alloc(padded * K));
-  ASP_TRY(d_ecur.alloc(padded));
-  ASP_TRY(d_ebest.alloc(padded));
-  ASP_TRY(d_accepted.alloc(padded));
-  ASP_TRY(d_x.alloc(static_cast<uint64_t>(repetitions) * words));
-  ASP_TRY(d_perm.alloc(static_cast<uint64_t>(repetitions) * L.num_blocks));
-  ASP_TRY(d_partial.alloc(static_cast<uint64_t>(repetitions) * L.num_blocks));
-  ASP_TRY(d_e.alloc(repetitions));
-  ASP_TRY(d_betas.upload(betas, num_sweeps, s));
-  if (x0) {
-    ASP_TRY(d_x0.alloc(words));
-    ASP_TRY(d_x0.upload(x0, words, s));
-  }
-  ShuffledArgs a{};
-  a.a_ptr = p->a_ptr_dev.ptr;
-  a.a_col = p->a_col_dev.ptr;
-  a.a_val = p->a_val_dev.ptr;
-  a.field = p->field_dev.ptr;
-  a.betas = d_betas.ptr;
-  a.x0 = x0 ? d_x0.ptr : nullptr;
-  a.spins = d_spins.ptr;
-  a.best = d_best.ptr;
-  a.e_cur = d_ecur.ptr;
-  a.e_best = d_ebest.ptr;
-  a.accepted = d_accepted.ptr;
-  a.seed = seed;
-  a.scale = std::ldexp(1.0, L.energy_scale_exp);
-  a.num_spins = static_cast<uint32_t>(K);
-  a.replica_first = replica_offset;
-  void (*kernel)(ShuffledArgs) = per_group == 8 ? k_sa_sweep_shuffled<8> : k_sa_sweep_shuffled<4>;
-  if (lds > 64 * 1024) {
-    ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-  }
-  const unsigned threads = K >= 4096 ? 1024u : (K >= 512 ? 256u : 64u);
-  // Two sets of order buffers: the host draws and levels chunk c + 1 while the kernel runs chunk c.
-  struct OrderSet {
-    std::vector<uint32_t> order, starts, levels;
-    DeviceBuffer<uint32_t> d_order, d_starts, d_levels;
-    hipEvent_t consumed = nullptr;
-    ~OrderSet() {
-      if (consumed) (void)hipEventDestroy(consumed);
-    }
-  } sets[2];
-  asp::StreamFence fence3(s);  // the sets outlive the work queued on them
-  for (OrderSet &o : sets) {
-    o.order.resize(static_cast<size_t>(chunk) * K);
-    o.levels.resize(chunk);
-    ASP_TRY(o.d_order.alloc(static_cast<uint64_t>(chunk) * K));
-    ASP_TRY(o.d_levels.alloc(chunk));
-    ASP_HIP_TRY(hipEventCreateWithFlags(&o.consumed, hipEventDisableTiming));
-    if (num_sweeps <= chunk) break;  // a single chunk needs one set
-  }
-  ASP_HIP_TRY(hipEventRecord(p->ev[0], s));
-  bool first_launch = true;
-  uint32_t turn = 0;
-  for (uint32_t done = 0; done < num_sweeps || first_launch; done += chunk, ++turn) {
-    const uint32_t now = num_sweeps > done ? std::min(chunk, num_sweeps - done) : 0u;
-    OrderSet &o = sets[turn & 1u];
-    if (now) {
-      if (turn >= 2) ASP_HIP_TRY(hipEventSynchronize(o.consumed));  // the kernel of two chunks ago is through
-      uint32_t cap = 0;
-      asp::shuffled_orders(L, seed, done, now, o.order.data(), &o.starts, &cap, o.levels.data());
-      a.cap = cap;
-      ASP_TRY(o.d_starts.ensure(o.starts.size()));
-      ASP_TRY(o.d_order.upload(o.order.data(), static_cast<size_t>(now) * K, s));
-      ASP_TRY(o.d_starts.upload(o.starts.data(), o.starts.size(), s));
-      ASP_TRY(o.d_levels.upload(o.levels.data(), now, s));
-    }
-    a.order = o.d_order.ptr;
-    a.level_start = o.d_starts.ptr;
-    a.num_levels = o.d_levels.ptr;
-    a.first_sweep = done;
-    a.chunk_sweeps = now;
-    a.initialise = first_launch ? 1u : 0u;
-    hipLaunchKernelGGL(kernel, dim3(groups), dim3(threads), lds, s, a);
-    ASP_HIP_TRY(hipGetLastError());
-    ASP_HIP_TRY(hipEventRecord(o.consumed, s));
-    first_launch = false;
-  }
-  ASP_HIP_TRY(hipEventRecord(p->ev[2], s));
-  // packed original-order bits of the best configurations, then the energies of §4.6
-  {
-    const uint64_t total = static_cast<uint64_t>(repetitions) * words;
-    hipLaunchKernelGGL(k_pack_spin_bytes, dim3(static_cast<unsigned>((total + 3) / 4)), dim3(256), 0, s,
-                       d_best.ptr, K, words, repetitions, d_x.ptr);
-    const uint64_t blocks = static_cast<uint64_t>(repetitions) * L.num_blocks;
-    hipLaunchKernelGGL(k_permute_bits, dim3(static_cast<unsigned>((blocks + 255) / 256)), dim3(256), 0, s,
-                       d_x.ptr, words, p->spin_of_pos.ptr, L.num_blocks, repetitions, d_perm.ptr);
-    ASP_HIP_TRY(hipGetLastError());
-  }
-  ASP_TRY(energies_of_perm(p, d_perm.ptr, repetitions, d_partial.ptr, d_e.ptr));
-  ASP_HIP_TRY(hipEventRecord(p->ev[3], s));
-  ASP_HIP_TRY(hipMemcpyAsync(out_x, d_x.ptr, static_cast<uint64_t>(repetitions) * words * sizeof(uint64_t),
-                             hipMemcpyDefault, s));
-  ASP_HIP_TRY(hipMemcpyAsync(out_e, d_e.ptr, repetitions * sizeof(double), hipMemcpyDefault, s));
-  p->last_tracked.assign(repetitions, 0);
-  p->last_accepted.assign(repetitions, 0);
-  ASP_HIP_TRY(hipMemcpyAsync(p->last_tracked.data(), d_ebest.ptr, repetitions * sizeof(int64_t),
-                             hipMemcpyDeviceToHost, s));
-  ASP_HIP_TRY(hipMemcpyAsync(p->last_accepted.data(), d_accepted.ptr, repetitions * sizeof(uint64_t),
-                             hipMemcpyDeviceToHost, s));
-  ASP_HIP_TRY(hipStreamSynchronize(s));
-  p->last_m = static_cast<int>(per_group);
-  p->last_layout = 5;
-  p->last_threads = static_cast<int>(threads);
-  p->last_groups = static_cast<int>(groups);
-  ASP_HIP_TRY(hipEventElapsedTime(&p->last_sweep_ms, p->ev[0], p->ev[2]));
-  ASP_HIP_TRY(hipEventElapsedTime(&p->last_total_ms, p->ev[0], p->ev[3]));
-  return ASP_OK;
 }
 
 int asp_sa_greedy(asp_sa_plan *p, uint32_t max_sweeps, uint64_t *out_x, double *out_e,

@@ -408,13 +408,19 @@ int asp_sa_anneal_trace(asp_sa_plan *p, uint64_t seed, double const *betas, uint
  * fixed one: DESIGN.md §6.1).  Sweep t visits the spins in ascending (priority, index), priority =
  * word 0 of Philox4x32-10(counter (i, t, 0xFFFFFFFE, 0), key seed); every chain uses the same
  * order.  Proposal arithmetic, random words, energy bookkeeping, outputs and determinism are those
- * of asp_sa_anneal; only the order differs.  Eight (or four) chains per workgroup, a byte per
- * spin in LDS (K <= ~1.6e5), about ten times slower than asp_sa_anneal: it exists to reproduce
- * the reference's statistics (annealer.anneal(..., sweep_order="shuffled")).
- * asp_sa_last_layout reports 5. */
+ * of asp_sa_anneal; only the order differs.  The orders are built ON THE DEVICE, a chunk of sweeps
+ * at a time (csrc/sa_shuffled.hip: priorities, levels of the priority graph, the sweep's couplings
+ * re-laid level by level), by a kernel that runs beside the sweep kernel of the previous chunk;
+ * spins stay in LDS in original order (K <= ~1.6e5).  out_x / out_e may be host or device
+ * pointers.  asp_sa_last_layout reports 5. */
 int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_sweeps,
                            uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0,
                            uint64_t *out_x, double *out_e);
+/* Launch geometry of the shuffled sweep (0 = automatic): chains per workgroup in {1,2,4,8} and
+ * wavefronts per workgroup in 1..16.  Results never depend on it. */
+int asp_sa_set_shuffled_launch(asp_sa_plan *p, int chains_per_group, int wavefronts);
+/* Of the last asp_sa_anneal_shuffled call: the largest number of levels of a sweep. */
+int asp_sa_last_shuffled(asp_sa_plan const *p, uint32_t *levels, float *order_ms);
 
 /* MANY independent problems in one call — the shape of the reference's production job: tens of
  * thousands of sampled clusters, each solved with 64 repetitions x 5120 sweeps
