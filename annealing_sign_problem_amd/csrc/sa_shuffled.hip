@@ -52,6 +52,7 @@ constexpr uint32_t kClassCap = 63;                  // rows of >= 63 quads share
 
 // status words shared by the kernels of a call (device memory, zeroed per attempt)
 enum : uint32_t { kStatBad = 0, kStatLevels = 1, kStatBlocks = 2, kStatQuads = 3, kStatWords = 4 };
+constexpr uint32_t kTimingSlots = 6, kTimingWaves = 8;  // u64[waves][slots] behind the status words (ASP_SHUF_TIMING)
 
 // ---------------------------------------------------------------------------
 // Order kernel
@@ -62,6 +63,7 @@ struct OrderArgs {
   const uint32_t *rq_ptr;  // [K + 1]
   const uint4 *rq_col;     // [quads]
   const double2 *rq_val;   // [quads][2]
+  const double *field;     // [K]
   uint64_t seed;
   uint32_t num_spins, first_sweep, count;
   uint32_t level_cap, block_cap, quad_cap;  // capacities per sweep of the outputs below
@@ -75,6 +77,7 @@ struct OrderArgs {
   uint32_t *num_levels;   // [count]
   uint2 *block_meta;      // [count][block_cap] {first quad relative to the sweep's ELL, quads}
   uint32_t *spin_of_pos;  // [count][block_cap * 64], kDummySpin = padding lane
+  double *field_of_pos;   // [count][block_cap * 64] the field of that spin
   uint4 *ell_col;         // [count][quad_cap][64]
   double2 *ell_val;       // [count][quad_cap][2][64]
   uint32_t *status;
@@ -294,9 +297,11 @@ __global__ __launch_bounds__(kOrderThreads) void k_shuffled_orders(OrderArgs a) 
   // ---- 7. the sweep's level-major sliced ELL ----
   uint4 *ell_col = a.ell_col + static_cast<uint64_t>(s) * a.quad_stride * 64u;
   double2 *ell_val = a.ell_val + static_cast<uint64_t>(s) * a.quad_stride * 128u;
+  double *fop = a.field_of_pos + static_cast<uint64_t>(s) * a.block_cap * 64u;
   for (uint32_t b = wave; b < B; b += waves) {
     const uint32_t i = sop[b * 64u + lane];
     const bool real = i != kDummySpin;
+    fop[b * 64u + lane] = real ? a.field[i] : 0.0;
     const uint32_t row = real ? a.rq_ptr[i] : 0u;
     const uint32_t mine = real ? a.rq_ptr[i + 1] - row : 0u;
     const uint32_t own = real ? i << a.col_shift : 0u;  // padding reads the lane's own spin (x +0.0)
@@ -345,10 +350,10 @@ struct ShuffledArgs {
   const uint32_t *num_levels;
   const uint2 *block_meta;
   const uint32_t *spin_of_pos;
+  const double *field_of_pos;
   const uint32_t *ell_col;
   const double *ell_val;
   const uint32_t *status;
-  const double *field;  // [K] original order
   const double *betas;  // all sweeps of the call
   const uint64_t *x0;   // packed original-order start configuration or nullptr
   uint8_t *state;       // [groups][K] bit m = chain m of the group is -1 (between chunks)
@@ -395,8 +400,137 @@ __device__ __forceinline__ void snapshot_original(const uint8_t *spins, const Sh
   }
 }
 
+// ---- the row sums of one quad, in two pinned stages ----
+// This kernel runs ONE or two wavefronts per SIMD (the levels of a sweep are short), so what
+// the instruction stream of a single wavefront looks like matters: with the register budget of
+// <= 2 wavefronts per SIMD hipcc hoists the sign instructions of later terms over the FMAs of
+// earlier ones and pays a register copy per term and chain (the multiplier's high word is
+// rewritten in place).  Signs and FMAs are therefore volatile asm in source order, and the LDS
+// gather of a quad is a stage of its own, issued one quad ahead of its use.
+// One quad of the sweep's ELL through BUFFER loads: the address is (resource: the sweep's
+// array, uniform) + (scalar offset: the quad) + (lane * 16), so a load costs no vector
+// address arithmetic — with global loads hipcc spends a 64-bit VALU add per load, and this kernel
+// issues up to 36 of them per block visit on its critical path.
+using BufferRsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ BufferRsrc make_rsrc(const void *base) {
+  // raw buffer, no range checking to speak of (4 GiB), gfx9 DATA_FORMAT word
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0xFFFFFFFF, 0x00020000);
+}
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+// Four consecutive ELL entries of one lane as the three loads deliver them (native vectors: a
+// bit cast, no component shuffling — a shuffle would have to wait for the load)
+struct HeldQuad {
+  u32x4 c;
+  f64x2 v01, v23;
+};
+__device__ __forceinline__ void load_quad_buffer(HeldQuad &q, BufferRsrc cols, BufferRsrc vals, uint32_t quad,
+                                                 uint32_t lane16) {
+  q.c = __builtin_amdgcn_raw_buffer_load_b128(cols, lane16, quad * 1024u, 0);
+  q.v01 = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(vals, lane16, quad * 2048u, 0));
+  q.v23 = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(vals, lane16 + 1024u, quad * 2048u, 0));
+}
+
+template <int LAYOUT>
+__device__ __forceinline__ void gather_quad(const HeldQuad &q, uint32_t (&s)[4]) {
+  const uint32_t cs[4] = {q.c.x, q.c.y, q.c.z, q.c.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    // columns are LDS byte addresses (sa_device.hpp: the spins start at LDS address 0)
+    if constexpr (LAYOUT == kWide) {
+      s[j] = *reinterpret_cast<LdsWord *>(static_cast<uintptr_t>(cs[j]));
+    } else {
+      s[j] = *reinterpret_cast<LdsByte *>(static_cast<uintptr_t>(cs[j]));
+    }
+  }
+}
+
+// high word of +-1.0 from byte m of a wide spin word, in place (see wide_factor)
+#define ASP_SDWA_SIGN(sel)                                                                         \
+  asm volatile("v_or_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD " \
+               "src1_sel:" sel : "+v"(hi) : "v"(0x3Fu), "v"(word))
+__device__ __forceinline__ double pinned_wide_factor(uint32_t word, int m, uint32_t &hi) {
+  switch (m) {
+    case 0: ASP_SDWA_SIGN("BYTE_0"); break;
+    case 1: ASP_SDWA_SIGN("BYTE_1"); break;
+    case 2: ASP_SDWA_SIGN("BYTE_2"); break;
+    default: ASP_SDWA_SIGN("BYTE_3"); break;
+  }
+  return __hiloint2double(static_cast<int>(hi), 0);
+}
+#undef ASP_SDWA_SIGN
+
 template <int M, int LAYOUT>
-__global__ __launch_bounds__(1024) void k_sa_sweep_shuffled(ShuffledArgs a) {
+__device__ __forceinline__ void apply_quad(const HeldQuad &q, const uint32_t (&s)[4], double (&acc)[M],
+                                           uint32_t (&one_hi)[4]) {
+  const double vs[4] = {q.v01.x, q.v01.y, q.v23.x, q.v23.y};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    // four chains at a time: their signs, then their FMAs (no FMA directly behind the
+    // instruction that builds its multiplier); each acc[m] receives its terms in ascending k
+#pragma unroll
+    for (int m0 = 0; m0 < M; m0 += 4) {
+      double f[4];
+#pragma unroll
+      for (int m = m0; m < M && m < m0 + 4; ++m) {
+        if constexpr (LAYOUT == kWide) {
+          f[m - m0] = pinned_wide_factor(s[j], m, one_hi[m & 3]);
+        } else {
+          uint32_t hi;
+          if (m == 0) {
+            asm volatile("v_lshl_or_b32 %0, %1, 31, %2" : "=v"(hi) : "v"(s[j]), "s"(0x3FF00000u));
+          } else {
+            // bit m to bit 0 with a RIGHT shift (a plain VOP2), then the m = 0 instruction
+            uint32_t down;
+            asm volatile("v_lshrrev_b32 %0, %1, %2" : "=v"(down) : "v"(static_cast<uint32_t>(m)), "v"(s[j]));
+            asm volatile("v_lshl_or_b32 %0, %1, 31, %2" : "=v"(hi) : "v"(down), "s"(0x3FF00000u));
+          }
+          f[m - m0] = __hiloint2double(static_cast<int>(hi), 0);
+        }
+      }
+#pragma unroll
+      for (int m = m0; m < M && m < m0 + 4; ++m) {
+        asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(acc[m]) : "v"(vs[j]), "v"(f[m - m0]));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Timing-only ablations (results are WRONG when set; never set in the product build):
+// 1 no row sums, 2 no accept phase, 3 no coupling loads, 4 no level barriers, 5 a cheap hash for
+// Philox, 6 a cheap compare for the exp filter
+#ifndef ASP_SHUF_ABL
+#define ASP_SHUF_ABL 0
+#endif
+
+// Development aid (-DASP_SHUF_TIMING=1): every wavefront of workgroup 0 adds up the shader-clock
+// cycles it spends in the row sums, the request, the accept phase, the level barriers and the
+// per-sweep bookkeeping; the totals land behind the status words (tools/time_shuffled.py --timing).
+#ifndef ASP_SHUF_TIMING
+#define ASP_SHUF_TIMING 0
+#endif
+#if ASP_SHUF_TIMING
+#define ASP_TICK(slot)                                  \
+  do {                                                  \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    ticks[slot] += now_ - tick_last;                    \
+    tick_last = now_;                                   \
+  } while (0)
+#else
+#define ASP_TICK(slot) do {} while (0)
+#endif
+
+constexpr uint32_t kNoBlock = 0xFFFFFFFFu;
+constexpr int kHeldQuads = 12;  // quads of a block kept in registers (wider blocks stream the rest)
+
+// The loads of a block do not depend on the spins, so a wavefront fetches its NEXT block — of this
+// level or of the next one — while it finishes the current one: the quads of the next block are
+// requested as soon as the k-loop has consumed the registers that held the current block's, and
+// arrive during the accept phase and the level barrier.  Per level the critical path is then
+// LDS gathers + FMAs + accept, not a chain of global-memory round trips.
+template <int M, int LAYOUT>
+__global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
   constexpr bool WIDE = LAYOUT == kWide;
   static_assert(LAYOUT == kWide || LAYOUT == kBytes, "spins are LDS words or LDS bytes");
   static_assert(!WIDE || M <= 4, "the wide layout holds up to four chains");
@@ -414,6 +548,11 @@ __global__ __launch_bounds__(1024) void k_sa_sweep_shuffled(ShuffledArgs a) {
   long long *delta = reinterpret_cast<long long *>(lds + P);  // [8] energy change of the running sweep
   long long *book = delta + 8;  // [m] current tracked energy, [8 + m] best, [16 + m] accepted flips
   uint32_t *improved_flag = reinterpret_cast<uint32_t *>(book + 24);
+  // the running sweep's tables, copied from HBM once per sweep (they were written by another
+  // kernel, possibly on another XCD: a scalar load of one entry is a full memory round trip,
+  // and the level loop would pay two of them per level)
+  uint2 *meta = reinterpret_cast<uint2 *>(improved_flag + 4);             // [block_cap]
+  uint32_t *level_block = reinterpret_cast<uint32_t *>(meta + a.block_cap);  // [level_cap + 2]
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), waves = blockDim.x >> 6;
   const uint32_t group = blockIdx.x;
@@ -467,15 +606,26 @@ __global__ __launch_bounds__(1024) void k_sa_sweep_shuffled(ShuffledArgs a) {
   }
 
   uint32_t one_hi[4] = {0x3FF00000u, 0x3FF00000u, 0x3FF00000u, 0x3FF00000u};
+#if ASP_SHUF_TIMING
+  unsigned long long ticks[kTimingSlots] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tick_last = __builtin_readcyclecounter();
+#endif
   for (uint32_t tt = 0; tt < a.chunk_sweeps; ++tt) {
     const uint32_t t = a.first_sweep + tt;
     const double beta = a.betas[t];
-    const uint32_t *level_block = a.level_block + static_cast<uint64_t>(tt) * (a.level_cap + 1u);
-    const uint2 *meta = a.block_meta + static_cast<uint64_t>(tt) * a.block_cap;
+    const uint32_t levels = a.num_levels[tt];
+    {
+      const uint32_t *g_level_block = a.level_block + static_cast<uint64_t>(tt) * (a.level_cap + 1u);
+      const uint2 *g_meta = a.block_meta + static_cast<uint64_t>(tt) * a.block_cap;
+      for (uint32_t l = tid; l <= levels; l += blockDim.x) level_block[l] = g_level_block[l];
+      const uint32_t blocks = g_level_block[levels];
+      for (uint32_t b = tid; b < blocks; b += blockDim.x) meta[b] = g_meta[b];
+      __syncthreads();  // (the previous sweep's last use of the tables is behind its final barriers)
+    }
     const uint32_t *sop = a.spin_of_pos + static_cast<uint64_t>(tt) * a.block_cap * 64u;
+    const double *fop = a.field_of_pos + static_cast<uint64_t>(tt) * a.block_cap * 64u;
     const uint4 *ell_col = reinterpret_cast<const uint4 *>(a.ell_col) + static_cast<uint64_t>(tt) * a.quad_stride * 64u;
     const double2 *ell_val = reinterpret_cast<const double2 *>(a.ell_val) + static_cast<uint64_t>(tt) * a.quad_stride * 128u;
-    const uint32_t levels = a.num_levels[tt];
     long long q_acc[M];
     uint32_t n_acc[M];
 #pragma unroll
@@ -483,90 +633,170 @@ __global__ __launch_bounds__(1024) void k_sa_sweep_shuffled(ShuffledArgs a) {
       q_acc[m] = 0;
       n_acc[m] = 0;
     }
-    uint32_t b_end = level_block[0];
+    // The block this wavefront holds in registers (requested one visit ahead): kNoBlock = none,
+    // then held_quads = 0 and every lane is a padding lane.
+    uint32_t held_quads = 0, held_spin = kDummySpin, held_first = 0;
+    double held_h = 0.0;
+    HeldQuad hq[kHeldQuads];
+    const BufferRsrc rsrc_col = make_rsrc(ell_col), rsrc_val = make_rsrc(ell_val);
+    const uint32_t lane16 = lane * 16u;
+    // requests everything of block `nb` that does not depend on other loads (ONE call site inside
+    // the loops, so that the registers of the quads are not duplicated)
+    auto request = [&](uint32_t nb) {
+      if (nb == kNoBlock) {
+        held_quads = 0;
+        held_spin = kDummySpin;
+        return;
+      }
+      const uint2 info = meta[nb];
+      held_quads = __builtin_amdgcn_readfirstlane(info.y);
+      held_first = __builtin_amdgcn_readfirstlane(info.x);
+      held_spin = sop[nb * 64u + lane];
+      held_h = fop[nb * 64u + lane];
+      // every register set is (re)defined by every request — those beyond the block's width
+      // with "any value" — so that nothing of the previous block stays live across the visit
+#pragma unroll
+      for (int j = 0; j < kHeldQuads; ++j) {
+        if (ASP_SHUF_ABL != 3 && static_cast<uint32_t>(j) < held_quads) {
+          load_quad_buffer(hq[j], rsrc_col, rsrc_val, held_first + static_cast<uint32_t>(j), lane16);
+        } else {
+          hq[j].c = __builtin_nondeterministic_value(hq[j].c);
+          hq[j].v01 = __builtin_nondeterministic_value(hq[j].v01);
+          hq[j].v23 = __builtin_nondeterministic_value(hq[j].v23);
+        }
+      }
+    };
+    uint32_t lb_begin = level_block[0];
+    uint32_t lb_end = level_block[levels ? 1u : 0u];
+    {
+      const uint32_t first = lb_begin + wave;
+      request(first < lb_end ? first : kNoBlock);
+    }
     for (uint32_t l = 0; l < levels; ++l) {
-      const uint32_t b_begin = b_end;
-      b_end = level_block[l + 1];
-      for (uint32_t b = b_begin + wave; b < b_end; b += waves) {
-        const uint2 info = meta[b];
-        const uint32_t quads = __builtin_amdgcn_readfirstlane(info.y);
-        const uint64_t first_quad = __builtin_amdgcn_readfirstlane(info.x);
-        const uint4 *cptr = ell_col + first_quad * 64u + lane;
-        const double2 *vptr = ell_val + first_quad * 128u + lane;
-        const uint32_t spin = sop[b * 64u + lane];
+      // the level after this one: its blocks are lb_end .. lb_after
+      const uint32_t lb_after = level_block[l + 2u <= levels ? l + 2u : levels];
+      uint32_t b = lb_begin + wave;
+      ASP_TICK(5);
+      for (;;) {
+        const bool busy = b < lb_end;  // (wave-uniform) the held block is block b of this level
+        // this wavefront's next block: the next round of this level, else its block of the next level
+        uint32_t nb = b + waves;
+        bool same_level = true;
+        if (!busy || nb >= lb_end) {
+          same_level = false;
+          nb = lb_end + wave;
+          if (nb >= lb_after) nb = kNoBlock;
+        }
+        const uint32_t spin = held_spin;
         const bool valid = spin != kDummySpin;
         const uint32_t me = valid ? spin : 0u;
-        const double h = a.field[me];
+        const double h = held_h;
         double acc[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[m] = 0.0;
-        // k-loop of csrc/sa_sweep.hip: the next quad's three 16-byte loads in flight while the
-        // current one is gathered from LDS and accumulated, in the order k = 0, 1, 2, ... of
-        // the row (= ascending column: the oracle's order); the last prefetch reads one quad past
-        // the block (the next block, or the slack behind the sweep's last one) and is never used
-        Quad qa, qb;
-        load_quad(qa, cptr, vptr, 0);
-        uint32_t i = 0;
-        for (; i + 2 <= quads; i += 2) {
-          load_quad(qb, cptr, vptr, i + 1);
-          __builtin_amdgcn_sched_barrier(0);
-          accumulate_quad<M, LAYOUT>(qa, spins, acc, one_hi);
-          __builtin_amdgcn_sched_barrier(0);
-          load_quad(qa, cptr, vptr, i + 2);
-          __builtin_amdgcn_sched_barrier(0);
-          accumulate_quad<M, LAYOUT>(qb, spins, acc, one_hi);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (i < quads) accumulate_quad<M, LAYOUT>(qa, spins, acc, one_hi);
-
-        const uint32_t own = WIDE ? wide[me] : static_cast<uint32_t>(spins[me]);
-        bool need = false;  // some proposal of this lane needs a random number
-        double de[M];
+        if (busy && ASP_SHUF_ABL != 1) {
+          const uint32_t quads = held_quads;
+          // the row sums in the order k = 0, 1, 2, ... of the row (= ascending column: the
+          // oracle's); the LDS gather of quad j + 1 is issued before the FMAs of quad j (past the
+          // block's last quad it reads whatever the registers held: harmless, never applied)
+          uint32_t sa[4], sb[4];
+          gather_quad<LAYOUT>(hq[0], sa);
 #pragma unroll
-        for (int m = 0; m < M; ++m) {
-          const double g = __dadd_rn(acc[m], h);
-          const bool negative = (own >> (WIDE ? 8 * m + 7 : m)) & 1u;  // s = -1
-          de[m] = __dmul_rn(negative ? 2.0 : -2.0, g);
-          // dE <= 0 is accepted and beta * dE >= 23 rejected whatever the draw
-          need = need || (valid && !(de[m] <= 0.0) && !(__dmul_rn(beta, de[m]) >= 23.0));
+          for (int j = 0; j < kHeldQuads; ++j) {
+            if (static_cast<uint32_t>(j) < quads) {
+              if (j + 1 < kHeldQuads) gather_quad<LAYOUT>(hq[j + 1], (j & 1) ? sa : sb);
+              __builtin_amdgcn_sched_barrier(0);
+              apply_quad<M, LAYOUT>(hq[j], (j & 1) ? sb : sa, acc, one_hi);
+            }
+          }
+          if (quads > static_cast<uint32_t>(kHeldQuads)) {
+            // a block wider than the registers hold (rows of more than 4 kHeldQuads couplings):
+            // the rest streams with one quad in flight
+            HeldQuad qa, qb;
+            load_quad_buffer(qa, rsrc_col, rsrc_val, held_first + kHeldQuads, lane16);
+            for (uint32_t j = kHeldQuads; j < quads; ++j) {
+              // (one quad past the block at the end: never used)
+              load_quad_buffer(qb, rsrc_col, rsrc_val, held_first + j + 1u, lane16);
+              __builtin_amdgcn_sched_barrier(0);
+              gather_quad<LAYOUT>(qa, sa);
+              apply_quad<M, LAYOUT>(qa, sa, acc, one_hi);
+              qa = qb;
+            }
+          }
         }
-        uint32_t flip = 0;
-        if (__ballot(need) != 0ull) {
-          Philox4 rnd{};
-          uint32_t have = 0xFFFFFFFFu;
+        ASP_TICK(0);
+        // the registers are free: the next block's loads fly during the accept phase and the barrier
+        // (a wavefront without a block in this level holds nothing and requests its block of the
+        // next level, if it has one there)
+        request(nb);
+        ASP_TICK(1);
+        if (busy && ASP_SHUF_ABL != 2) {
+          const uint32_t own = WIDE ? wide[me] : static_cast<uint32_t>(spins[me]);
+          bool need = false;  // some proposal of this lane needs a random number
+          double de[M];
 #pragma unroll
           for (int m = 0; m < M; ++m) {
-            const uint32_t r = r0 + m;
-            if (m == 0 || (r >> 2) != have) {
-              have = r >> 2;
-              rnd = philox4x32_10(spin, t, have, 0u, key0, key1);
+            const double g = __dadd_rn(acc[m], h);
+            const bool negative = (own >> (WIDE ? 8 * m + 7 : m)) & 1u;  // s = -1
+            de[m] = __dmul_rn(negative ? 2.0 : -2.0, g);
+            // dE <= 0 is accepted and beta * dE >= 23 rejected whatever the draw
+            need = need || (valid && !(de[m] <= 0.0) && !(__dmul_rn(beta, de[m]) >= 23.0));
+          }
+          uint32_t flip = 0;
+          if (__ballot(need) != 0ull) {
+            Philox4 rnd{};
+            uint32_t have = 0xFFFFFFFFu;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+              const uint32_t r = r0 + m;
+              if (m == 0 || (r >> 2) != have) {
+                have = r >> 2;
+#if ASP_SHUF_ABL == 5
+                rnd = Philox4{{spin * 2654435761u ^ t, spin ^ (t * 40503u), spin + have, t ^ key0}};
+#else
+                rnd = philox4x32_10(spin, t, have, 0u, key0, key1);
+#endif
+              }
+#if ASP_SHUF_ABL == 6
+              const bool accept = valid && (de[m] <= 0.0 || pick_word(rnd, r & 3u) <
+                                                                static_cast<uint32_t>(__dmul_rn(beta, de[m])));
+#else
+              const bool accept = valid && (de[m] <= 0.0 || metropolis_accept_word(pick_word(rnd, r & 3u),
+                                                                                   __dmul_rn(beta, de[m])));
+#endif
+              flip |= (accept ? 1u : 0u) << m;
             }
-            const bool accept = valid && (de[m] <= 0.0 || metropolis_accept_word(pick_word(rnd, r & 3u),
-                                                                                 __dmul_rn(beta, de[m])));
-            flip |= (accept ? 1u : 0u) << m;
-          }
-        } else {
-#pragma unroll
-          for (int m = 0; m < M; ++m) flip |= ((valid && de[m] <= 0.0) ? 1u : 0u) << m;
-        }
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-          if ((flip >> m) & 1u) {
-            // rint(dE * 2^S): |dE * 2^S| < 2^51 by the plan's S
-            q_acc[m] += __double_as_longlong(__dadd_rn(__dmul_rn(de[m], a.scale), 0x1.8p52)) -
-                        0x4338000000000000ll;
-            n_acc[m] += 1;
-          }
-        }
-        if (flip) {  // no neighbour of this spin is in the level: nobody reads it before the barrier
-          if constexpr (WIDE) {
-            wide[me] = own ^ spread_mask(flip);
           } else {
-            spins[me] = static_cast<uint8_t>(own ^ flip);
+#pragma unroll
+            for (int m = 0; m < M; ++m) flip |= ((valid && de[m] <= 0.0) ? 1u : 0u) << m;
+          }
+#pragma unroll
+          for (int m = 0; m < M; ++m) {
+            if ((flip >> m) & 1u) {
+              // rint(dE * 2^S): |dE * 2^S| < 2^51 by the plan's S
+              q_acc[m] += __double_as_longlong(__dadd_rn(__dmul_rn(de[m], a.scale), 0x1.8p52)) -
+                          0x4338000000000000ll;
+              n_acc[m] += 1;
+            }
+          }
+          if (flip) {  // no neighbour of this spin is in the level: nobody reads it before the barrier
+            if constexpr (WIDE) {
+              wide[me] = own ^ spread_mask(flip);
+            } else {
+              spins[me] = static_cast<uint8_t>(own ^ flip);
+            }
           }
         }
+        ASP_TICK(2);
+        if (!same_level) break;
+        b = nb;
       }
+#if ASP_SHUF_ABL != 4
       __syncthreads();
+#endif
+      ASP_TICK(3);
+      lb_begin = lb_end;
+      lb_end = lb_after;
     }
 
     // ---- exact (integer) reduction of the sweep's energy change ----
@@ -594,7 +824,15 @@ __global__ __launch_bounds__(1024) void k_sa_sweep_shuffled(ShuffledArgs a) {
     if (improved) snapshot_original<M, LAYOUT>(spins, a, group, improved);
     __syncthreads();
     if (tid == 0) *improved_flag = 0;  // next write to it is two barriers away
+    ASP_TICK(4);
   }
+#if ASP_SHUF_TIMING
+  if (group == 0 && lane == 0 && wave < kTimingWaves) {
+    unsigned long long *out = reinterpret_cast<unsigned long long *>(const_cast<uint32_t *>(a.status) + kStatWords) +
+                              wave * kTimingSlots;
+    for (uint32_t k = 0; k < kTimingSlots; ++k) atomicAdd(out + k, ticks[k]);
+  }
+#endif
 
   for (uint32_t i = tid; i < K; i += blockDim.x) {
     state[i] = static_cast<uint8_t>(from_lds<LAYOUT>(WIDE ? wide[i] : static_cast<uint32_t>(spins[i])));
@@ -627,8 +865,10 @@ ShuffledKernel shuffled_kernel_for(int m, bool wide) {
   }
 }
 
-size_t sweep_lds_bytes(uint64_t K, bool wide) {
-  return (((wide ? K * 4 : K) + 15) & ~size_t{15}) + 32 * sizeof(long long) + 16;
+// spins | delta[8] book[24] | flag (16 B) | meta[block_cap] | level_block[level_cap + 2]
+size_t sweep_lds_bytes(uint64_t K, bool wide, uint32_t level_cap, uint32_t block_cap) {
+  return (((wide ? K * 4 : K) + 15) & ~size_t{15}) + 32 * sizeof(long long) + 16 +
+         static_cast<size_t>(block_cap) * sizeof(uint2) + (static_cast<size_t>(level_cap) + 2) * sizeof(uint32_t);
 }
 
 size_t order_lds_bytes(uint32_t level_cap, uint32_t block_cap, uint32_t waves) {
@@ -670,7 +910,7 @@ int asp_sa_set_shuffled_launch(asp_sa_plan *p, int chains_per_group, int wavefro
   if (chains_per_group != 0 && !shuffled_kernel_for(chains_per_group, false)) {
     return asp::set_error(ASP_ERR_INVALID, "chains_per_group must be 0, 1, 2, 4 or 8");
   }
-  if (wavefronts < 0 || wavefronts > 16) return asp::set_error(ASP_ERR_INVALID, "wavefronts must be 0..16");
+  if (wavefronts < 0 || wavefronts > 8) return asp::set_error(ASP_ERR_INVALID, "wavefronts must be 0..8");
   p->shuffled_m = chains_per_group;
   p->shuffled_waves = wavefronts;
   return ASP_OK;
@@ -706,10 +946,6 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
     for (uint32_t r = 0; r < repetitions; ++r) out_e[r] = 0.0;
     return ASP_OK;
   }
-  if (sweep_lds_bytes(K, false) > p->max_lds) {
-    return asp::set_error(ASP_ERR_TOO_LARGE, "the shuffled sweep keeps a byte per spin in LDS: %llu "
-                                             "spins do not fit", (unsigned long long)K);
-  }
   ASP_TRY(ensure_static(p));
 
   // ---- launch geometry ----
@@ -725,7 +961,6 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
       }
     }
   }
-  const bool wide = m <= 4 && sweep_lds_bytes(K, true) <= p->max_lds;
   const double mean_degree = std::max(1.0, static_cast<double>(L.a_col.size()) / static_cast<double>(K));
   // levels of a sweep: the longest descending-priority path, about 2.5 x the mean degree on the
   // clusters of this problem (measured: 15 at degree 8, 51 at degree 20); the last call's count
@@ -735,16 +970,10 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
   if (!waves) {
     // a wavefront per block of an average level
     waves = static_cast<uint32_t>(std::ceil(static_cast<double>(K) / levels_guess / 64.0));
-    waves = std::max(1u, std::min(16u, waves));
+    waves = std::max(1u, std::min(8u, waves));
   }
   const uint32_t groups = (repetitions + m - 1) / m;
   const uint64_t padded = static_cast<uint64_t>(groups) * m;
-  const size_t lds = sweep_lds_bytes(K, wide);
-  ShuffledKernel kernel = shuffled_kernel_for(m, wide);
-  if (lds > 64 * 1024) {
-    ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-  }
 
   // ---- capacities of one sweep's order (grown and the call repeated if an order kernel says so) ----
   uint32_t level_cap = static_cast<uint32_t>(std::min<double>(static_cast<double>(K), 2.0 * levels_guess + 32.0));
@@ -777,6 +1006,7 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
   DeviceBuffer<uint32_t> d_status, d_prio, d_indeg, d_order;
   struct OrderSet {
     DeviceBuffer<uint32_t> level_block, num_levels, spin_of_pos;
+    DeviceBuffer<double> field_of_pos;
     DeviceBuffer<uint2> block_meta;
     DeviceBuffer<uint4> ell_col;
     DeviceBuffer<double2> ell_val;
@@ -792,7 +1022,7 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
   ASP_TRY(d_perm.alloc(static_cast<uint64_t>(repetitions) * L.num_blocks));
   ASP_TRY(d_partial.alloc(static_cast<uint64_t>(repetitions) * L.num_blocks));
   ASP_TRY(d_e.alloc(repetitions));
-  ASP_TRY(d_status.alloc(kStatWords));
+  ASP_TRY(d_status.alloc(kStatWords + 2 * kTimingSlots * kTimingWaves));
   ASP_TRY(d_betas.upload(betas, num_sweeps, s));
   if (x0) {
     ASP_TRY(d_x0.alloc(words));
@@ -804,6 +1034,18 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
   uint32_t status[kStatWords] = {0, 0, 0, 0};
   for (int attempt = 0;; ++attempt) {
     const uint32_t block_cap = words + level_cap;
+    // a word per spin (the one-instruction sign) when that fits the LDS beside the sweep's tables
+    const bool wide = m <= 4 && sweep_lds_bytes(K, true, level_cap, block_cap) <= p->max_lds;
+    const size_t lds = sweep_lds_bytes(K, wide, level_cap, block_cap);
+    if (lds > p->max_lds) {
+      return asp::set_error(ASP_ERR_TOO_LARGE, "the shuffled sweep keeps a byte per spin in LDS: %llu "
+                                               "spins do not fit", (unsigned long long)K);
+    }
+    ShuffledKernel kernel = shuffled_kernel_for(m, wide);
+    if (lds > 64 * 1024) {
+      ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    }
     if (!quad_cap) {
       // exact class sort (rows below 63 quads): a block is no wider than every row of the block
       // before it in its level, so the blocks hold at most (sum of the row quads) / 64 + one
@@ -813,8 +1055,8 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
       const uint64_t loose = static_cast<uint64_t>(block_cap) * max_quads;
       quad_cap = static_cast<uint32_t>(std::min<uint64_t>(max_quads < kClassCap ? tight : loose, 0x7FFFFFFFull));
     }
-    const uint32_t quad_alloc = quad_cap + 2;  // slack: the sweep kernel's prefetch reads one quad too far
-    const uint64_t per_sweep = static_cast<uint64_t>(quad_alloc) * 64 * 48 + static_cast<uint64_t>(block_cap) * (256 + 8) +
+    const uint32_t quad_alloc = quad_cap + 2;  // slack: the sweep kernel reads one quad past a wide block
+    const uint64_t per_sweep = static_cast<uint64_t>(quad_alloc) * 64 * 48 + static_cast<uint64_t>(block_cap) * (768 + 8) +
                                (level_cap + 1ull) * 4 + 12ull * K;
     uint32_t chunk = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(256, budget / per_sweep)));
     chunk = std::max(1u, std::min(chunk, (num_sweeps + 3) / 4));  // at least four chunks: the pipeline needs them
@@ -837,10 +1079,11 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
       ASP_TRY(o.num_levels.ensure(chunk));
       ASP_TRY(o.block_meta.ensure(static_cast<uint64_t>(chunk) * block_cap));
       ASP_TRY(o.spin_of_pos.ensure(static_cast<uint64_t>(chunk) * block_cap * 64));
+      ASP_TRY(o.field_of_pos.ensure(static_cast<uint64_t>(chunk) * block_cap * 64));
       ASP_TRY(o.ell_col.ensure(static_cast<uint64_t>(chunk) * quad_alloc * 64));
       ASP_TRY(o.ell_val.ensure(static_cast<uint64_t>(chunk) * quad_alloc * 128));
     }
-    ASP_HIP_TRY(hipMemsetAsync(d_status.ptr, 0, kStatWords * sizeof(uint32_t), s));
+    ASP_HIP_TRY(hipMemsetAsync(d_status.ptr, 0, (kStatWords + 2 * kTimingSlots * kTimingWaves) * sizeof(uint32_t), s));
     ASP_HIP_TRY(hipEventRecord(p->ev[0], s));
     ASP_HIP_TRY(hipStreamWaitEvent(order_stream.stream, p->ev[0], 0));  // status zeroed, buffers ours
 
@@ -848,6 +1091,7 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
     oa.rq_ptr = p->rq_ptr.ptr;
     oa.rq_col = reinterpret_cast<const uint4 *>(p->rq_col.ptr);
     oa.rq_val = reinterpret_cast<const double2 *>(p->rq_val.ptr);
+    oa.field = p->field_dev.ptr;
     oa.seed = seed;
     oa.num_spins = static_cast<uint32_t>(K);
     oa.level_cap = level_cap;
@@ -862,7 +1106,6 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
     oa.status = d_status.ptr;
     ShuffledArgs a{};
     a.status = d_status.ptr;
-    a.field = p->field_dev.ptr;
     a.betas = d_betas.ptr;
     a.x0 = x0 ? d_x0.ptr : nullptr;
     a.state = d_state.ptr;
@@ -895,6 +1138,7 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
         oa.num_levels = o.num_levels.ptr;
         oa.block_meta = o.block_meta.ptr;
         oa.spin_of_pos = o.spin_of_pos.ptr;
+        oa.field_of_pos = o.field_of_pos.ptr;
         oa.ell_col = o.ell_col.ptr;
         oa.ell_val = o.ell_val.ptr;
         hipLaunchKernelGGL(k_shuffled_orders, dim3(now), dim3(order_threads), order_lds, order_stream.stream, oa);
@@ -906,6 +1150,7 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
       a.num_levels = o.num_levels.ptr;
       a.block_meta = o.block_meta.ptr;
       a.spin_of_pos = o.spin_of_pos.ptr;
+      a.field_of_pos = o.field_of_pos.ptr;
       a.ell_col = reinterpret_cast<const uint32_t *>(o.ell_col.ptr);
       a.ell_val = reinterpret_cast<const double *>(o.ell_val.ptr);
       a.first_sweep = done;
@@ -935,6 +1180,20 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
     }
   }
   p->last_shuffled_levels = static_cast<int>(status[kStatLevels]);
+#if ASP_SHUF_TIMING
+  {
+    unsigned long long host_ticks[kTimingSlots * kTimingWaves];
+    ASP_HIP_TRY(hipMemcpy(host_ticks, d_status.ptr + kStatWords, sizeof host_ticks, hipMemcpyDeviceToHost));
+    static const char *names[kTimingSlots] = {"row sums", "request", "accept", "barrier", "sweep end", "level head"};
+    for (uint32_t w = 0; w < waves && w < kTimingWaves; ++w) {
+      std::fprintf(stderr, "wave %u:", w);
+      for (uint32_t k = 0; k < kTimingSlots; ++k) {
+        std::fprintf(stderr, " %s %.3f Mcyc", names[k], static_cast<double>(host_ticks[w * kTimingSlots + k]) * 1e-6);
+      }
+      std::fprintf(stderr, "\n");
+    }
+  }
+#endif
 
   // energies of §4.6 from the packed best configurations
   ASP_TRY(asp::sa_permute_bits(p, d_best.ptr, repetitions, d_perm.ptr));

@@ -417,7 +417,7 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
                            uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0,
                            uint64_t *out_x, double *out_e);
 /* Launch geometry of the shuffled sweep (0 = automatic): chains per workgroup in {1,2,4,8} and
- * wavefronts per workgroup in 1..16.  Results never depend on it. */
+ * wavefronts per workgroup in 1..8.  Results never depend on it. */
 int asp_sa_set_shuffled_launch(asp_sa_plan *p, int chains_per_group, int wavefronts);
 /* Of the last asp_sa_anneal_shuffled call: the largest number of levels of a sweep. */
 int asp_sa_last_shuffled(asp_sa_plan const *p, uint32_t *levels, float *order_ms);
