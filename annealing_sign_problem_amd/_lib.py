@@ -51,6 +51,9 @@ class SaInfo(ctypes.Structure):
     ]
 
 
+SA_BATCH_SHUFFLED = 1  # asp.h: ASP_SA_BATCH_SHUFFLED
+
+
 class SaBatchItem(ctypes.Structure):
     """Mirror of ``asp_sa_batch_item`` (include/asp.h)."""
 
@@ -61,7 +64,7 @@ class SaBatchItem(ctypes.Structure):
         ("num_sweeps", c_u32),
         ("repetitions", c_u32),
         ("replica_offset", c_u32),
-        ("reserved", c_u32),
+        ("flags", c_u32),
         ("out_x", c_void_p),
         ("out_e", c_void_p),
     ]

@@ -177,6 +177,15 @@ class Hamiltonian:
         return out
 
 
+def resolve_sweep_order(sweep_order: Optional[str]) -> str:
+    """``"colour"`` or ``"shuffled"``; ``None`` reads ``$ASP_SWEEP_ORDER`` (default colour)."""
+    if sweep_order is None:
+        sweep_order = os.environ.get("ASP_SWEEP_ORDER") or "colour"
+    if sweep_order not in ("colour", "shuffled"):
+        raise ValueError("'sweep_order' must be 'colour' or 'shuffled'")
+    return sweep_order
+
+
 def _resolve_seed(seed) -> int:
     if seed is None:
         return int.from_bytes(os.urandom(8), "little")
@@ -205,7 +214,8 @@ def anneal_raw(hamiltonian: Hamiltonian, seed: int, betas: np.ndarray, repetitio
 
 
 def anneal_raw_into(hamiltonian: Hamiltonian, seed: int, betas: np.ndarray, repetitions: int,
-                    replica_offset: int, x0, out_x_ptr: int, out_e_ptr: int) -> None:
+                    replica_offset: int, x0, out_x_ptr: int, out_e_ptr: int,
+                    shuffled: bool = False) -> None:
     """``anneal_raw`` writing into caller-owned memory given as raw addresses — host or DEVICE
     (e.g. ``tensor.data_ptr()`` of torch tensors on this library's GPU): ``out_x`` receives
     ``repetitions * ceil(K/64)`` words, ``out_e`` ``repetitions`` doubles."""
@@ -215,15 +225,16 @@ def anneal_raw_into(hamiltonian: Hamiltonian, seed: int, betas: np.ndarray, repe
         x0 = np.ascontiguousarray(x0, dtype=np.uint64).reshape(-1)
         if x0.shape[0] != (hamiltonian.size + 63) // 64:
             raise ValueError("'x0' must have {} words".format((hamiltonian.size + 63) // 64))
-    _lib.check(lib.asp_sa_anneal(hamiltonian.plan(), ctypes.c_uint64(seed), _lib.ptr(betas),
-                                 ctypes.c_uint32(betas.shape[0]), ctypes.c_uint32(repetitions),
-                                 ctypes.c_uint32(replica_offset), _lib.ptr(x0),
-                                 ctypes.c_void_p(out_x_ptr), ctypes.c_void_p(out_e_ptr)))
+    entry = lib.asp_sa_anneal_shuffled if shuffled else lib.asp_sa_anneal
+    _lib.check(entry(hamiltonian.plan(), ctypes.c_uint64(seed), _lib.ptr(betas),
+                     ctypes.c_uint32(betas.shape[0]), ctypes.c_uint32(repetitions),
+                     ctypes.c_uint32(replica_offset), _lib.ptr(x0),
+                     ctypes.c_void_p(out_x_ptr), ctypes.c_void_p(out_e_ptr)))
 
 
 def anneal(hamiltonian: Hamiltonian, x0=None, seed=None, number_sweeps: int = 5120,
            beta0: Optional[float] = None, beta1: Optional[float] = None, repetitions: int = 1,
-           only_best: bool = True, distributed: bool = True, sweep_order: str = "colour"):
+           only_best: bool = True, distributed: bool = True, sweep_order: Optional[str] = None):
     """Simulated annealing of ``hamiltonian``.
 
     Returns ``(x, e)``: with ``only_best=True`` the best packed configuration
@@ -234,8 +245,9 @@ def anneal(hamiltonian: Hamiltonian, x0=None, seed=None, number_sweeps: int = 51
     ``sweep_order="colour"`` (default): the fixed colour order of specification ASP-SA-1.
     ``sweep_order="shuffled"``: a fresh random visiting order every sweep — what the reference's
     ``ising_glass_annealer`` does as far as its published success probabilities can tell
-    (DESIGN.md §6.1); statistically the library's behaviour, several times slower here and with
-    a LOWER success probability per sweep than the colour order.  Single process only.
+    (DESIGN.md §6.1); statistically the library's behaviour, a third to a quarter of the colour
+    order's rate here and with a LOWER success probability per sweep.  ``None``: the value of
+    ``$ASP_SWEEP_ORDER`` if set, else ``"colour"``.
 
     When ``torch.distributed`` is initialised with more than one rank (and
     ``distributed`` is true) the repetitions are sharded over the ranks and
@@ -249,10 +261,8 @@ def anneal(hamiltonian: Hamiltonian, x0=None, seed=None, number_sweeps: int = 51
         raise ValueError("'repetitions' must be positive")
     from . import distributed as _dist  # late import: torch is optional plumbing
 
-    if sweep_order not in ("colour", "shuffled"):
-        raise ValueError("'sweep_order' must be 'colour' or 'shuffled'")
-    shuffled = sweep_order == "shuffled"
-    sharded = distributed and _dist.shards_chains() and not shuffled
+    shuffled = resolve_sweep_order(sweep_order) == "shuffled"
+    sharded = distributed and _dist.shards_chains()
     seed = _dist.agree_on_seed(seed) if sharded else _resolve_seed(seed)
     if beta0 is None or beta1 is None:
         info = hamiltonian.info()
@@ -261,9 +271,9 @@ def anneal(hamiltonian: Hamiltonian, x0=None, seed=None, number_sweeps: int = 51
     betas = make_schedule(float(beta0), float(beta1), number_sweeps)
 
     if sharded and only_best:
-        return _dist.anneal_sharded_best(hamiltonian, seed, betas, repetitions, x0)
+        return _dist.anneal_sharded_best(hamiltonian, seed, betas, repetitions, x0, shuffled=shuffled)
     if sharded:
-        xs, es = _dist.anneal_sharded(hamiltonian, seed, betas, repetitions, x0)
+        xs, es = _dist.anneal_sharded(hamiltonian, seed, betas, repetitions, x0, shuffled=shuffled)
     else:
         xs, es = anneal_raw(hamiltonian, seed, betas, repetitions, 0, x0, shuffled=shuffled)
     if only_best:
@@ -272,11 +282,14 @@ def anneal(hamiltonian: Hamiltonian, x0=None, seed=None, number_sweeps: int = 51
     return xs, es
 
 
-def anneal_batch_raw(hamiltonians, seeds, schedules, repetitions, replica_offsets=None):
+def anneal_batch_raw(hamiltonians, seeds, schedules, repetitions, replica_offsets=None,
+                     shuffled: bool = False):
     """Many independent problems in ONE device call (``asp_sa_anneal_batch``): problem ``i`` is
     ``anneal_raw(hamiltonians[i], seeds[i], schedules[i], repetitions[i], replica_offsets[i])``,
     chain for chain, but the groups of all problems share a few launches, so a batch of small
-    clusters fills the chip.  Returns ``[(xs, es), ...]`` in order."""
+    clusters fills the chip.  ``shuffled``: every problem is an ``asp_sa_anneal_shuffled`` call
+    (a fresh visiting order every sweep); their kernels overlap on the problems' own streams.
+    Returns ``[(xs, es), ...]`` in order."""
     lib = _lib.load()
     n = len(hamiltonians)
     repetitions = [int(r) for r in (repetitions if np.ndim(repetitions) else [repetitions] * n)]
@@ -300,7 +313,7 @@ def anneal_batch_raw(hamiltonians, seeds, schedules, repetitions, replica_offset
         items[i].num_sweeps = betas.shape[0]
         items[i].repetitions = repetitions[i]
         items[i].replica_offset = offsets[i]
-        items[i].reserved = 0
+        items[i].flags = _lib.SA_BATCH_SHUFFLED if shuffled else 0
         items[i].out_x = xs.ctypes.data
         items[i].out_e = es.ctypes.data
     _lib.check(lib.asp_sa_anneal_batch(items, ctypes.c_uint32(n)))
@@ -309,7 +322,7 @@ def anneal_batch_raw(hamiltonians, seeds, schedules, repetitions, replica_offset
 
 def anneal_batch(hamiltonians, seed=None, number_sweeps: int = 5120, repetitions: int = 64,
                  only_best: bool = True, beta0: Optional[float] = None,
-                 beta1: Optional[float] = None):
+                 beta1: Optional[float] = None, sweep_order: Optional[str] = None):
     """``[anneal(h, seed=seed, number_sweeps=..., repetitions=..., only_best=...) for h in
     hamiltonians]`` in one device call — identical results (each problem keeps its own automatic
     ladder and the same chains), a fraction of the time for many small problems.  ``seed`` may be
@@ -335,7 +348,8 @@ def anneal_batch(hamiltonians, seed=None, number_sweeps: int = 5120, repetitions
             b0 = info.beta0_auto if b0 is None else b0
             b1 = info.beta1_auto if b1 is None else b1
         schedules.append(make_schedule(float(b0), float(b1), number_sweeps))
-    results = anneal_batch_raw(hamiltonians, seeds, schedules, [repetitions] * n)
+    results = anneal_batch_raw(hamiltonians, seeds, schedules, [repetitions] * n,
+                               shuffled=resolve_sweep_order(sweep_order) == "shuffled")
     if not only_best:
         return results
     best = []

@@ -233,12 +233,15 @@ def solve_ising_model(
     number_sweeps: int = 5120,
     repetitions: int = 64,
     only_best: bool = True,
+    sweep_order: Optional[str] = None,
 ) -> np.ndarray:
     """Optimise the signs of ``model`` and project them onto ``frozen_spins``
-    (common.py:232-261)."""
+    (common.py:232-261).  ``sweep_order`` (not in the reference): ``"colour"``, the fixed order
+    of this package's default annealer, or ``"shuffled"``, a fresh random order every sweep as
+    in the reference's annealer (``sa.anneal``); ``None`` = ``$ASP_SWEEP_ORDER`` or colour."""
     if mode == "sa":
         x, _ = sa.anneal(model.ising_hamiltonian, seed=seed, number_sweeps=number_sweeps,
-                         repetitions=repetitions, only_best=only_best)
+                         repetitions=repetitions, only_best=only_best, sweep_order=sweep_order)
     elif mode == "greedy":
         x, _ = sa.greedy_solve(model.ising_hamiltonian)
     else:
@@ -257,7 +260,7 @@ def _project_on_frozen(model: IsingModel, x: np.ndarray, frozen_spins) -> np.nda
 
 
 def solve_ising_models(models, frozen_spins=None, seed: int = 12345, number_sweeps: int = 5120,
-                       repetitions: int = 64):
+                       repetitions: int = 64, sweep_order: Optional[str] = None):
     """``[solve_ising_model(m, "sa", f, seed, number_sweeps, repetitions) for m, f in
     zip(models, frozen_spins)]`` with all annealing chains of all models in ONE device call
     (``sa.anneal_batch``): the same result for every model, at the throughput of a full chip
@@ -265,7 +268,8 @@ def solve_ising_models(models, frozen_spins=None, seed: int = 12345, number_swee
     models = list(models)
     frozen = [None] * len(models) if frozen_spins is None else list(frozen_spins)
     best = sa.anneal_batch([m.ising_hamiltonian for m in models], seed=seed,
-                           number_sweeps=number_sweeps, repetitions=repetitions, only_best=True)
+                           number_sweeps=number_sweeps, repetitions=repetitions, only_best=True,
+                           sweep_order=sweep_order)
     return [_project_on_frozen(m, x, f) for m, (x, _), f in zip(models, best, frozen)]
 
 

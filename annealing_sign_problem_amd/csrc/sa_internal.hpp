@@ -78,4 +78,8 @@ int sa_permute_bits(asp_sa_plan *p, const uint64_t *x, uint32_t count, uint64_t 
 int sa_energies_of_perm(asp_sa_plan *p, const uint64_t *perm, uint32_t count, double *partial,
                         double *out_e);
 
+// asp_sa_anneal_batch's items with ASP_SA_BATCH_SHUFFLED set (csrc/sa_shuffled.hip): items[which[k]],
+// k < count; adds the device time of their sweeps to *sweep_ms.
+int sa_shuffled_batch(asp_sa_batch_item const *items, const uint32_t *which, uint32_t count, float *sweep_ms);
+
 }  // namespace asp

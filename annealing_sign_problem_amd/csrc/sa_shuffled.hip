@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <memory>
 #include <vector>
 
 #include "asp_common.hpp"
@@ -901,103 +902,33 @@ int ensure_static(asp_sa_plan *p) {
   return ASP_OK;
 }
 
-}  // namespace
+// ---------------------------------------------------------------------------
+// One call = one ShuffledRun: set-up, then attempts (enqueue everything, collect the status
+// words; an order kernel that ran out of room makes the run grow its capacities and try again
+// from the chains' initial configurations), then the energies and the copies to the caller.
+// asp_sa_anneal_shuffled drives one run; the batched entry point enqueues the attempts of many
+// runs — each on its plan's own stream pair — before it waits for any of them, so a batch of
+// small clusters overlaps on the device.
+// ---------------------------------------------------------------------------
+struct ShuffledRun {
+  asp_sa_plan *p = nullptr;
+  uint64_t seed = 0;
+  const double *betas = nullptr;
+  uint32_t num_sweeps = 0, repetitions = 0, replica_offset = 0;
+  const uint64_t *x0 = nullptr;
+  uint64_t *out_x = nullptr;
+  double *out_e = nullptr;
+  uint64_t budget = 3ull << 30;  // bytes of visiting orders per buffer set
 
-extern "C" {
+  uint64_t K = 0;
+  uint32_t words = 0, groups = 0, waves = 1, level_cap = 0, quad_cap = 0, order_threads = 64, lanes_per_row = 1;
+  uint64_t padded = 0;
+  int m = 1, attempt = 0;
+  bool trivial = false;  // nothing to launch (no spins or no chains)
+  uint32_t status[kStatWords] = {0, 0, 0, 0};
 
-int asp_sa_set_shuffled_launch(asp_sa_plan *p, int chains_per_group, int wavefronts) {
-  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
-  if (chains_per_group != 0 && !shuffled_kernel_for(chains_per_group, false)) {
-    return asp::set_error(ASP_ERR_INVALID, "chains_per_group must be 0, 1, 2, 4 or 8");
-  }
-  if (wavefronts < 0 || wavefronts > 8) return asp::set_error(ASP_ERR_INVALID, "wavefronts must be 0..8");
-  p->shuffled_m = chains_per_group;
-  p->shuffled_waves = wavefronts;
-  return ASP_OK;
-}
-
-int asp_sa_last_shuffled(asp_sa_plan const *p, uint32_t *levels, float *order_ms) {
-  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
-  if (levels) *levels = static_cast<uint32_t>(p->last_shuffled_levels);
-  if (order_ms) *order_ms = p->last_order_ms;
-  return ASP_OK;
-}
-
-int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_sweeps,
-                           uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0,
-                           uint64_t *out_x, double *out_e) {
-  asp_clear_error();
-  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
-  ASP_TRY(asp::bind_device());
-  if (repetitions == 0) return ASP_OK;
-  if (!out_x || !out_e || (num_sweeps && !betas)) return asp::set_error(ASP_ERR_INVALID, "null argument");
-  if (num_sweeps >= 0xFFFFFFFEu) return asp::set_error(ASP_ERR_INVALID, "num_sweeps too large");
-  if (static_cast<uint64_t>(replica_offset) + repetitions + 8 > 0xFFFFFFFFull) {
-    return asp::set_error(ASP_ERR_INVALID, "replica ids exceed 32 bits");
-  }
-  for (uint32_t t = 0; t < num_sweeps; ++t) {
-    if (!(betas[t] >= 0.0)) return asp::set_error(ASP_ERR_INVALID, "betas[%u] is not >= 0", t);
-  }
-  const asp::SaHostLayout &L = p->host;
-  const uint64_t K = L.num_spins;
-  const uint32_t words = static_cast<uint32_t>((K + 63) / 64);
-  p->last_sweep_ms = p->last_total_ms = p->last_order_ms = 0.0f;
-  if (K == 0) {
-    for (uint32_t r = 0; r < repetitions; ++r) out_e[r] = 0.0;
-    return ASP_OK;
-  }
-  ASP_TRY(ensure_static(p));
-
-  // ---- launch geometry ----
-  // chains per workgroup: as many as still leave a workgroup per compute unit
-  int m = 1;
-  if (p->shuffled_m) {
-    m = p->shuffled_m;
-  } else {
-    for (int cand : {8, 4, 2}) {
-      if ((repetitions + cand - 1) / cand >= static_cast<uint32_t>(p->num_cus)) {
-        m = cand;
-        break;
-      }
-    }
-  }
-  const double mean_degree = std::max(1.0, static_cast<double>(L.a_col.size()) / static_cast<double>(K));
-  // levels of a sweep: the longest descending-priority path, about 2.5 x the mean degree on the
-  // clusters of this problem (measured: 15 at degree 8, 51 at degree 20); the last call's count
-  // when there is one
-  const double levels_guess = p->last_shuffled_levels > 0 ? p->last_shuffled_levels : 2.5 * mean_degree + 4.0;
-  uint32_t waves = static_cast<uint32_t>(p->shuffled_waves);
-  if (!waves) {
-    // a wavefront per block of an average level
-    waves = static_cast<uint32_t>(std::ceil(static_cast<double>(K) / levels_guess / 64.0));
-    waves = std::max(1u, std::min(8u, waves));
-  }
-  const uint32_t groups = (repetitions + m - 1) / m;
-  const uint64_t padded = static_cast<uint64_t>(groups) * m;
-
-  // ---- capacities of one sweep's order (grown and the call repeated if an order kernel says so) ----
-  uint32_t level_cap = static_cast<uint32_t>(std::min<double>(static_cast<double>(K), 2.0 * levels_guess + 32.0));
-  const uint32_t max_quads = p->rq_max_quads;
-  uint32_t quad_cap = 0;  // 0: derive from level_cap
-  const uint32_t order_threads = K >= 4096 ? kOrderThreads : (K >= 512 ? 256u : 64u);
-  const uint32_t lanes_per_row = std::min(64u, std::min(order_threads, next_pow2(std::max(
-      1u, static_cast<uint32_t>(std::ceil(mean_degree / 4.0))))));
-
-  hipStream_t s = p->stream;
   asp::ScopedStream order_stream;
-  ASP_TRY(order_stream.acquire());
-  struct Events {
-    hipEvent_t ordered[2] = {nullptr, nullptr}, swept[2] = {nullptr, nullptr};
-    ~Events() {
-      for (hipEvent_t e : ordered) if (e) (void)hipEventDestroy(e);
-      for (hipEvent_t e : swept) if (e) (void)hipEventDestroy(e);
-    }
-  } ev;
-  for (int i = 0; i < 2; ++i) {
-    ASP_HIP_TRY(hipEventCreateWithFlags(&ev.ordered[i], hipEventDisableTiming));
-    ASP_HIP_TRY(hipEventCreateWithFlags(&ev.swept[i], hipEventDisableTiming));
-  }
-
+  hipEvent_t ordered[2] = {nullptr, nullptr}, swept[2] = {nullptr, nullptr};
   DeviceBuffer<double> d_betas, d_partial, d_e;
   DeviceBuffer<uint64_t> d_x0, d_best, d_perm;
   DeviceBuffer<uint8_t> d_state;
@@ -1011,28 +942,108 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
     DeviceBuffer<uint4> ell_col;
     DeviceBuffer<double2> ell_val;
   } sets[2];
-  asp::StreamFence fence_orders(order_stream.stream);  // (declared after the buffers: waits first)
-  asp::StreamFence fence(s);
-  ASP_TRY(d_betas.alloc(num_sweeps));
-  ASP_TRY(d_state.alloc(static_cast<uint64_t>(groups) * K));
-  ASP_TRY(d_best.alloc(padded * words));
-  ASP_TRY(d_ecur.alloc(padded));
-  ASP_TRY(d_ebest.alloc(padded));
-  ASP_TRY(d_accepted.alloc(padded));
-  ASP_TRY(d_perm.alloc(static_cast<uint64_t>(repetitions) * L.num_blocks));
-  ASP_TRY(d_partial.alloc(static_cast<uint64_t>(repetitions) * L.num_blocks));
-  ASP_TRY(d_e.alloc(repetitions));
-  ASP_TRY(d_status.alloc(kStatWords + 2 * kTimingSlots * kTimingWaves));
-  ASP_TRY(d_betas.upload(betas, num_sweeps, s));
-  if (x0) {
-    ASP_TRY(d_x0.alloc(words));
-    ASP_TRY(d_x0.upload(x0, words, s));
-  }
-  uint64_t budget = 3ull << 30;  // bytes of visiting orders per buffer set
-  if (const char *env = std::getenv("ASP_SHUFFLED_BYTES")) budget = std::strtoull(env, nullptr, 10);
 
-  uint32_t status[kStatWords] = {0, 0, 0, 0};
-  for (int attempt = 0;; ++attempt) {
+  ShuffledRun() = default;
+  ShuffledRun(const ShuffledRun &) = delete;
+  ShuffledRun &operator=(const ShuffledRun &) = delete;
+  ~ShuffledRun() {
+    // (the buffers are released after this body: first wait for whatever still uses them)
+    if (order_stream.stream) (void)hipStreamSynchronize(order_stream.stream);
+    if (p && p->stream) (void)hipStreamSynchronize(p->stream);
+    for (hipEvent_t e : ordered) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : swept) if (e) (void)hipEventDestroy(e);
+  }
+
+  int setup() {
+    if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+    if (repetitions == 0) {
+      trivial = true;
+      return ASP_OK;
+    }
+    if (!out_x || !out_e || (num_sweeps && !betas)) return asp::set_error(ASP_ERR_INVALID, "null argument");
+    if (num_sweeps >= 0xFFFFFFFEu) return asp::set_error(ASP_ERR_INVALID, "num_sweeps too large");
+    if (static_cast<uint64_t>(replica_offset) + repetitions + 8 > 0xFFFFFFFFull) {
+      return asp::set_error(ASP_ERR_INVALID, "replica ids exceed 32 bits");
+    }
+    for (uint32_t t = 0; t < num_sweeps; ++t) {
+      if (!(betas[t] >= 0.0)) return asp::set_error(ASP_ERR_INVALID, "betas[%u] is not >= 0", t);
+    }
+    const asp::SaHostLayout &L = p->host;
+    K = L.num_spins;
+    words = static_cast<uint32_t>((K + 63) / 64);
+    p->last_sweep_ms = p->last_total_ms = p->last_order_ms = 0.0f;
+    if (K == 0) {
+      for (uint32_t r = 0; r < repetitions; ++r) out_e[r] = 0.0;  // (host pointers: nothing ran)
+      trivial = true;
+      return ASP_OK;
+    }
+    ASP_TRY(ensure_static(p));
+    // chains per workgroup: as many as still leave a workgroup per compute unit
+    m = 1;
+    if (p->shuffled_m) {
+      m = p->shuffled_m;
+    } else {
+      for (int cand : {8, 4, 2}) {
+        if ((repetitions + cand - 1) / cand >= static_cast<uint32_t>(p->num_cus)) {
+          m = cand;
+          break;
+        }
+      }
+    }
+    const double mean_degree = std::max(1.0, static_cast<double>(L.a_col.size()) / static_cast<double>(K));
+    // levels of a sweep: the longest descending-priority path, about 2.5 x the mean degree on
+    // the clusters of this problem (measured: 29 at degree 8, 59-69 at degree 23); the last
+    // call's count when there is one
+    const double levels_guess = p->last_shuffled_levels > 0 ? p->last_shuffled_levels : 2.5 * mean_degree + 4.0;
+    waves = static_cast<uint32_t>(p->shuffled_waves);
+    if (!waves) {
+      // a wavefront per block of an average level, and one more: the first blocks of a level are
+      // its widest (K = 12 870: 4 blocks per level, 4 -> 8 wavefronts +6 %)
+      waves = static_cast<uint32_t>(std::ceil(static_cast<double>(K) / levels_guess / 64.0)) + 1u;
+      waves = std::max(1u, std::min(8u, waves));
+    }
+    groups = (repetitions + m - 1) / m;
+    padded = static_cast<uint64_t>(groups) * m;
+    level_cap = static_cast<uint32_t>(std::min<double>(static_cast<double>(K), 2.0 * levels_guess + 32.0));
+    if (const char *env = std::getenv("ASP_SHUFFLED_LEVEL_CAP")) {  // test hook: provoke the retry
+      level_cap = std::max(1u, static_cast<uint32_t>(std::strtoul(env, nullptr, 10)));
+    }
+    quad_cap = 0;  // 0: derive from level_cap
+    order_threads = K >= 4096 ? kOrderThreads : (K >= 512 ? 256u : 64u);
+    lanes_per_row = std::min(64u, std::min(order_threads, next_pow2(std::max(
+        1u, static_cast<uint32_t>(std::ceil(mean_degree / 4.0))))));
+    if (const char *env = std::getenv("ASP_SHUFFLED_BYTES")) budget = std::strtoull(env, nullptr, 10);
+
+    ASP_TRY(order_stream.acquire());
+    for (int i = 0; i < 2; ++i) {
+      ASP_HIP_TRY(hipEventCreateWithFlags(&ordered[i], hipEventDisableTiming));
+      ASP_HIP_TRY(hipEventCreateWithFlags(&swept[i], hipEventDisableTiming));
+    }
+    hipStream_t s = p->stream;
+    ASP_TRY(d_betas.alloc(num_sweeps));
+    ASP_TRY(d_state.alloc(static_cast<uint64_t>(groups) * K));
+    ASP_TRY(d_best.alloc(padded * words));
+    ASP_TRY(d_ecur.alloc(padded));
+    ASP_TRY(d_ebest.alloc(padded));
+    ASP_TRY(d_accepted.alloc(padded));
+    ASP_TRY(d_perm.alloc(static_cast<uint64_t>(repetitions) * L.num_blocks));
+    ASP_TRY(d_partial.alloc(static_cast<uint64_t>(repetitions) * L.num_blocks));
+    ASP_TRY(d_e.alloc(repetitions));
+    ASP_TRY(d_status.alloc(kStatWords + 2 * kTimingSlots * kTimingWaves));
+    ASP_TRY(d_betas.upload(betas, num_sweeps, s));
+    if (x0) {
+      ASP_TRY(d_x0.alloc(words));
+      ASP_TRY(d_x0.upload(x0, words, s));
+    }
+    return ASP_OK;
+  }
+
+  // Queues one whole attempt (all chunks) on the two streams; returns without waiting.
+  int enqueue() {
+    if (trivial) return ASP_OK;
+    const asp::SaHostLayout &L = p->host;
+    hipStream_t s = p->stream;
+    const uint32_t max_quads = p->rq_max_quads;
     const uint32_t block_cap = words + level_cap;
     // a word per spin (the one-instruction sign) when that fits the LDS beside the sweep's tables
     const bool wide = m <= 4 && sweep_lds_bytes(K, true, level_cap, block_cap) <= p->max_lds;
@@ -1053,7 +1064,7 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
       const uint64_t tight = (static_cast<uint64_t>(p->rq_quads) + 63) / 64 +
                              static_cast<uint64_t>(level_cap) * max_quads;
       const uint64_t loose = static_cast<uint64_t>(block_cap) * max_quads;
-      quad_cap = static_cast<uint32_t>(std::min<uint64_t>(max_quads < kClassCap ? tight : loose, 0x7FFFFFFFull));
+      quad_cap = static_cast<uint32_t>(std::min<uint64_t>(max_quads < kClassCap ? tight : loose, 0x1FFFFFull));
     }
     const uint32_t quad_alloc = quad_cap + 2;  // slack: the sweep kernel reads one quad past a wide block
     const uint64_t per_sweep = static_cast<uint64_t>(quad_alloc) * 64 * 48 + static_cast<uint64_t>(block_cap) * (768 + 8) +
@@ -1130,8 +1141,8 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
       OrderSet &o = sets[nsets == 2 ? which : 0];
       if (now) {
         // the orders of this chunk: after the sweep kernel of two chunks ago has let go of the set
-        if (turn >= 2) ASP_HIP_TRY(hipStreamWaitEvent(order_stream.stream, ev.swept[which], 0));
-        // (one scratch area: order kernels of consecutive chunks run one after the other anyway)
+        // (one scratch area: the order kernels of consecutive chunks run one after the other)
+        if (turn >= 2) ASP_HIP_TRY(hipStreamWaitEvent(order_stream.stream, swept[which], 0));
         oa.first_sweep = done;
         oa.count = now;
         oa.level_block = o.level_block.ptr;
@@ -1143,8 +1154,8 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
         oa.ell_val = o.ell_val.ptr;
         hipLaunchKernelGGL(k_shuffled_orders, dim3(now), dim3(order_threads), order_lds, order_stream.stream, oa);
         ASP_HIP_TRY(hipGetLastError());
-        ASP_HIP_TRY(hipEventRecord(ev.ordered[which], order_stream.stream));
-        ASP_HIP_TRY(hipStreamWaitEvent(s, ev.ordered[which], 0));
+        ASP_HIP_TRY(hipEventRecord(ordered[which], order_stream.stream));
+        ASP_HIP_TRY(hipStreamWaitEvent(s, ordered[which], 0));
       }
       a.level_block = o.level_block.ptr;
       a.num_levels = o.num_levels.ptr;
@@ -1158,64 +1169,174 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
       a.initialise = first_launch ? 1u : 0u;
       hipLaunchKernelGGL(kernel, dim3(groups), dim3(waves * 64), lds, s, a);
       ASP_HIP_TRY(hipGetLastError());
-      ASP_HIP_TRY(hipEventRecord(ev.swept[which], s));
+      ASP_HIP_TRY(hipEventRecord(swept[which], s));
       first_launch = false;
     }
     ASP_HIP_TRY(hipEventRecord(p->ev[2], s));
     ASP_HIP_TRY(hipMemcpyAsync(status, d_status.ptr, sizeof status, hipMemcpyDeviceToHost, s));
-    ASP_HIP_TRY(hipStreamSynchronize(s));
+    return ASP_OK;
+  }
+
+  // Waits for the attempt; *again = true when the capacities had to grow and the attempt must be
+  // repeated (chains restart from their initial configuration; results do not depend on the
+  // capacities).
+  int collect(bool *again) {
+    *again = false;
+    if (trivial) return ASP_OK;
+    ASP_HIP_TRY(hipStreamSynchronize(p->stream));
     ASP_HIP_TRY(hipStreamSynchronize(order_stream.stream));
-    if (status[kStatBad] == 0) break;
-    if (attempt >= 4) {
+    if (status[kStatBad] == 0) return ASP_OK;
+    if (++attempt > 4) {
       return asp::set_error(ASP_ERR_TOO_LARGE, "visiting orders of %u levels / %u quads per sweep do not fit",
                             status[kStatLevels], status[kStatQuads]);
     }
-    // an order kernel needed more levels or quads than provided: grow and run the call again
-    // (chains restart from their initial configuration; results do not depend on the capacities)
     if (status[kStatLevels] > level_cap) {
       level_cap = static_cast<uint32_t>(std::min<uint64_t>(K, 2ull * status[kStatLevels] + 16));
       quad_cap = 0;
     } else {
-      quad_cap = static_cast<uint32_t>(std::min<uint64_t>(0x7FFFFFFFull, 2ull * std::max(status[kStatQuads], quad_cap)));
+      quad_cap = static_cast<uint32_t>(std::min<uint64_t>(0x1FFFFFull, 2ull * std::max(status[kStatQuads], quad_cap)));
     }
+    *again = true;
+    return ASP_OK;
   }
-  p->last_shuffled_levels = static_cast<int>(status[kStatLevels]);
-#if ASP_SHUF_TIMING
-  {
-    unsigned long long host_ticks[kTimingSlots * kTimingWaves];
-    ASP_HIP_TRY(hipMemcpy(host_ticks, d_status.ptr + kStatWords, sizeof host_ticks, hipMemcpyDeviceToHost));
-    static const char *names[kTimingSlots] = {"row sums", "request", "accept", "barrier", "sweep end", "level head"};
-    for (uint32_t w = 0; w < waves && w < kTimingWaves; ++w) {
-      std::fprintf(stderr, "wave %u:", w);
-      for (uint32_t k = 0; k < kTimingSlots; ++k) {
-        std::fprintf(stderr, " %s %.3f Mcyc", names[k], static_cast<double>(host_ticks[w * kTimingSlots + k]) * 1e-6);
-      }
-      std::fprintf(stderr, "\n");
-    }
-  }
-#endif
 
-  // energies of §4.6 from the packed best configurations
-  ASP_TRY(asp::sa_permute_bits(p, d_best.ptr, repetitions, d_perm.ptr));
-  ASP_TRY(asp::sa_energies_of_perm(p, d_perm.ptr, repetitions, d_partial.ptr, d_e.ptr));
-  ASP_HIP_TRY(hipEventRecord(p->ev[3], s));
-  ASP_HIP_TRY(hipMemcpyAsync(out_x, d_best.ptr, static_cast<uint64_t>(repetitions) * words * sizeof(uint64_t),
-                             hipMemcpyDefault, s));
-  ASP_HIP_TRY(hipMemcpyAsync(out_e, d_e.ptr, repetitions * sizeof(double), hipMemcpyDefault, s));
-  p->last_tracked.assign(repetitions, 0);
-  p->last_accepted.assign(repetitions, 0);
-  ASP_HIP_TRY(hipMemcpyAsync(p->last_tracked.data(), d_ebest.ptr, repetitions * sizeof(int64_t),
-                             hipMemcpyDeviceToHost, s));
-  ASP_HIP_TRY(hipMemcpyAsync(p->last_accepted.data(), d_accepted.ptr, repetitions * sizeof(uint64_t),
-                             hipMemcpyDeviceToHost, s));
-  ASP_HIP_TRY(hipStreamSynchronize(s));
-  p->last_m = m;
-  p->last_layout = 5;
-  p->last_threads = static_cast<int>(waves * 64);
-  p->last_groups = static_cast<int>(groups);
-  ASP_HIP_TRY(hipEventElapsedTime(&p->last_sweep_ms, p->ev[0], p->ev[2]));
-  ASP_HIP_TRY(hipEventElapsedTime(&p->last_total_ms, p->ev[0], p->ev[3]));
+  // Energies of §4.6 from the packed best configurations and the copies to the caller (queued).
+  int finish_enqueue() {
+    if (trivial) return ASP_OK;
+    hipStream_t s = p->stream;
+    p->last_shuffled_levels = static_cast<int>(status[kStatLevels]);
+#if ASP_SHUF_TIMING
+    {
+      unsigned long long host_ticks[kTimingSlots * kTimingWaves];
+      ASP_HIP_TRY(hipMemcpy(host_ticks, d_status.ptr + kStatWords, sizeof host_ticks, hipMemcpyDeviceToHost));
+      static const char *names[kTimingSlots] = {"row sums", "request", "accept", "barrier", "sweep end", "level head"};
+      for (uint32_t w = 0; w < waves && w < kTimingWaves; ++w) {
+        std::fprintf(stderr, "wave %u:", w);
+        for (uint32_t k = 0; k < kTimingSlots; ++k) {
+          std::fprintf(stderr, " %s %.3f Mcyc", names[k], static_cast<double>(host_ticks[w * kTimingSlots + k]) * 1e-6);
+        }
+        std::fprintf(stderr, "\n");
+      }
+    }
+#endif
+    ASP_TRY(asp::sa_permute_bits(p, d_best.ptr, repetitions, d_perm.ptr));
+    ASP_TRY(asp::sa_energies_of_perm(p, d_perm.ptr, repetitions, d_partial.ptr, d_e.ptr));
+    ASP_HIP_TRY(hipEventRecord(p->ev[3], s));
+    // hipMemcpyDefault: out_x / out_e may be host pointers (the usual call) or device pointers
+    ASP_HIP_TRY(hipMemcpyAsync(out_x, d_best.ptr, static_cast<uint64_t>(repetitions) * words * sizeof(uint64_t),
+                               hipMemcpyDefault, s));
+    ASP_HIP_TRY(hipMemcpyAsync(out_e, d_e.ptr, repetitions * sizeof(double), hipMemcpyDefault, s));
+    p->last_tracked.assign(repetitions, 0);
+    p->last_accepted.assign(repetitions, 0);
+    ASP_HIP_TRY(hipMemcpyAsync(p->last_tracked.data(), d_ebest.ptr, repetitions * sizeof(int64_t),
+                               hipMemcpyDeviceToHost, s));
+    ASP_HIP_TRY(hipMemcpyAsync(p->last_accepted.data(), d_accepted.ptr, repetitions * sizeof(uint64_t),
+                               hipMemcpyDeviceToHost, s));
+    return ASP_OK;
+  }
+
+  int finish_wait() {
+    if (trivial) return ASP_OK;
+    ASP_HIP_TRY(hipStreamSynchronize(p->stream));
+    p->last_m = m;
+    p->last_layout = 5;
+    p->last_threads = static_cast<int>(waves * 64);
+    p->last_groups = static_cast<int>(groups);
+    ASP_HIP_TRY(hipEventElapsedTime(&p->last_sweep_ms, p->ev[0], p->ev[2]));
+    ASP_HIP_TRY(hipEventElapsedTime(&p->last_total_ms, p->ev[0], p->ev[3]));
+    return ASP_OK;
+  }
+};
+
+}  // namespace
+
+namespace asp {
+
+// The shuffled items of asp_sa_anneal_batch (csrc/sa_sweep.hip): every item is exactly its own
+// asp_sa_anneal_shuffled call; the attempts of all of them are queued before any is waited for.
+int sa_shuffled_batch(asp_sa_batch_item const *items, const uint32_t *which, uint32_t count, float *sweep_ms) {
+  std::vector<std::unique_ptr<ShuffledRun>> runs;
+  runs.reserve(count);
+  uint64_t budget = 16ull << 30;  // bytes of visiting orders for the whole batch, per buffer set
+  if (const char *env = std::getenv("ASP_SHUFFLED_BATCH_BYTES")) budget = std::strtoull(env, nullptr, 10);
+  for (uint32_t k = 0; k < count; ++k) {
+    const asp_sa_batch_item &it = items[which[k]];
+    runs.emplace_back(new ShuffledRun());
+    ShuffledRun &r = *runs.back();
+    r.p = it.plan;
+    r.seed = it.seed;
+    r.betas = it.betas;
+    r.num_sweeps = it.num_sweeps;
+    r.repetitions = it.repetitions;
+    r.replica_offset = it.replica_offset;
+    r.out_x = it.out_x;
+    r.out_e = it.out_e;
+    r.budget = std::max<uint64_t>(64ull << 20, std::min<uint64_t>(3ull << 30, budget / count));
+    ASP_TRY(r.setup());
+  }
+  for (auto &r : runs) ASP_TRY(r->enqueue());
+  for (auto &r : runs) {
+    bool again = false;
+    ASP_TRY(r->collect(&again));
+    while (again) {
+      ASP_TRY(r->enqueue());
+      ASP_TRY(r->collect(&again));
+    }
+  }
+  for (auto &r : runs) ASP_TRY(r->finish_enqueue());
+  for (auto &r : runs) {
+    ASP_TRY(r->finish_wait());
+    if (sweep_ms && r->p) *sweep_ms += r->p->last_sweep_ms;
+  }
   return ASP_OK;
+}
+
+}  // namespace asp
+
+extern "C" {
+
+int asp_sa_set_shuffled_launch(asp_sa_plan *p, int chains_per_group, int wavefronts) {
+  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  if (chains_per_group != 0 && !shuffled_kernel_for(chains_per_group, false)) {
+    return asp::set_error(ASP_ERR_INVALID, "chains_per_group must be 0, 1, 2, 4 or 8");
+  }
+  if (wavefronts < 0 || wavefronts > 8) return asp::set_error(ASP_ERR_INVALID, "wavefronts must be 0..8");
+  p->shuffled_m = chains_per_group;
+  p->shuffled_waves = wavefronts;
+  return ASP_OK;
+}
+
+int asp_sa_last_shuffled(asp_sa_plan const *p, uint32_t *levels, float *order_ms) {
+  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  if (levels) *levels = static_cast<uint32_t>(p->last_shuffled_levels);
+  if (order_ms) *order_ms = p->last_order_ms;
+  return ASP_OK;
+}
+
+int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_sweeps,
+                           uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0,
+                           uint64_t *out_x, double *out_e) {
+  asp_clear_error();
+  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  ASP_TRY(asp::bind_device());
+  ShuffledRun run;
+  run.p = p;
+  run.seed = seed;
+  run.betas = betas;
+  run.num_sweeps = num_sweeps;
+  run.repetitions = repetitions;
+  run.replica_offset = replica_offset;
+  run.x0 = x0;
+  run.out_x = out_x;
+  run.out_e = out_e;
+  ASP_TRY(run.setup());
+  bool again = true;
+  while (again) {
+    ASP_TRY(run.enqueue());
+    ASP_TRY(run.collect(&again));
+  }
+  ASP_TRY(run.finish_enqueue());
+  return run.finish_wait();
 }
 
 }  // extern "C"

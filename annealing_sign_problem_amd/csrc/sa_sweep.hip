@@ -1836,6 +1836,9 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
     if (it.num_sweeps == 0xFFFFFFFFu) {
       return asp::set_error(ASP_ERR_INVALID, "item %u: num_sweeps 2^32-1 is reserved", i);
     }
+    if (it.flags & ~static_cast<uint32_t>(ASP_SA_BATCH_SHUFFLED)) {
+      return asp::set_error(ASP_ERR_INVALID, "item %u: unknown flags 0x%x", i, it.flags);
+    }
     if (static_cast<uint64_t>(it.replica_offset) + it.repetitions + 8 > 0xFFFFFFFFull) {
       return asp::set_error(ASP_ERR_INVALID, "item %u: replica ids exceed 32 bits", i);
     }
@@ -1852,12 +1855,18 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
   }
   // ---- which items go into the shared launches ----
   // Problems whose spins need the bit-packed layouts, plans with a forced launch geometry
-  // (tests, measurements) and a batch of one keep the single-problem path (team sweep included).
+  // (tests, measurements) and a batch of one keep the single-problem path (team sweep included);
+  // items asking for a fresh visiting order every sweep run concurrently on their plans' own
+  // streams (csrc/sa_shuffled.hip).
   std::vector<BatchEntry> entries;
-  std::vector<uint32_t> alone;
+  std::vector<uint32_t> alone, shuffled;
   for (uint32_t i = 0; i < count; ++i) {
     const asp_sa_batch_item &it = items[i];
     if (it.repetitions == 0) continue;
+    if (it.flags & ASP_SA_BATCH_SHUFFLED) {
+      shuffled.push_back(i);
+      continue;
+    }
     const asp_sa_plan *p = it.plan;
     const asp::SaHostLayout &L = p->host;
     const bool fits = L.num_spins > 0 && sweep_lds_bytes(L, kBytes) <= p->max_lds;
@@ -1881,6 +1890,10 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
   if (entries.size() == 1) {
     alone.push_back(entries[0].item);
     entries.clear();
+  }
+  if (!shuffled.empty()) {
+    ASP_TRY(asp::sa_shuffled_batch(items, shuffled.data(), static_cast<uint32_t>(shuffled.size()),
+                                   &g_batch_sweep_ms));
   }
   for (uint32_t i : alone) {
     const asp_sa_batch_item &it = items[i];

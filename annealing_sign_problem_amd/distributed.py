@@ -135,7 +135,7 @@ def all_gather_rows(local: np.ndarray, counts, group=None) -> np.ndarray:
 
 
 def anneal_sharded(hamiltonian, seed: int, betas: np.ndarray, repetitions: int, x0=None,
-                   group=None):
+                   group=None, shuffled: bool = False):
     """Run this rank's block of chains, then gather: (xs[R, words], es[R]) on every rank.
 
     With RCCL (backend ``nccl``) the kernel's results are copied device-to-device into the
@@ -158,16 +158,18 @@ def anneal_sharded(hamiltonian, seed: int, betas: np.ndarray, repetitions: int, 
         # one payload row per chain: [packed spins | energy bits]
         xs_t = torch.zeros((most, max(words, 1)), dtype=torch.int64, device=device)
         es_t = torch.zeros((most,), dtype=torch.float64, device=device)
+        # the zero fill runs on torch's stream, the library writes from its own: order them
+        torch.cuda.current_stream().synchronize()
         if count > 0:
             annealer.anneal_raw_into(hamiltonian, seed, betas, count, offset, x0,
-                                     xs_t.data_ptr(), es_t.data_ptr())
+                                     xs_t.data_ptr(), es_t.data_ptr(), shuffled=shuffled)
         mine = torch.cat([xs_t[:, :words], es_t.view(torch.int64).unsqueeze(1)], dim=1).contiguous()
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine, group=group)
         full = torch.cat([parts[k][: counts[k]] for k in range(world)], dim=0).cpu().numpy()
     else:
         if count > 0:
-            xs, es = annealer.anneal_raw(hamiltonian, seed, betas, count, offset, x0)
+            xs, es = annealer.anneal_raw(hamiltonian, seed, betas, count, offset, x0, shuffled=shuffled)
         else:
             xs = np.zeros((0, words), dtype=np.uint64)
             es = np.zeros(0, dtype=np.float64)
@@ -207,7 +209,7 @@ def agree_on_seed(seed: Optional[int], group=None) -> int:
 
 
 def anneal_sharded_best(hamiltonian, seed: int, betas: np.ndarray, repetitions: int, x0=None,
-                        group=None):
+                        group=None, shuffled: bool = False):
     """``only_best=True`` without moving every chain: each rank reduces its own block, one
     all_gather of (energy, global replica id) per rank names the winner — lowest energy, lowest
     id among equals, i.e. the first minimum of the single-GPU result — and the winner's rank
@@ -227,7 +229,7 @@ def anneal_sharded_best(hamiltonian, seed: int, betas: np.ndarray, repetitions: 
     local_x = np.zeros(max(words, 1), dtype=np.uint64)
     local_e = np.inf
     if count > 0:
-        xs, es = anneal_raw(hamiltonian, seed, betas, count, offset, x0)
+        xs, es = anneal_raw(hamiltonian, seed, betas, count, offset, x0, shuffled=shuffled)
         best = int(np.argmin(es))
         local_x[:words] = xs[best]
         local_e = float(es[best])

@@ -19,6 +19,7 @@ apart from the (3,3) entry of the J2 term in j1j2_square_4x4.yaml:22-25.
 """
 from __future__ import annotations
 
+import threading
 from dataclasses import dataclass
 from itertools import combinations
 from typing import List, Optional, Sequence, Tuple
@@ -48,6 +49,13 @@ class SpinBasis:
         self.hamming_weight = None if hamming_weight is None else int(hamming_weight)
         self.group = None if (group is None or group.is_trivial) else group
         self._states: Optional[np.ndarray] = None
+        # the HBM copy of the state list behind batched_index (csrc/key_table.hip): created once,
+        # under a lock — the first calls come from the --jobs worker threads of the pipeline
+        self._table = None
+        self._table_of = None
+        self._lib_module = None
+        self._table_lock = threading.Lock()
+        self._table_users = 0
 
     def build(self, representatives: Optional[np.ndarray] = None) -> None:
         if representatives is not None:
@@ -113,25 +121,44 @@ class SpinBasis:
         from . import _lib
 
         lib = _lib.load()
-        table = getattr(self, "_table", None)
-        if table is None or self._table_of is not self._states:
-            _lib.require_gpu()
-            self.release_table()
-            table = ctypes.c_void_p()
-            _lib.check(lib.asp_table_create(self.number_states, _lib.ptr(self._states), ctypes.byref(table)))
-            self._table, self._table_of, self._lib_module = table, self._states, _lib
-            _lib.track(self)
-        idx = np.empty(max(spins.shape[0], 1), dtype=np.int64)
-        _lib.check(lib.asp_table_index(table, spins.shape[0], _lib.ptr(spins), _lib.ptr(idx)))
+        with self._table_lock:
+            if self._table is None or self._table_of is not self._states:
+                _lib.require_gpu()
+                if self._table_users:
+                    raise RuntimeError("the basis was rebuilt while batched_index calls were running")
+                self._release_table_locked()
+                table = ctypes.c_void_p()
+                _lib.check(lib.asp_table_create(self.number_states, _lib.ptr(self._states), ctypes.byref(table)))
+                self._table, self._table_of, self._lib_module = table, self._states, _lib
+                _lib.track(self)
+            table = self._table
+            self._table_users += 1  # release_table() waits for no one: it refuses while in use
+        try:
+            idx = np.empty(max(spins.shape[0], 1), dtype=np.int64)
+            _lib.check(lib.asp_table_index(table, spins.shape[0], _lib.ptr(spins), _lib.ptr(idx)))
+        finally:
+            with self._table_lock:
+                self._table_users -= 1
         idx = idx[: spins.shape[0]]
         if np.any(idx < 0):
             raise ValueError("state does not belong to the basis")
         return idx.astype(np.uint64)
 
-    def release_table(self) -> None:
-        table, self._table = getattr(self, "_table", None), None
+    def _release_table_locked(self) -> None:
+        table, self._table = self._table, None
+        self._table_of = None
         if table:
             self._lib_module.load().asp_table_destroy(table)
+
+    def release_table(self) -> None:
+        """Frees the HBM copy (it comes back on the next ``batched_index``).  A table that a
+        running ``batched_index`` call of another thread is using stays."""
+        lock = getattr(self, "_table_lock", None)
+        if lock is None:
+            return
+        with lock:
+            if self._table_users == 0:
+                self._release_table_locked()
 
     release = release_table  # (the library's shutdown hook calls `release` on tracked objects)
 

@@ -22,7 +22,7 @@ from __future__ import annotations
 import argparse
 import os
 from dataclasses import dataclass
-from typing import List, Sequence
+from typing import List, Optional, Sequence
 
 import numpy as np
 
@@ -116,14 +116,14 @@ class OptimizationResult:
 
 
 def solve_and_test_model(h: common.IsingModel, frozen_spins, exact_signs, weights,
-                         annealing: bool) -> OptimizationResult:
+                         annealing: bool, sweep_order: Optional[str] = None) -> OptimizationResult:
     """Greedy always, SA when requested, both projected on the original cluster
     (driver :696-716; NB the driver's --number-sweeps/--repetitions are not forwarded, the
     defaults of solve_ising_model apply, common.py:236-239)."""
     x = common.solve_ising_model(h, mode="greedy", frozen_spins=frozen_spins)
     greedy_accuracy, greedy_overlap = common.compute_accuracy_and_overlap(x, exact_signs, weights)
     if annealing:
-        x = common.solve_ising_model(h, mode="sa", frozen_spins=frozen_spins)
+        x = common.solve_ising_model(h, mode="sa", frozen_spins=frozen_spins, sweep_order=sweep_order)
         sa_accuracy, sa_overlap = common.compute_accuracy_and_overlap(x, exact_signs, weights)
     else:
         sa_accuracy = sa_overlap = float("nan")
@@ -140,7 +140,8 @@ def amplitude_overlap(cluster, ground_state, noisy_ground_state, basis) -> float
 
 
 def process_cluster(cluster, hamiltonian, ground_state, noisy_ground_state, noisy_log_coeff_fn,
-                    order: int, global_cutoff: float, annealing: bool) -> List[OptimizationResult]:
+                    order: int, global_cutoff: float, annealing: bool,
+                    sweep_order: Optional[str] = None) -> List[OptimizationResult]:
     """driver :726-751."""
     basis = hamiltonian.basis
     exact_psi = ground_state[np.asarray(basis.batched_index(cluster), dtype=np.int64)]
@@ -155,7 +156,7 @@ def process_cluster(cluster, hamiltonian, ground_state, noisy_ground_state, nois
         else:
             h = common.make_hamiltonian_extension(h, noisy_log_coeff_fn)
             h = common.sparsify_using_global_cutoff(h, global_cutoff, cluster)
-        r = solve_and_test_model(h, cluster, exact_signs, weights, annealing)
+        r = solve_and_test_model(h, cluster, exact_signs, weights, annealing, sweep_order)
         r.amplitude_overlap = amplitude_overlap(h.spins, ground_state, noisy_ground_state, basis)
         results.append(r)
     return results
@@ -163,8 +164,8 @@ def process_cluster(cluster, hamiltonian, ground_state, noisy_ground_state, nois
 
 def process_clusters_batched(clusters: Sequence[np.ndarray], hamiltonian, ground_state,
                              noisy_ground_state, noisy_log_coeff_fn, order: int,
-                             global_cutoff: float, annealing: bool,
-                             jobs: int = 1) -> List[List[OptimizationResult]]:
+                             global_cutoff: float, annealing: bool, jobs: int = 1,
+                             sweep_order: Optional[str] = None) -> List[List[OptimizationResult]]:
     """``[process_cluster(c, ...) for c in clusters]`` with the annealing of ALL models — every
     cluster at every order — in one batched device call.  The models of a cluster do not depend
     on its solutions (the extension of order i grows from the model of order i-1, common.py:516),
@@ -203,7 +204,8 @@ def process_clusters_batched(clusters: Sequence[np.ndarray], hamiltonian, ground
         staged = [entry for item in enumerate(clusters) for entry in stage(item)]
     if annealing and staged:
         solutions = common.solve_ising_models([m for _, m, _, _, _ in staged],
-                                              [clusters[c] for c, _, _, _, _ in staged])
+                                              [clusters[c] for c, _, _, _, _ in staged],
+                                              sweep_order=sweep_order)
         for (_, _, exact_signs, weights, r), x in zip(staged, solutions):
             r.sa_accuracy, r.sa_overlap = common.compute_accuracy_and_overlap(x, exact_signs, weights)
     results: List[List[OptimizationResult]] = [[] for _ in clusters]
@@ -240,6 +242,10 @@ def parse_command_line(argv=None):
                         help="clusters whose annealing chains share one batched device call "
                              "(asp_sa_anneal_batch); 1 = one call per model, as the reference's "
                              "loop.  The output does not depend on it")
+    parser.add_argument("--sweep-order", type=str, default="colour", choices=["colour", "shuffled"],
+                        help="visiting order of the annealing sweeps: 'colour' (this package's "
+                             "default, fixed) or 'shuffled' (a fresh random order every sweep: the "
+                             "reference annealer's statistics)")
     parser.add_argument("--jobs", type=int, default=1,
                         help="host threads building / solving clusters concurrently (independent "
                              "plans and HIP streams on one GPU; the output does not depend on it)")
@@ -294,9 +300,14 @@ def main(argv=None):
     else:
         noisy_ground_state = ground_state
     noisy_log_coeff_fn = common.ground_state_to_log_coeff_fn(noisy_ground_state, hamiltonian.basis)
-    clusters = generate_clusters(hamiltonian, ground_state, args.number_samples,
-                                 args.sampled_power, args.min_cluster_size,
-                                 args.max_cluster_size, args.keep_probability)
+    # the clusters are grown once, by rank 0, and handed to the others (same file for any world
+    # size: the draws come from rank 0's seeded stream either way)
+    clusters = None
+    if writer:
+        clusters = generate_clusters(hamiltonian, ground_state, args.number_samples,
+                                     args.sampled_power, args.min_cluster_size,
+                                     args.max_cluster_size, args.keep_probability)
+    clusters = asp_dist.broadcast_object(clusters)
     if writer:
         with open(args.output, "w") as f:
             f.write("# Generated by annealing_sign_problem_amd.sampled_components\n")
@@ -307,18 +318,24 @@ def main(argv=None):
             f.write("# {}\n".format(OptimizationResult.csv_header()))
     def work(cluster):
         return process_cluster(cluster, hamiltonian, ground_state, noisy_ground_state,
-                               noisy_log_coeff_fn, args.order, args.global_cutoff, args.annealing)
+                               noisy_log_coeff_fn, args.order, args.global_cutoff, args.annealing,
+                               args.sweep_order)
 
     def work_many(some):
         """CSV lines of a list of clusters, their annealing batched --batch clusters at a time."""
         if args.batch <= 1 or not args.annealing:
+            if args.jobs > 1 and len(some) > 1:
+                from concurrent.futures import ThreadPoolExecutor
+
+                with ThreadPoolExecutor(max_workers=args.jobs) as pool:  # (map keeps the order)
+                    return [",".join(r.to_csv_str() for r in columns) for columns in pool.map(work, some)]
             return [",".join(r.to_csv_str() for r in work(c)) for c in some]
         lines = []
         for start in range(0, len(some), args.batch):
             chunk = process_clusters_batched(some[start:start + args.batch], hamiltonian,
                                              ground_state, noisy_ground_state, noisy_log_coeff_fn,
                                              args.order, args.global_cutoff, args.annealing,
-                                             jobs=args.jobs)
+                                             jobs=args.jobs, sweep_order=args.sweep_order)
             lines += [",".join(r.to_csv_str() for r in columns) for columns in chunk]
         return lines
 
@@ -332,9 +349,14 @@ def main(argv=None):
     # rank generated the same clusters above (same seed), so the file does not depend on the
     # world size.
     if asp_dist.world_size() > 1:
-        lines = asp_dist.map_sharded_many(clusters, work_many)
-        if writer:
-            append(lines)
+        # a round of --batch clusters per rank at a time; rank 0 appends every round's lines, so a
+        # job that is killed keeps what it has finished (driver :828-830 appends per cluster).
+        # The round size is a multiple of the world size: cluster c stays on rank c mod world.
+        step = max(args.batch, 1) * asp_dist.world_size()
+        for start in range(0, len(clusters), step):
+            lines = asp_dist.map_sharded_many(clusters[start:start + step], work_many)
+            if writer:
+                append(lines)
         if created_group:
             import torch.distributed as dist
 

@@ -430,7 +430,10 @@ int asp_sa_last_shuffled(asp_sa_plan const *p, uint32_t *levels, float *order_ms
  * become the workgroups of a few shared launches (one per wavefront count), so a batch of small
  * clusters fills the chip instead of leaving > 90 % of it idle launch by launch.  Plans must
  * be distinct.  Problems that need the bit-packed spin layouts, and a batch of one, take the
- * single-problem path inside the call. */
+ * single-problem path inside the call.  Items with ASP_SA_BATCH_SHUFFLED in `flags` are
+ * asp_sa_anneal_shuffled calls (a fresh visiting order every sweep): their kernels are queued on
+ * the plans' own streams before any of them is waited for, so they overlap on the device. */
+#define ASP_SA_BATCH_SHUFFLED 1u
 typedef struct asp_sa_batch_item {
   asp_sa_plan *plan;
   uint64_t seed;
@@ -438,7 +441,7 @@ typedef struct asp_sa_batch_item {
   uint32_t num_sweeps;
   uint32_t repetitions;
   uint32_t replica_offset;
-  uint32_t reserved;    /* 0 */
+  uint32_t flags;       /* 0, or ASP_SA_BATCH_SHUFFLED: the item is an asp_sa_anneal_shuffled call */
   uint64_t *out_x;      /* repetitions * ceil(K/64) words */
   double *out_e;        /* repetitions */
 } asp_sa_batch_item;

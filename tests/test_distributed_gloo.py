@@ -32,8 +32,8 @@ def _worker(rank, world, port, repetitions, out_dir):
     betas = np.geomspace(0.5, 100.0, 15)
 
     def fake_anneal_raw(hamiltonian, seed, betas, count, offset=0, x0=None, shuffled=False):
-        xs, es, _, _ = oracle.sa_anneal(hamiltonian.exchange, hamiltonian.field, seed, betas, count,
-                                        offset, x0, 40)
+        run = oracle.sa_anneal_shuffled if shuffled else oracle.sa_anneal
+        xs, es, _, _ = run(hamiltonian.exchange, hamiltonian.field, seed, betas, count, offset, x0, 40)
         return xs, es
 
     annealer.anneal_raw = fake_anneal_raw
@@ -52,6 +52,14 @@ def _worker(rank, world, port, repetitions, out_dir):
     # seed=None: rank 0 draws, every rank must run the same stream
     xr, er = annealer.anneal(ham, seed=None, number_sweeps=15, repetitions=repetitions)
     np.savez(os.path.join(out_dir, "drawn%d.npz" % rank), x=xr, e=er)
+    # the shuffled visiting order shards the same way (global replica ids key its random words too)
+    xs_s, es_s = annealer.anneal(ham, seed=999, number_sweeps=15, repetitions=repetitions,
+                                 only_best=False, sweep_order="shuffled")
+    xb, eb = annealer.anneal(ham, seed=999, number_sweeps=15, repetitions=repetitions,
+                             sweep_order="shuffled")
+    xd, ed = annealer.anneal(ham, seed=None, number_sweeps=15, repetitions=repetitions,
+                             sweep_order="shuffled")
+    np.savez(os.path.join(out_dir, "shuffled%d.npz" % rank), xs=xs_s, es=es_s, x=xb, e=eb, xd=xd, ed=ed)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -77,6 +85,13 @@ def test_sharded_anneal_equals_single_process(tmp_path, repetitions):
         assert np.array_equal(best["x"], xs[k]) and float(best["e"]) == es[k]
     drawn = [np.load(tmp_path / ("drawn%d.npz" % rank)) for rank in range(world)]
     assert np.array_equal(drawn[0]["x"], drawn[1]["x"]) and float(drawn[0]["e"]) == float(drawn[1]["e"])
+    sxs, ses, _, _ = oracle.sa_anneal_shuffled(J, h, 999, betas, repetitions, 0, None, 40)
+    shuffled = [np.load(tmp_path / ("shuffled%d.npz" % rank)) for rank in range(world)]
+    for got in shuffled:
+        assert np.array_equal(got["xs"], sxs) and got["es"].tobytes() == ses.tobytes()
+        k = int(np.argmin(ses))
+        assert np.array_equal(got["x"], sxs[k]) and float(got["e"]) == ses[k]
+    assert np.array_equal(shuffled[0]["xd"], shuffled[1]["xd"])  # seed=None: one draw for all ranks
 
 
 def _cluster_worker(rank, world, port, out_dir):
@@ -150,16 +165,28 @@ def _main_worker(rank, world, port, out_path, expect_refusal):
         states = hamiltonian.basis.states
         return [states[7 * c: 7 * c + 5 + c].copy() for c in range(number_samples)]
 
-    def fake_process(cluster, hamiltonian, ground_state, noisy, fn, order, cutoff, annealing):
+    def fake_process(cluster, hamiltonian, ground_state, noisy, fn, order, cutoff, annealing,
+                     sweep_order=None):
         assert not distributed.shards_chains()  # inside a sharded item chains stay on the rank
+        assert sweep_order == "shuffled"       # --sweep-order reaches the solver
+        if distributed.rank() == 0 and os.path.exists(out_path):
+            # how many result lines the file held when this cluster was being solved
+            done = sum(1 for l in open(out_path) if not l.startswith("#"))
+            with open(out_path + ".growth", "a") as f:
+                f.write("%d %d\n" % (int(cluster.size) - 5, done))
         return [sc.OptimizationResult(int(cluster.size) + i, float(cluster[0] % 97) / 97.0, 0.5, 0.25,
                                       0.125, float(distributed.world_size())) for i in range(order + 1)]
 
-    sc.generate_clusters = fake_clusters
+    def fake_generate(*args):
+        assert distributed.rank() == 0  # rank 0 grows the clusters, the others receive them
+        return fake_clusters(*args)
+
+    sc.generate_clusters = fake_generate
     sc.process_cluster = fake_process
-    sc.process_clusters_batched = lambda clusters, *rest, jobs=1: [fake_process(c, *rest) for c in clusters]
+    sc.process_clusters_batched = lambda clusters, *rest, jobs=1, sweep_order=None: [
+        fake_process(c, *rest, sweep_order=sweep_order) for c in clusters]
     argv = ["--model", "heisenberg_kagome_16", "--output", out_path, "--order", "1",
-            "--number-samples", "5", "--seed", "3"]
+            "--number-samples", "5", "--seed", "3", "--batch", "1", "--sweep-order", "shuffled"]
     if expect_refusal:
         with pytest.raises(SystemExit):
             sc.main(argv)
@@ -181,4 +208,15 @@ def test_pipeline_main_initialises_ranks_from_env(tmp_path):
     sizes = [int(l.split(",")[0]) for l in lines]
     assert sizes == [5 + c for c in range(5)]
     assert all(l.split(",")[5] == "2.00000000e+00" for l in lines)  # computed under world size 2
+    # rank 0 appends round by round (--batch 1 x 2 ranks = 2 clusters a round), so a killed job
+    # keeps its finished rounds: its clusters 0, 2, 4 saw 0, 2 and 4 lines already in the file
+    growth = dict(tuple(map(int, l.split())) for l in open(out + ".growth"))
+    assert growth == {0: 0, 2: 2, 4: 4}
+    # the same file as a single process writes (up to the column the stand-in fills with the
+    # world size)
+    single = str(tmp_path / "single.csv")
+    mp.spawn(_main_worker, args=(1, _free_port(), single, False), nprocs=1, join=True)
+    strip = lambda path: [",".join(c for i, c in enumerate(l.split(",")) if i % 6 != 5)
+                          for l in open(path).read().splitlines()]
+    assert strip(single) == strip(out)
     mp.spawn(_main_worker, args=(2, _free_port(), out, True), nprocs=2, join=True)

@@ -891,11 +891,12 @@ def test_shuffled_sweep_bit_exact(n, degree, sweeps, reps):
 
 
 def test_shuffled_sweep_runs_long_ladders_in_chunks():
-    """More sweeps than one chunk of visiting orders holds (64 MiB): the chain state survives
-    between the chunks' launches; compared with the oracle."""
+    """More sweeps than one chunk of visiting orders holds (at most 256): the chain state
+    survives between the chunks' launches, and the order kernel of a chunk runs beside the sweep
+    kernel of the chunk before; compared with the oracle."""
     from annealing_sign_problem_amd import annealer as sa
 
-    n = 40000  # 64 MiB / (4 B * 40000) = 419 sweeps per chunk
+    n = 40000
     J, h, _ = _planted(n, 8, mean_degree=4.0)
     ham = sa.Hamiltonian(J, h)
     info = ham.info()
@@ -904,3 +905,140 @@ def test_shuffled_sweep_runs_long_ladders_in_chunks():
     oxs, oes, _, _ = oracle.sa_anneal_shuffled(J, h, 11, betas, 2, 0, None, info.energy_scale_exp,
                                                num_threads=2)
     assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+
+
+def _shuffled_case(n, degree, sweeps, seed=5, **kw):
+    from annealing_sign_problem_amd import annealer as sa
+
+    J, h, _ = _planted(n, seed, mean_degree=degree, **kw)
+    ham = sa.Hamiltonian(J, h)
+    info = ham.info()
+    betas = sa.make_schedule(max(info.beta0_auto, 1e-3), min(max(info.beta1_auto, 1.0), 1e6), sweeps)
+    return J, h, ham, info, betas
+
+
+@pytest.mark.parametrize("m,waves", [(1, 1), (1, 8), (2, 3), (4, 1), (4, 5), (8, 2), (8, 8)])
+def test_shuffled_sweep_does_not_depend_on_the_launch_geometry(m, waves):
+    """Chains per workgroup (word layout for <= 4, bytes for 8) and wavefronts per workgroup:
+    the same chains as the oracle for every choice; 11 chains leave a ragged last group."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    J, h, ham, info, betas = _shuffled_case(1300, 9.0, 14)
+    lib = _lib.load()
+    _lib.check(lib.asp_sa_set_shuffled_launch(ham.plan(), m, waves))
+    xs, es = sa.anneal_raw(ham, 77, betas, 11, 6, None, shuffled=True)
+    got_m, got_threads, got_groups = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.asp_sa_last_launch(ham.plan(), ctypes.byref(got_m), ctypes.byref(got_threads),
+                                      ctypes.byref(got_groups)))
+    assert (got_m.value, got_threads.value, got_groups.value) == (m, 64 * waves, (11 + m - 1) // m)
+    tracked, accepted = _stats(ham, 11)
+    oxs, oes, otracked, oaccepted = oracle.sa_anneal_shuffled(J, h, 77, betas, 11, 6, None,
+                                                             info.energy_scale_exp, num_threads=4)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    assert np.array_equal(tracked, otracked) and np.array_equal(accepted, oaccepted)
+
+
+def test_shuffled_sweep_rows_wider_than_the_held_quads():
+    """Rows of more than 48 couplings (a dense SK-like cluster: 120 per row) do not fit the
+    registers a wavefront keeps a block in: the rest of the row streams.  Same bits."""
+    from annealing_sign_problem_amd import annealer as sa
+    from annealing_sign_problem_amd import synthetic
+
+    J, h = synthetic.sk_cluster(400, degree=120, seed=3)
+    ham = sa.Hamiltonian(J, h)
+    info = ham.info()
+    assert info.max_degree > 60
+    betas = sa.make_schedule(info.beta0_auto, info.beta1_auto, 10)
+    for m in (4, 8):
+        from annealing_sign_problem_amd import _lib
+
+        _lib.check(_lib.load().asp_sa_set_shuffled_launch(ham.plan(), m, 0))
+        xs, es = sa.anneal_raw(ham, 3, betas, 9, 0, None, shuffled=True)
+        oxs, oes, _, _ = oracle.sa_anneal_shuffled(J, h, 3, betas, 9, 0, None, info.energy_scale_exp,
+                                                   num_threads=4)
+        assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+
+
+def test_shuffled_sweep_grows_its_capacities_and_repeats(monkeypatch):
+    """The order kernel works within capacities guessed from the degree; a sweep with more levels
+    than provided makes it raise a flag, the sweep kernels of the attempt stand down, and the call
+    is repeated with the capacities the flag words ask for.  Provoked here with a cap of 2 levels."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    J, h, ham, info, betas = _shuffled_case(2500, 12.0, 9)
+    reference = sa.anneal_raw(ham, 21, betas, 5, 0, None, shuffled=True)
+    levels = ctypes.c_uint32(0)
+    _lib.check(_lib.load().asp_sa_last_shuffled(ham.plan(), ctypes.byref(levels), None))
+    assert levels.value > 8
+    monkeypatch.setenv("ASP_SHUFFLED_LEVEL_CAP", "2")
+    again = sa.anneal_raw(ham, 21, betas, 5, 0, None, shuffled=True)
+    assert np.array_equal(again[0], reference[0]) and again[1].tobytes() == reference[1].tobytes()
+    oxs, oes, _, _ = oracle.sa_anneal_shuffled(J, h, 21, betas, 5, 0, None, info.energy_scale_exp,
+                                               num_threads=4)
+    assert np.array_equal(again[0], oxs) and again[1].tobytes() == oes.tobytes()
+
+
+def test_shuffled_sweep_byte_layout_of_large_clusters():
+    """Beyond ~4e4 spins a word per spin no longer fits the LDS: a byte per spin (bit m = chain
+    m), also for four chains per workgroup.  70 000 spins, the oracle on 3 chains x 5 sweeps."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    J, h, ham, info, betas = _shuffled_case(70000, 6.0, 5)
+    _lib.check(_lib.load().asp_sa_set_shuffled_launch(ham.plan(), 4, 0))
+    xs, es = sa.anneal_raw(ham, 9, betas, 3, 2, None, shuffled=True)
+    oxs, oes, _, _ = oracle.sa_anneal_shuffled(J, h, 9, betas, 3, 2, None, info.energy_scale_exp,
+                                               num_threads=3)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+
+
+def test_shuffled_batch_equals_the_single_calls():
+    """asp_sa_anneal_batch with ASP_SA_BATCH_SHUFFLED: every problem is its own
+    asp_sa_anneal_shuffled call, chain for chain (and the oracle's), while their kernels overlap
+    on the plans' streams; mixed with colour-ordered items in one batch through two calls."""
+    from annealing_sign_problem_amd import annealer as sa
+
+    problems = []
+    for k, deg in ((90, 4.0), (700, 8.0), (2600, 14.0), (1, 1.0)):
+        J, h, ham, info, betas = _shuffled_case(k, min(deg, max(k / 3, 1.0)), 40 + k % 7, seed=k)
+        problems.append((J, h, ham, info, betas))
+    hams = [p[2] for p in problems]
+    seeds = [5, 6, 7, 8]
+    reps = [6, 3, 9, 2]
+    offsets = [0, 4, 1, 0]
+    batch = sa.anneal_batch_raw(hams, seeds, [p[4] for p in problems], reps, offsets, shuffled=True)
+    for (J, h, ham, info, betas), seed, r, off, (bx, be) in zip(problems, seeds, reps, offsets, batch):
+        sx, se = sa.anneal_raw(ham, seed, betas, r, off, None, shuffled=True)
+        assert np.array_equal(bx, sx) and be.tobytes() == se.tobytes()
+        ox, oe, _, _ = oracle.sa_anneal_shuffled(J, h, seed, betas, r, off, None, info.energy_scale_exp,
+                                                 num_threads=4)
+        assert np.array_equal(bx, ox) and be.tobytes() == oe.tobytes()
+    # the public entry points: anneal_batch(sweep_order=...) == [anneal(..., sweep_order=...)]
+    best = sa.anneal_batch(hams[:3], seed=12345, number_sweeps=30, repetitions=5, sweep_order="shuffled")
+    for ham, (x, e) in zip(hams[:3], best):
+        sx, se = sa.anneal(ham, seed=12345, number_sweeps=30, repetitions=5, sweep_order="shuffled")
+        assert np.array_equal(x, sx) and e == se
+    colour = sa.anneal_batch(hams[:3], seed=12345, number_sweeps=30, repetitions=5)
+    assert any(not np.array_equal(x, cx) for (x, _), (cx, _) in zip(best, colour))
+
+
+def test_sweep_order_reaches_the_solver_entry_points(monkeypatch):
+    """common.solve_ising_model(s)(sweep_order=...) and $ASP_SWEEP_ORDER select the annealer."""
+    from annealing_sign_problem_amd import annealer as sa
+    from annealing_sign_problem_amd import common
+
+    J, h, ham, info, betas = _shuffled_case(600, 7.0, 8)
+    model = common.IsingModel(np.arange(600, dtype=np.uint64), None, ham, sa.signs_to_bits(np.ones(600)))
+    x_colour = common.solve_ising_model(model, seed=3, number_sweeps=50, repetitions=4)
+    x_shuffled = common.solve_ising_model(model, seed=3, number_sweeps=50, repetitions=4,
+                                          sweep_order="shuffled")
+    expected, _ = sa.anneal(ham, seed=3, number_sweeps=50, repetitions=4, sweep_order="shuffled")
+    assert np.array_equal(x_shuffled, expected) and not np.array_equal(x_shuffled, x_colour)
+    assert np.array_equal(common.solve_ising_models([model], seed=3, number_sweeps=50, repetitions=4,
+                                                    sweep_order="shuffled")[0], expected)
+    monkeypatch.setenv("ASP_SWEEP_ORDER", "shuffled")
+    assert np.array_equal(common.solve_ising_model(model, seed=3, number_sweeps=50, repetitions=4), expected)
+    with pytest.raises(ValueError):
+        sa.anneal(ham, seed=3, number_sweeps=5, sweep_order="typewriter")
