@@ -15,12 +15,19 @@ rank*1024 ...); value = all ranks' flip attempts / max-over-ranks wall time.
 
 The JSON line also carries
   roofline      for the sweep kernel, against the resource that binds it — VALU
-                issue: (VALU instructions per flip from the committed PMC summary) x
-                (SIMD cycles per instruction from the on-chip probe) x (flips/s from
-                HIP events on the launch stream, live) over 1024 SIMDs x 2.4 GHz;
-                beside it the measured HBM fraction, the useful-f64-FMA fraction, the
-                algorithmic bytes/s (B_flip = 12*dbar + 16) and the rate
-                with every proposal evaluated (field cache / inert skipping off);
+                issue: (VALU instructions per flip from the committed PMC summary, per
+                cluster size) x (SIMD cycles per instruction from the on-chip probe) x
+                (flips/s from HIP events on the launch stream, live) over 1024 SIMDs x
+                2.4 GHz; beside it the measured HBM fraction, the useful-f64-FMA
+                fraction, the algorithmic bytes/s (B_flip = 12*dbar + 16) and
+                the rate with every proposal evaluated (field cache / inert skipping
+                off).  The PMC summary carries the fingerprint of the library build it was
+                measured on: when that is not the running library, `frac` is null and
+                `frac_null_reason` says so;
+  shuffled_order  the same clusters, chains and sweeps with the reference annealer's
+                visiting order (a fresh random permutation every sweep,
+                asp_sa_anneal_shuffled), and the reference's default call (64 chains x
+                5120 sweeps);
   cpu_baseline  the oracle's OpenMP port of the same sweep on the host cores,
                 timed on a bounded sample (rank 0, N = 1 only);
   build         the coupling build (build_matrix) on the K = 1e5 cluster, device
@@ -69,13 +76,8 @@ def parse_args():
     return p.parse_args()
 
 
-def sweep_counters_from_profiles():
-    """VALU instructions per flip attempt and the measured clock of the sweep kernel on this
-    workload (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE), and the SIMD cycles one such
-    instruction occupies (tools/issue_rate_probe.hip), from the committed summary."""
-    path = os.path.join(ROOT, "profiles", "sweep_counters.json")
-    if not os.path.exists(path):
-        return None
+def _load_profile(name):
+    path = os.path.join(ROOT, "profiles", name)
     try:
         with open(path) as f:
             return json.load(f)
@@ -83,17 +85,40 @@ def sweep_counters_from_profiles():
         return None
 
 
-def traffic_from_profiles():
-    """Measured HBM bytes per sweep-kernel launch (rocprofv3 PMC passes, corrected as
-    MI355X_MICROARCH.md §HBM prescribes), if a committed summary names this workload."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(path):
+def profiled_counters(built_fingerprint):
+    """``(counters, traffic, reason)``: the committed rocprofv3 summaries
+    (profiles/sweep_counters.json, profiles/traffic.json; tools/gpu_profile_r3.sh) — but only
+    when they were taken from THIS library build.  Both files carry the fingerprint of the
+    sources and flags of the libasp_hip.so they were measured on (build.py); when it differs
+    from the one of the library that is running, the counters say nothing about this binary,
+    ``counters`` and ``traffic`` are None and ``reason`` says why, and every ``frac`` of the bench
+    line is null instead of a number carried over from another kernel."""
+    counters, traffic = _load_profile("sweep_counters.json"), _load_profile("traffic.json")
+    if counters is None:
+        return None, None, "profiles/sweep_counters.json missing or unreadable"
+    have = counters.get("library_fingerprint")
+    if not have:
+        return None, None, "profiles/sweep_counters.json carries no library fingerprint"
+    if not built_fingerprint:
+        return None, None, "the running library has no build stamp to compare the counters with"
+    if have != built_fingerprint:
+        return None, None, ("stale counters: profiles/sweep_counters.json was measured on library build "
+                            "%s..., the running library is build %s... (re-run tools/gpu_profile_r3.sh)"
+                            % (have[:12], built_fingerprint[:12]))
+    if traffic is not None and traffic.get("library_fingerprint") != built_fingerprint:
+        traffic = None
+    return counters, traffic, None
+
+
+def issue_fraction(case, counters, flips_per_s):
+    """VALU-issue fraction of one profiled case at a rate measured live: (VALU instructions per
+    flip, PMC) x (SIMD cycles per instruction, on-chip probe) x flips/s over 1024 SIMDs x 2.4 GHz."""
+    if not counters or case not in counters.get("cases", {}):
         return None
-    try:
-        with open(path) as f:
-            return json.load(f)
-    except Exception:
+    per_flip = counters["cases"][case].get("valu_insts_per_flip")
+    if per_flip is None or not flips_per_s:
         return None
+    return per_flip * counters["cycles_per_valu_inst"] * flips_per_s / 1e9 / (NUM_SIMDS * CLOCK_GHZ)
 
 
 def usable_cores() -> int:
@@ -353,6 +378,7 @@ def bench_batched_clusters(num_problems=128, serial_every=8):
                     "sweeps each" % (num_problems, sum(sizes), reps, sweeps),
         "batched_s": t_batched,
         "batched_sweep_kernels_ms": batched_kernel_ms,
+        "batched_kernel_flips_per_s": flips_all / (batched_kernel_ms * 1e-3),
         "batched_flips_per_s": flips_all / t_batched,
         "batched_problems_per_s": num_problems / t_batched,
         "serial_sample": "every %dth problem (%d problems)" % (serial_every, len(subset)),
@@ -363,7 +389,8 @@ def bench_batched_clusters(num_problems=128, serial_every=8):
     }
 
 
-def bench_real_kagome_36(replicas, sweeps, targets=(10_000, 30_000, 100_000), seeds=24):
+def bench_real_kagome_36(replicas, sweeps, targets=(10_000, 30_000, 100_000), seeds=24, calls=5,
+                         warmup=2):
     """The headline step on REAL clusters of the 36-site kagome model, not planted ones: the
     ground state of heisenberg_kagome_36.yaml's symmetry sector is computed here (31.5 M
     representatives; enumeration, resident Hamiltonian and Lanczos on this GPU, sector_ed.py —
@@ -402,32 +429,34 @@ def bench_real_kagome_36(replicas, sweeps, targets=(10_000, 30_000, 100_000), se
     from annealing_sign_problem_amd import _lib
 
     lib = _lib.load()
-    flips, seconds, kernel_ms, shapes = 0, 0.0, 0.0, []
+    flips, flips_profiled, seconds, kernel_ms, shapes = 0, 0, 0.0, 0.0, []
     for m in chosen:
         ham = m.ising_hamiltonian
         hinfo = ham.info()
         betas = sa.make_schedule(hinfo.beta0_auto, hinfo.beta1_auto, sweeps)
-        for _ in range(2):
+        for _ in range(warmup):
             sa.anneal_raw(ham, 12345, betas, replicas)  # warm-up (plan upload, clocks)
-        calls = []
-        for _ in range(5):
+        timed = []
+        for _ in range(calls):
             t0 = time.perf_counter()
             sa.anneal_raw(ham, 12345, betas, replicas)
-            calls.append((time.perf_counter() - t0, lib.asp_sa_last_sweep_ms(ham.plan())))
+            timed.append((time.perf_counter() - t0, lib.asp_sa_last_sweep_ms(ham.plan())))
         # medians: an occasional host-side stall (50 ms once in ten calls) is not the workload
-        seconds += float(np.median([c[0] for c in calls]))
-        kernel_ms += float(np.median([c[1] for c in calls]))
+        seconds += float(np.median([c[0] for c in timed]))
+        kernel_ms += float(np.median([c[1] for c in timed]))
         flips += m.size * replicas * sweeps
+        flips_profiled += m.size * replicas * sweeps * (warmup + calls)
         j = ham.exchange
         shapes.append({"K": int(m.size), "dbar": float(j.nnz / j.shape[0]),
                        "colors": int(hinfo.num_colors), "max_degree": int(hinfo.max_degree),
-                       "call_ms": [round(c[0] * 1e3, 2) for c in calls],
-                       "sweep_kernel_ms": [round(c[1], 2) for c in calls]})
+                       "call_ms": [round(c[0] * 1e3, 2) for c in timed],
+                       "sweep_kernel_ms": [round(c[1], 2) for c in timed]})
     return {
         "workload": "real heisenberg_kagome_36 clusters (order-2 extension, cutoff 1e-6) closest to "
-                    "K = %s, %d chains x %d sweeps per call (median of 5 calls each)" % (
-                        "/".join(str(t) for t in targets), replicas, sweeps),
+                    "K = %s, %d chains x %d sweeps per call (median of %d calls each)" % (
+                        "/".join(str(t) for t in targets), replicas, sweeps, calls),
         "flips_per_s": flips / seconds,
+        "flips_profiled": flips_profiled,
         "kernel_flips_per_s": flips / (kernel_ms * 1e-3),
         "clusters": shapes,
         "sector_dimension": int(info["dimension"]),
@@ -440,6 +469,60 @@ def bench_real_kagome_36(replicas, sweeps, targets=(10_000, 30_000, 100_000), se
         "clusters_built": len(models),
         "sizes_built": sorted(int(m.size) for m in models),
     }
+
+
+def bench_shuffled_order(clusters, replicas, sweeps, offset, counters):
+    """The reference annealer's visiting order — a fresh random permutation every sweep,
+    ASP-SA-1S — on the headline workload: the same three planted clusters, the
+    same chains and sweeps per call, through asp_sa_anneal_shuffled (orders built on the device
+    beside the sweeps, csrc/sa_shuffled.hip); and the reference's default call, 64 repetitions x
+    5120 sweeps (common.py:236-239), on the smallest of them.  Rates of whole calls (host wall
+    clock) and of the kernels alone (HIP events on the launch stream, order kernels included)."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    lib = _lib.load()
+    out = {"workload": "asp_sa_anneal_shuffled on the headline clusters, %d chains x %d sweeps per call "
+                       "(median of 3 calls)" % (replicas, sweeps), "clusters": []}
+    flips = seconds = kernel_s = 0.0
+    for c in clusters:
+        k = c["J"].shape[0]
+        sa.anneal_raw(c["ham"], 12345, c["betas"], replicas, offset, shuffled=True)  # warm-up (row quads resident)
+        timed = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            sa.anneal_raw(c["ham"], 12345, c["betas"], replicas, offset, shuffled=True)
+            timed.append((time.perf_counter() - t0, lib.asp_sa_last_sweep_ms(c["ham"].plan()) * 1e-3))
+        call_s = float(np.median([t[0] for t in timed]))
+        kern_s = float(np.median([t[1] for t in timed]))
+        levels = ctypes.c_uint32(0)
+        lib.asp_sa_last_shuffled(c["ham"].plan(), ctypes.byref(levels), None)
+        m, th, g = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        lib.asp_sa_last_launch(c["ham"].plan(), ctypes.byref(m), ctypes.byref(th), ctypes.byref(g))
+        rate = k * replicas * sweeps / kern_s
+        out["clusters"].append({
+            "K": k, "levels_per_sweep_max": int(levels.value), "chains_per_group": m.value,
+            "wavefronts": th.value // 64, "groups": g.value, "call_ms": call_s * 1e3,
+            "kernels_ms": kern_s * 1e3, "kernel_flips_per_s": rate,
+            "valu_issue_frac": issue_fraction("shuffled_%d" % k, counters, rate)})
+        flips += k * replicas * sweeps
+        seconds += call_s
+        kernel_s += kern_s
+    out["flips_per_s"] = flips / seconds
+    out["kernel_flips_per_s"] = flips / kernel_s
+    # the reference's default call on the K = 1e4 cluster
+    c = clusters[0]
+    k = c["J"].shape[0]
+    betas = sa.make_schedule(c["info"].beta0_auto, c["info"].beta1_auto, 5120)
+    t0 = time.perf_counter()
+    sa.anneal_raw(c["ham"], 12345, betas, 64, 0, shuffled=True)
+    t = time.perf_counter() - t0
+    kern = lib.asp_sa_last_sweep_ms(c["ham"].plan()) * 1e-3
+    out["reference_default_call"] = {
+        "workload": "64 chains x 5120 sweeps, K=%d" % k, "call_s": t, "flips_per_s": k * 64 * 5120 / t,
+        "kernel_flips_per_s": k * 64 * 5120 / kern,
+        "valu_issue_frac": issue_fraction("shuffled64_%d" % k, counters, k * 64 * 5120 / kern)}
+    return out
 
 
 def main():
@@ -565,8 +648,9 @@ def main():
         kernel_s = sum(ms for _, ms in sweep_ms) * 1e-3
         launches = max(1, len(sweep_ms))
         kernel_flips = flips_per_step * args.steps / kernel_s
-        traffic = traffic_from_profiles()
-        counters = sweep_counters_from_profiles()
+        from annealing_sign_problem_amd import build as asp_build
+
+        counters, traffic, stale = profiled_counters(asp_build.built_fingerprint())
         # every proposal evaluated: field cache and inert-block skipping off (results identical).
         # Left out under --no-build, the form the rocprofv3 passes use, so that their per-launch
         # averages cover the timed workload only.
@@ -581,17 +665,41 @@ def main():
             kernel_flips_no_skip = flips_per_step / (no_skip_ms * 1e-3)
         # The sweep kernel is bound by VALU ISSUE, not by HBM (couplings are L2/MALL-resident
         # and shared by the replicas of a workgroup; spins never leave LDS): achieved = SIMD
-        # issue cycles its VALU instructions occupy per second = (instructions per flip, PMC)
-        # x (cycles per instruction, on-chip probe) x (flips/s, measured live here).
+        # issue cycles its VALU instructions occupy per second = (instructions per flip, PMC, per
+        # cluster size) x (cycles per instruction, on-chip probe) x (flips/s, measured live here).
         peak_issue = NUM_SIMDS * CLOCK_GHZ  # G SIMD-cycles/s
-        if counters:
-            issue = (counters["valu_insts_per_flip"] * counters["cycles_per_valu_inst"]
-                     * kernel_flips / 1e9)
-        else:
-            issue = None
+        per_size, issue_cycles, hbm_bytes, have_all = [], 0.0, 0.0, counters is not None
+        for c in clusters:
+            k = c["J"].shape[0]
+            ms = [t for cc, t in sweep_ms if cc is c]
+            rate = k * replicas * args.sweeps * len(ms) / (sum(ms) * 1e-3)
+            case = "colour_%d" % k
+            entry = counters["cases"].get(case) if counters else None
+            frac = issue_fraction(case, counters, rate)
+            per_flip_bytes = (traffic or {}).get("cases", {}).get(case, {}).get("hbm_bytes_per_flip")
+            per_size.append({"K": k, "kernel_flips_per_s": rate, "avg_launch_ms": sum(ms) / len(ms),
+                             "valu_insts_per_flip": entry.get("valu_insts_per_flip") if entry else None,
+                             "frac": frac,
+                             "hbm_measured_frac": (per_flip_bytes * rate / 1e9 / HBM_PEAK_GBS
+                                                   if per_flip_bytes else None)})
+            if frac is None:
+                have_all = False
+            else:
+                # cycles this size's launches occupied = frac x peak x their time
+                issue_cycles += frac * peak_issue * sum(ms) * 1e-3
+            if per_flip_bytes:
+                hbm_bytes += per_flip_bytes * k * replicas * args.sweeps * len(ms)
+            else:
+                hbm_bytes = float("nan")
+        issue = issue_cycles / kernel_s if have_all else None
+        hbm_per_launch = hbm_bytes / launches if hbm_bytes == hbm_bytes and traffic else None
         mean_offdiag = sum((c["dbar"] - 1.0) * c["J"].shape[0] for c in clusters) / sum(
             c["J"].shape[0] for c in clusters)
-        hbm_bytes = traffic.get("hbm_bytes_per_launch") if traffic else None
+        clock = None
+        if counters:
+            clocks = [counters["cases"].get("colour_%d" % c["J"].shape[0], {}).get("clock_ghz") for c in clusters]
+            if all(clocks):
+                clock = sum(clocks) / len(clocks)
         roofline = {
             "bound": "valu",
             "kernel": "k_sa_sweep",
@@ -599,14 +707,16 @@ def main():
             "peak": peak_issue,
             "unit": "G SIMD issue cycles/s",
             "frac": issue / peak_issue if issue is not None else None,
-            "traffic": hbm_bytes,
-            "valu_insts_per_flip": counters.get("valu_insts_per_flip") if counters else None,
+            "frac_null_reason": stale if issue is None else None,
+            "counters_library_fingerprint": counters.get("library_fingerprint") if counters else None,
+            "running_library_fingerprint": asp_build.built_fingerprint(),
+            "traffic": hbm_per_launch,
+            "per_cluster_size": per_size,
             "cycles_per_valu_inst": counters.get("cycles_per_valu_inst") if counters else None,
-            "measured_clock_ghz": counters.get("clock_ghz") if counters else None,
-            "frac_at_measured_clock": (issue / (NUM_SIMDS * counters["clock_ghz"])
-                                       if counters and counters.get("clock_ghz") else None),
-            "hbm_measured_frac": (hbm_bytes / (kernel_s / launches) / 1e9 / HBM_PEAK_GBS
-                                  if hbm_bytes else None),
+            "measured_clock_ghz": clock,
+            "frac_at_measured_clock": (issue / (NUM_SIMDS * clock) if issue is not None and clock else None),
+            "hbm_measured_frac": (hbm_per_launch / (kernel_s / launches) / 1e9 / HBM_PEAK_GBS
+                                  if hbm_per_launch else None),
             "f64_fma_frac": kernel_flips * mean_offdiag * 2.0 / 1e12 / F64_VALU_PEAK_TFLOPS,
             "algorithmic_GBps": alg_bytes / kernel_s / 1e9,
             "algorithmic_bytes_per_launch": alg_bytes / launches,
@@ -616,7 +726,8 @@ def main():
             "note": "bound = VALU issue (DESIGN.md §6): algorithmic_GBps = B_flip x flips/s is the "
                     "traffic of a one-replica CPU sweep and exceeds the HBM peak because rows are "
                     "shared by the replicas of a workgroup and stay cache-resident; the HBM side "
-                    "is hbm_measured_frac",
+                    "is hbm_measured_frac.  frac is computed from PMC counters committed under "
+                    "profiles/ and is null when they were not measured on the running library",
         }
         out = {
             "metric": "SA spin-flips/sec, kagome_36-sized clusters",
@@ -651,10 +762,19 @@ def main():
             out["build"] = bench_build(clusters[-1]["J"], 1)
             out["reference_default_call"] = bench_default_call()
             out["batched_small_clusters"] = bench_batched_clusters()
+            out["batched_small_clusters"]["valu_issue_frac"] = issue_fraction(
+                "batch", counters, out["batched_small_clusters"]["batched_kernel_flips_per_s"])
+            out["reference_default_call"]["team_valu_issue_frac"] = issue_fraction(
+                "team", counters, out["reference_default_call"]["team_flips_per_s"])
             try:
                 out["real_kagome_36_clusters"] = bench_real_kagome_36(replicas, args.sweeps)
+                out["real_kagome_36_clusters"]["valu_issue_frac"] = issue_fraction(
+                    "real_kagome_36", counters, out["real_kagome_36_clusters"]["kernel_flips_per_s"])
             except Exception as error:  # a secondary leg never costs the headline line
                 out["real_kagome_36_clusters"] = {"error": "%s: %s" % (type(error).__name__, error)}
+        if world == 1:
+            # (also under --no-build: it is part of what the rocprofv3 passes of the bench see)
+            out["shuffled_order"] = bench_shuffled_order(clusters, replicas, args.sweeps, offset, counters)
         print(json.dumps(out))
 
     if use_dist:

@@ -359,3 +359,32 @@ def test_hamiltonian_arrays_are_frozen_against_stale_plans():
     assert ham.field[3] == 0.0
     # the usual read-only uses of the reference keep working (common.py:444,654,674)
     assert ham.exchange.tocoo().nnz == ham.exchange.nnz and ham.exchange[:5][:, :5].shape == (5, 5)
+
+
+def test_bench_roofline_refuses_counters_of_another_library_build(tmp_path, monkeypatch):
+    """bench.py multiplied the live rate by constants from a committed JSON, so a
+    changed kernel with a forgotten PMC pass still printed the old fraction.  The JSON now names
+    the library build it was measured on; any other running build gets no fraction but a reason."""
+    import json
+
+    import bench
+
+    profiles = tmp_path / "profiles"
+    profiles.mkdir()
+    counters = {"library_fingerprint": "a" * 64, "cycles_per_valu_inst": 4.35,
+                "cases": {"colour_10000": {"valu_insts_per_flip": 1.5}}}
+    (profiles / "sweep_counters.json").write_text(json.dumps(counters))
+    (profiles / "traffic.json").write_text(json.dumps({"library_fingerprint": "b" * 64, "cases": {}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    got, traffic, reason = bench.profiled_counters("a" * 64)
+    assert got == counters and reason is None
+    assert traffic is None  # measured on yet another build: dropped on its own
+    frac = bench.issue_fraction("colour_10000", got, 200e9)
+    assert abs(frac - 1.5 * 4.35 * 200 / (1024 * 2.4)) < 1e-12
+    assert bench.issue_fraction("colour_30000", got, 200e9) is None  # a case that was not profiled
+    stale, traffic, reason = bench.profiled_counters("c" * 64)
+    assert stale is None and traffic is None and "stale" in reason and "aaaaaaaaaaaa" in reason
+    assert bench.issue_fraction("colour_10000", stale, 200e9) is None
+    assert bench.profiled_counters(None)[2] is not None  # no build stamp: no fraction either
+    (profiles / "sweep_counters.json").write_text(json.dumps({"cases": {}}))  # a summary without fingerprint
+    assert bench.profiled_counters("a" * 64)[0] is None
