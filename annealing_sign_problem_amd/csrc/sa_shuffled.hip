@@ -50,6 +50,7 @@ using namespace asp::dev;
 constexpr uint32_t kPriorityCounter = 0xFFFFFFFEu;  // counter word 2 of the priority draw
 constexpr uint32_t kOrderThreads = 1024;            // threads of an order workgroup (large K)
 constexpr uint32_t kClassCap = 63;                  // rows of >= 63 quads share the last class
+constexpr uint64_t kQuadLimit = 0x100000;           // quads of one sweep: 3 KiB each within 32-bit byte offsets
 
 // status words shared by the kernels of a call (device memory, zeroed per attempt)
 enum : uint32_t { kStatBad = 0, kStatLevels = 1, kStatBlocks = 2, kStatQuads = 3, kStatWords = 4 };
@@ -68,7 +69,7 @@ struct OrderArgs {
   uint64_t seed;
   uint32_t num_spins, first_sweep, count;
   uint32_t level_cap, block_cap, quad_cap;  // capacities per sweep of the outputs below
-  uint32_t quad_stride;                     // quads between the ELLs of consecutive sweeps (> quad_cap)
+  uint32_t stream_kib;                      // KiB between the coupling streams of consecutive sweeps
   uint32_t lanes_per_row;                   // power of two <= 64: lanes sharing a row in the graph passes
   uint32_t col_shift;                       // columns are written as (neighbour << col_shift): LDS addresses
   // scratch, [count][K] each
@@ -76,11 +77,14 @@ struct OrderArgs {
   // outputs, per sweep of the chunk
   uint32_t *level_block;  // [count][level_cap + 1] first block of level l; entry [levels] = blocks
   uint32_t *num_levels;   // [count]
-  uint2 *block_meta;      // [count][block_cap] {first quad relative to the sweep's ELL, quads}
-  uint32_t *spin_of_pos;  // [count][block_cap * 64], kDummySpin = padding lane
-  double *field_of_pos;   // [count][block_cap * 64] the field of that spin
-  uint4 *ell_col;         // [count][quad_cap][64]
-  double2 *ell_val;       // [count][quad_cap][2][64]
+  uint2 *block_meta;      // [count][block_cap] {KiB offset of the block in the sweep's stream, quads}
+  uint32_t *spin_of_pos;  // [count][block_cap * 64] scratch: kDummySpin = padding lane
+  // The sweep's couplings as ONE stream per sweep, block after block in level-major order.  A
+  // block is a 1 KiB header — spin of the lane u32[64] (kDummySpin = padding lane), 256 B unused,
+  // field of that spin f64[64] — followed by 3 KiB per quad of couplings: columns uint4[64],
+  // values double2[64] (entries 0, 1), values double2[64] (entries 2, 3); the quad layout of
+  // csrc/sa_plan.cpp.  One buffer resource and one scalar offset address all of a block.
+  uint8_t *stream;        // [count][stream_kib KiB]
   uint32_t *status;
 };
 
@@ -281,11 +285,12 @@ __global__ __launch_bounds__(kOrderThreads) void k_shuffled_orders(OrderArgs a) 
     for (int step = 1; step < 64; step <<= 1) w = max(w, static_cast<uint32_t>(__shfl_xor(w, step, 64)));
     if (lane == 0) {
       block_quads[b] = w;
-      block_first[b] = w;
+      block_first[b] = 1u + 3u * w;  // KiB of the block: header + quads
     }
   }
   __syncthreads();
-  const uint32_t Q = block_exclusive_scan(block_first, B, wave_tot, ctl + 3);
+  const uint32_t kib = block_exclusive_scan(block_first, B, wave_tot, ctl + 3);
+  const uint32_t Q = (kib - B) / 3u;
   if (Q > a.quad_cap) {
     if (tid == 0) {
       atomicMax(a.status + kStatQuads, Q);
@@ -295,23 +300,23 @@ __global__ __launch_bounds__(kOrderThreads) void k_shuffled_orders(OrderArgs a) 
     return;
   }
 
-  // ---- 7. the sweep's level-major sliced ELL ----
-  uint4 *ell_col = a.ell_col + static_cast<uint64_t>(s) * a.quad_stride * 64u;
-  double2 *ell_val = a.ell_val + static_cast<uint64_t>(s) * a.quad_stride * 128u;
-  double *fop = a.field_of_pos + static_cast<uint64_t>(s) * a.block_cap * 64u;
+  // ---- 7. the sweep's coupling stream ----
+  uint8_t *stream = a.stream + static_cast<uint64_t>(s) * a.stream_kib * 1024u;
   for (uint32_t b = wave; b < B; b += waves) {
     const uint32_t i = sop[b * 64u + lane];
     const bool real = i != kDummySpin;
-    fop[b * 64u + lane] = real ? a.field[i] : 0.0;
     const uint32_t row = real ? a.rq_ptr[i] : 0u;
     const uint32_t mine = real ? a.rq_ptr[i + 1] - row : 0u;
     const uint32_t own = real ? i << a.col_shift : 0u;  // padding reads the lane's own spin (x +0.0)
     const uint32_t quads = block_quads[b];
-    const uint64_t first = block_first[b];
+    uint8_t *block = stream + static_cast<uint64_t>(block_first[b]) * 1024u;
+    reinterpret_cast<uint32_t *>(block)[lane] = i;
+    reinterpret_cast<double *>(block + 512)[lane] = real ? a.field[i] : 0.0;
     for (uint32_t q = 0; q < quads; ++q) {
       uint4 c = make_uint4(own, own, own, own);
       double2 v01 = make_double2(0.0, 0.0), v23 = make_double2(0.0, 0.0);
       if (q < mine) {
+        // (padding entries of a row carry the row's own index: shifted like every column)
         c = a.rq_col[row + q];
         c.x <<= a.col_shift;
         c.y <<= a.col_shift;
@@ -320,13 +325,12 @@ __global__ __launch_bounds__(kOrderThreads) void k_shuffled_orders(OrderArgs a) 
         v01 = a.rq_val[static_cast<uint64_t>(row + q) * 2u];
         v23 = a.rq_val[static_cast<uint64_t>(row + q) * 2u + 1u];
       }
-      ell_col[(first + q) * 64u + lane] = c;
-      ell_val[(first + q) * 128u + lane] = v01;
-      ell_val[(first + q) * 128u + 64u + lane] = v23;
+      uint8_t *quad = block + 1024u + static_cast<uint64_t>(q) * 3072u;
+      reinterpret_cast<uint4 *>(quad)[lane] = c;
+      reinterpret_cast<double2 *>(quad + 1024)[lane] = v01;
+      reinterpret_cast<double2 *>(quad + 2048)[lane] = v23;
     }
   }
-  // padding quads of a row carry the row's own column with +0.0; in the static rows the own
-  // column is the spin INDEX, so it is shifted like every other column above
 
   // ---- 8. the sweep's tables ----
   uint32_t *out_lb = a.level_block + static_cast<uint64_t>(s) * (a.level_cap + 1u);
@@ -350,10 +354,7 @@ struct ShuffledArgs {
   const uint32_t *level_block;
   const uint32_t *num_levels;
   const uint2 *block_meta;
-  const uint32_t *spin_of_pos;
-  const double *field_of_pos;
-  const uint32_t *ell_col;
-  const double *ell_val;
+  const uint8_t *stream;  // the coupling streams of the chunk's sweeps (k_shuffled_orders)
   const uint32_t *status;
   const double *betas;  // all sweeps of the call
   const uint64_t *x0;   // packed original-order start configuration or nullptr
@@ -363,7 +364,7 @@ struct ShuffledArgs {
   unsigned long long *accepted;  // [groups * M]
   uint64_t seed;
   double scale;
-  uint32_t num_spins, words, level_cap, block_cap, quad_stride;
+  uint32_t num_spins, words, level_cap, block_cap, stream_kib;
   uint32_t first_sweep, chunk_sweeps, replica_first, initialise;
 };
 
@@ -418,18 +419,19 @@ __device__ __forceinline__ BufferRsrc make_rsrc(const void *base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0xFFFFFFFF, 0x00020000);
 }
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
-// Four consecutive ELL entries of one lane as the three loads deliver them (native vectors: a
+// Four consecutive couplings of one lane as the three loads deliver them (native vectors: a
 // bit cast, no component shuffling — a shuffle would have to wait for the load)
 struct HeldQuad {
   u32x4 c;
   f64x2 v01, v23;
 };
-__device__ __forceinline__ void load_quad_buffer(HeldQuad &q, BufferRsrc cols, BufferRsrc vals, uint32_t quad,
-                                                 uint32_t lane16) {
-  q.c = __builtin_amdgcn_raw_buffer_load_b128(cols, lane16, quad * 1024u, 0);
-  q.v01 = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(vals, lane16, quad * 2048u, 0));
-  q.v23 = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(vals, lane16 + 1024u, quad * 2048u, 0));
+// `at` = byte offset of the quad in the sweep's stream (scalar); lane16 = lane * 16
+__device__ __forceinline__ void load_quad_buffer(HeldQuad &q, BufferRsrc stream, uint32_t at, uint32_t lane16) {
+  q.c = __builtin_amdgcn_raw_buffer_load_b128(stream, lane16, at, 0);
+  q.v01 = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(stream, lane16 + 1024u, at, 0));
+  q.v23 = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(stream, lane16 + 2048u, at, 0));
 }
 
 template <int LAYOUT>
@@ -623,10 +625,7 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
       for (uint32_t b = tid; b < blocks; b += blockDim.x) meta[b] = g_meta[b];
       __syncthreads();  // (the previous sweep's last use of the tables is behind its final barriers)
     }
-    const uint32_t *sop = a.spin_of_pos + static_cast<uint64_t>(tt) * a.block_cap * 64u;
-    const double *fop = a.field_of_pos + static_cast<uint64_t>(tt) * a.block_cap * 64u;
-    const uint4 *ell_col = reinterpret_cast<const uint4 *>(a.ell_col) + static_cast<uint64_t>(tt) * a.quad_stride * 64u;
-    const double2 *ell_val = reinterpret_cast<const double2 *>(a.ell_val) + static_cast<uint64_t>(tt) * a.quad_stride * 128u;
+    const BufferRsrc stream = make_rsrc(a.stream + static_cast<uint64_t>(tt) * a.stream_kib * 1024u);
     long long q_acc[M];
     uint32_t n_acc[M];
 #pragma unroll
@@ -639,27 +638,19 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
     uint32_t held_quads = 0, held_spin = kDummySpin, held_first = 0;
     double held_h = 0.0;
     HeldQuad hq[kHeldQuads];
-    const BufferRsrc rsrc_col = make_rsrc(ell_col), rsrc_val = make_rsrc(ell_val);
     const uint32_t lane16 = lane * 16u;
-    // requests everything of block `nb` that does not depend on other loads (ONE call site inside
-    // the loops, so that the registers of the quads are not duplicated)
-    auto request = [&](uint32_t nb) {
-      if (nb == kNoBlock) {
-        held_quads = 0;
-        held_spin = kDummySpin;
-        return;
-      }
-      const uint2 info = meta[nb];
-      held_quads = __builtin_amdgcn_readfirstlane(info.y);
-      held_first = __builtin_amdgcn_readfirstlane(info.x);
-      held_spin = sop[nb * 64u + lane];
-      held_h = fop[nb * 64u + lane];
-      // every register set is (re)defined by every request — those beyond the block's width
-      // with "any value" — so that nothing of the previous block stays live across the visit
+    // Requests block `nb`: what does not depend on other loads, in two instalments — a compute
+    // unit keeps only so many cache misses in flight (a burst of 36 KiB per wavefront stalls the
+    // issuing wavefront until the queue drains), so the header and the first half of the quads go
+    // out after the row sums, the second half after the accept phase.  Every register set is
+    // (re)defined by every request — those beyond the block's width with "any value" — so that
+    // nothing of the previous block stays live across the visit; ONE call site each inside the
+    // loops, so that the registers of the quads are not duplicated.
+    auto request_quads = [&](int lo, int hi) {
 #pragma unroll
-      for (int j = 0; j < kHeldQuads; ++j) {
+      for (int j = lo; j < hi; ++j) {
         if (ASP_SHUF_ABL != 3 && static_cast<uint32_t>(j) < held_quads) {
-          load_quad_buffer(hq[j], rsrc_col, rsrc_val, held_first + static_cast<uint32_t>(j), lane16);
+          load_quad_buffer(hq[j], stream, held_first + 1024u + static_cast<uint32_t>(j) * 3072u, lane16);
         } else {
           hq[j].c = __builtin_nondeterministic_value(hq[j].c);
           hq[j].v01 = __builtin_nondeterministic_value(hq[j].v01);
@@ -667,11 +658,26 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
         }
       }
     };
+    auto request_first = [&](uint32_t nb) {
+      if (nb == kNoBlock) {
+        held_quads = 0;
+        held_spin = kDummySpin;
+      } else {
+        const uint2 info = meta[nb];
+        held_quads = __builtin_amdgcn_readfirstlane(info.y);
+        held_first = __builtin_amdgcn_readfirstlane(info.x) << 10;  // byte offset of the block
+        held_spin = __builtin_amdgcn_raw_buffer_load_b32(stream, lane * 4u, held_first, 0);
+        held_h = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(stream, 512u + lane * 8u, held_first, 0));
+      }
+      request_quads(0, kHeldQuads / 2);
+    };
+    auto request_rest = [&]() { request_quads(kHeldQuads / 2, kHeldQuads); };
     uint32_t lb_begin = level_block[0];
     uint32_t lb_end = level_block[levels ? 1u : 0u];
     {
       const uint32_t first = lb_begin + wave;
-      request(first < lb_end ? first : kNoBlock);
+      request_first(first < lb_end ? first : kNoBlock);
+      request_rest();
     }
     for (uint32_t l = 0; l < levels; ++l) {
       // the level after this one: its blocks are lb_end .. lb_after
@@ -714,10 +720,10 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
             // a block wider than the registers hold (rows of more than 4 kHeldQuads couplings):
             // the rest streams with one quad in flight
             HeldQuad qa, qb;
-            load_quad_buffer(qa, rsrc_col, rsrc_val, held_first + kHeldQuads, lane16);
+            load_quad_buffer(qa, stream, held_first + 1024u + kHeldQuads * 3072u, lane16);
             for (uint32_t j = kHeldQuads; j < quads; ++j) {
               // (one quad past the block at the end: never used)
-              load_quad_buffer(qb, rsrc_col, rsrc_val, held_first + j + 1u, lane16);
+              load_quad_buffer(qb, stream, held_first + 1024u + (j + 1u) * 3072u, lane16);
               __builtin_amdgcn_sched_barrier(0);
               gather_quad<LAYOUT>(qa, sa);
               apply_quad<M, LAYOUT>(qa, sa, acc, one_hi);
@@ -729,7 +735,9 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
         // the registers are free: the next block's loads fly during the accept phase and the barrier
         // (a wavefront without a block in this level holds nothing and requests its block of the
         // next level, if it has one there)
-        request(nb);
+        __builtin_amdgcn_sched_barrier(0);
+        request_first(nb);
+        __builtin_amdgcn_sched_barrier(0);
         ASP_TICK(1);
         if (busy && ASP_SHUF_ABL != 2) {
           const uint32_t own = WIDE ? wide[me] : static_cast<uint32_t>(spins[me]);
@@ -788,6 +796,9 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
             }
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        request_rest();
+        __builtin_amdgcn_sched_barrier(0);
         ASP_TICK(2);
         if (!same_level) break;
         b = nb;
@@ -937,10 +948,8 @@ struct ShuffledRun {
   DeviceBuffer<uint32_t> d_status, d_prio, d_indeg, d_order;
   struct OrderSet {
     DeviceBuffer<uint32_t> level_block, num_levels, spin_of_pos;
-    DeviceBuffer<double> field_of_pos;
     DeviceBuffer<uint2> block_meta;
-    DeviceBuffer<uint4> ell_col;
-    DeviceBuffer<double2> ell_val;
+    DeviceBuffer<uint8_t> stream;
   } sets[2];
 
   ShuffledRun() = default;
@@ -1064,10 +1073,12 @@ struct ShuffledRun {
       const uint64_t tight = (static_cast<uint64_t>(p->rq_quads) + 63) / 64 +
                              static_cast<uint64_t>(level_cap) * max_quads;
       const uint64_t loose = static_cast<uint64_t>(block_cap) * max_quads;
-      quad_cap = static_cast<uint32_t>(std::min<uint64_t>(max_quads < kClassCap ? tight : loose, 0x1FFFFFull));
+      quad_cap = static_cast<uint32_t>(std::min<uint64_t>(max_quads < kClassCap ? tight : loose, kQuadLimit));
     }
-    const uint32_t quad_alloc = quad_cap + 2;  // slack: the sweep kernel reads one quad past a wide block
-    const uint64_t per_sweep = static_cast<uint64_t>(quad_alloc) * 64 * 48 + static_cast<uint64_t>(block_cap) * (768 + 8) +
+    // KiB of one sweep's stream: a header per block, 3 KiB per quad, and slack for the sweep
+    // kernel's read of one quad past a wide block (< 4 GiB: 32-bit scalar offsets)
+    const uint32_t stream_kib = block_cap + 3u * (quad_cap + 2u);
+    const uint64_t per_sweep = static_cast<uint64_t>(stream_kib) * 1024 + static_cast<uint64_t>(block_cap) * (256 + 8) +
                                (level_cap + 1ull) * 4 + 12ull * K;
     uint32_t chunk = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(256, budget / per_sweep)));
     chunk = std::max(1u, std::min(chunk, (num_sweeps + 3) / 4));  // at least four chunks: the pipeline needs them
@@ -1090,9 +1101,7 @@ struct ShuffledRun {
       ASP_TRY(o.num_levels.ensure(chunk));
       ASP_TRY(o.block_meta.ensure(static_cast<uint64_t>(chunk) * block_cap));
       ASP_TRY(o.spin_of_pos.ensure(static_cast<uint64_t>(chunk) * block_cap * 64));
-      ASP_TRY(o.field_of_pos.ensure(static_cast<uint64_t>(chunk) * block_cap * 64));
-      ASP_TRY(o.ell_col.ensure(static_cast<uint64_t>(chunk) * quad_alloc * 64));
-      ASP_TRY(o.ell_val.ensure(static_cast<uint64_t>(chunk) * quad_alloc * 128));
+      ASP_TRY(o.stream.ensure(static_cast<uint64_t>(chunk) * stream_kib * 1024));
     }
     ASP_HIP_TRY(hipMemsetAsync(d_status.ptr, 0, (kStatWords + 2 * kTimingSlots * kTimingWaves) * sizeof(uint32_t), s));
     ASP_HIP_TRY(hipEventRecord(p->ev[0], s));
@@ -1108,7 +1117,7 @@ struct ShuffledRun {
     oa.level_cap = level_cap;
     oa.block_cap = block_cap;
     oa.quad_cap = quad_cap;
-    oa.quad_stride = quad_alloc;
+    oa.stream_kib = stream_kib;
     oa.lanes_per_row = lanes_per_row;
     oa.col_shift = wide ? 2u : 0u;
     oa.prio = d_prio.ptr;
@@ -1130,7 +1139,7 @@ struct ShuffledRun {
     a.words = words;
     a.level_cap = level_cap;
     a.block_cap = block_cap;
-    a.quad_stride = quad_alloc;
+    a.stream_kib = stream_kib;
     a.replica_first = replica_offset;
 
     bool first_launch = true;
@@ -1149,9 +1158,7 @@ struct ShuffledRun {
         oa.num_levels = o.num_levels.ptr;
         oa.block_meta = o.block_meta.ptr;
         oa.spin_of_pos = o.spin_of_pos.ptr;
-        oa.field_of_pos = o.field_of_pos.ptr;
-        oa.ell_col = o.ell_col.ptr;
-        oa.ell_val = o.ell_val.ptr;
+        oa.stream = o.stream.ptr;
         hipLaunchKernelGGL(k_shuffled_orders, dim3(now), dim3(order_threads), order_lds, order_stream.stream, oa);
         ASP_HIP_TRY(hipGetLastError());
         ASP_HIP_TRY(hipEventRecord(ordered[which], order_stream.stream));
@@ -1160,10 +1167,7 @@ struct ShuffledRun {
       a.level_block = o.level_block.ptr;
       a.num_levels = o.num_levels.ptr;
       a.block_meta = o.block_meta.ptr;
-      a.spin_of_pos = o.spin_of_pos.ptr;
-      a.field_of_pos = o.field_of_pos.ptr;
-      a.ell_col = reinterpret_cast<const uint32_t *>(o.ell_col.ptr);
-      a.ell_val = reinterpret_cast<const double *>(o.ell_val.ptr);
+      a.stream = o.stream.ptr;
       a.first_sweep = done;
       a.chunk_sweeps = now;
       a.initialise = first_launch ? 1u : 0u;
@@ -1194,7 +1198,7 @@ struct ShuffledRun {
       level_cap = static_cast<uint32_t>(std::min<uint64_t>(K, 2ull * status[kStatLevels] + 16));
       quad_cap = 0;
     } else {
-      quad_cap = static_cast<uint32_t>(std::min<uint64_t>(0x1FFFFFull, 2ull * std::max(status[kStatQuads], quad_cap)));
+      quad_cap = static_cast<uint32_t>(std::min<uint64_t>(kQuadLimit, 2ull * std::max(status[kStatQuads], quad_cap)));
     }
     *again = true;
     return ASP_OK;
