@@ -101,6 +101,31 @@ class Hamiltonian:
         self._plan = None
         self._plan_key = None
 
+    @classmethod
+    def from_canonical_csr(cls, indptr, indices, data, field) -> "Hamiltonian":
+        """A Hamiltonian from CSR arrays that ARE canonical already — rows in order, columns
+        sorted and duplicate-free, as the device builders deliver them (asp_operator_ising,
+        asp_sparsify_component) — without the copy, ``sum_duplicates`` and ``sort_indices`` of the
+        general constructor (a quarter of the host time of a sampled-cluster run went there).  The
+        arrays are adopted and frozen; ``asp_sa_plan_create`` still validates them."""
+        indptr = np.ascontiguousarray(indptr)
+        n = indptr.shape[0] - 1
+        matrix = scipy.sparse.csr_matrix((np.ascontiguousarray(data, dtype=np.float64),
+                                          np.ascontiguousarray(indices), indptr), shape=(n, n), copy=False)
+        matrix.has_sorted_indices = True
+        matrix.has_canonical_format = True
+        field = np.ascontiguousarray(field, dtype=np.float64)
+        if field.shape != (n,):
+            raise ValueError("'field' must have shape ({},)".format(n))
+        self = cls.__new__(cls)
+        for array in (matrix.data, matrix.indices, matrix.indptr, field):
+            array.flags.writeable = False
+        self.exchange = matrix
+        self.field = field
+        self._plan = None
+        self._plan_key = None
+        return self
+
     @property
     def shape(self) -> Tuple[int, int]:
         return self.exchange.shape

@@ -166,6 +166,7 @@ def make_ising_model(
     psi /= np.linalg.norm(psi)
 
     matrix = None
+    ising_hamiltonian = None
     if _on_device(quantum_hamiltonian):
         # action, search, elements and (M + M^T)/2 on the GPU, nothing materialised on the host
         # (csrc/operator_apply.hip): the pair-fused pass for operators whose rows reach distinct
@@ -173,11 +174,14 @@ def make_ising_model(
         # AND one-directional matrix elements are refused: host route below.
         try:
             row, col, val = quantum_hamiltonian.device().ising(spins, psi)
-            matrix = scipy.sparse.coo_matrix((val, (row, col)), shape=(n, n))
+            # row-major, columns ascending, no duplicates (csrc/operator_apply.hip): CSR by counting
+            indptr = np.zeros(n + 1, dtype=np.int32 if val.shape[0] < 2**31 else np.int64)
+            np.cumsum(np.bincount(row, minlength=n), out=indptr[1:])
+            ising_hamiltonian = sa.Hamiltonian.from_canonical_csr(indptr, col, val, np.zeros(n))
         except _lib.AspError as error:
             if error.code != -3:
                 raise
-    if matrix is None:
+    if ising_hamiltonian is None:
         other_spins, other_coeffs, other_counts = _batched_apply(quantum_hamiltonian, spins)
         other_indices, _member, elements, offsets = ising_elements(
             spins, psi, other_spins, other_coeffs, other_counts)
@@ -185,9 +189,7 @@ def make_ising_model(
         matrix = 0.5 * (matrix + matrix.T)
         matrix.sort_indices()
         matrix = matrix.tocoo()
-
-    field = np.zeros(n, dtype=np.float64)
-    ising_hamiltonian = sa.Hamiltonian(matrix, field)
+        ising_hamiltonian = sa.Hamiltonian(matrix, np.zeros(n, dtype=np.float64))
     x0 = sa.signs_to_bits(np.sign(psi))
     return IsingModel(spins, quantum_hamiltonian, ising_hamiltonian, x0)
 
@@ -321,6 +323,8 @@ def sparsify_component(exchange, is_frozen, reltol: float, anchor: int):
     n, z = int(kept.value), int(nnz.value)
     block = scipy.sparse.csr_matrix((out_data[:z].copy(), out_indices[:z].copy(),
                                      out_indptr[:n + 1].astype(np.int32)), shape=(n, n))
+    block.has_sorted_indices = True  # (rows of a canonical matrix restricted to a subset)
+    block.has_canonical_format = True
     return keep[:k].astype(bool), block
 
 
@@ -337,8 +341,8 @@ def sparsify_using_global_cutoff(model: IsingModel, reltol: float, frozen_spins)
     spins = model.spins[keep]
     signs = sa.bits_to_signs(model.initial_signs, model.size)[keep]
     field = model.ising_hamiltonian.field[keep]
-    return IsingModel(spins, model.quantum_hamiltonian, sa.Hamiltonian(exchange, field),
-                      sa.signs_to_bits(signs))
+    hamiltonian = sa.Hamiltonian.from_canonical_csr(exchange.indptr, exchange.indices, exchange.data, field)
+    return IsingModel(spins, model.quantum_hamiltonian, hamiltonian, sa.signs_to_bits(signs))
 
 
 def invert_permutation(p) -> np.ndarray:

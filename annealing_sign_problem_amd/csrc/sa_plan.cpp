@@ -4,7 +4,9 @@
 #include "sa_plan.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <functional>
 #include <limits>
@@ -60,6 +62,17 @@ unsigned host_threads(uint64_t n) {
 int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *indices,
                     const double *data, const double *field, SaHostLayout *out) {
   const uint64_t n = num_spins;
+  // ASP_PLAN_TIMING=1: stage times of this function on stderr (development aid)
+  const bool timing = std::getenv("ASP_PLAN_TIMING") != nullptr;
+  auto clock_now = [] { return std::chrono::steady_clock::now(); };
+  auto stage_start = clock_now();
+  auto stage = [&](const char *name) {
+    if (!timing) return;
+    const auto now = clock_now();
+    std::fprintf(stderr, "  plan stage %-12s %8.3f ms\n", name,
+                 std::chrono::duration<double, std::milli>(now - stage_start).count());
+    stage_start = now;
+  };
   if (n >= (1ull << 31)) {
     return set_error(ASP_ERR_TOO_LARGE, "%llu spins exceed the 2^31 limit", (unsigned long long)n);
   }
@@ -98,6 +111,7 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
     }
   }
 
+  stage("validate");
   // ---- J^T by rows (bucket the entries by column; rows are visited in order so
   //      every bucket ends up sorted by original row) --------------------------
   const unsigned parts = host_threads(n);
@@ -132,6 +146,7 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
     });
   }
 
+  stage("transpose");
   // ---- A = offdiag(J + J^T), D = sum_i J_ii ----------------------------------
   // Row i of A is the merge of row i of J and row i of J^T; two passes (count, fill) so that
   // the rows can be produced in parallel.  emit(col, value) is called in column order.
@@ -197,6 +212,7 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
   L.diag_sum = diag;
   std::vector<Entry>().swap(t_entries);
 
+  stage("merge A");
   // ---- DSATUR colouring (Brelaz 1979) --------------------------------
   // Repeatedly colour the uncoloured spin with the most DISTINCT colours among its
   // neighbours (ties: larger degree, then smaller index) with the smallest colour none of
@@ -297,6 +313,7 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
     L.num_colors = ncol;
   }
 
+  stage("colouring");
   // ---- permutation: (colour asc, degree desc, index asc) ----------------------
   std::vector<uint32_t> order(n);
   std::iota(order.begin(), order.end(), 0u);
@@ -309,6 +326,7 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
     L.max_degree = std::max<uint32_t>(L.max_degree, static_cast<uint32_t>(degree(i)));
   }
 
+  stage("permutation");
   // ---- blocks ------------------------------------------------------------------
   L.color_block_start.assign(L.num_colors + 1, 0);
   L.pos_of_spin.assign(n, 0);
@@ -344,6 +362,7 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
     L.num_blocks = block;
   }
 
+  stage("blocks");
   // ---- sliced ELL ----------------------------------------------------------------
   L.ell_off.assign(L.num_blocks + 1, 0);
   for (uint32_t b = 0; b < L.num_blocks; ++b) L.ell_off[b + 1] = L.ell_off[b] + L.block_width[b];
@@ -385,6 +404,7 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
   }
   });
 
+  stage("ELL fill");
   // ---- energy scale and automatic beta range ----------------------------------------
   double bound = 0.0;      // B = 1/2 sum|A| + sum|h|  (E - D ranges within +-B)
   double max_delta = 0.0;  // max_i 2 (sum_j |A_ij| + |h_i|)
@@ -416,6 +436,7 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
   } else {
     L.beta0_auto = L.beta1_auto = 1.0;
   }
+  stage("scales");
   return ASP_OK;
 }
 

@@ -9,6 +9,10 @@ of the REAL 36- and 32-site models, whose ground states are computed on the GPU 
   config 3  heisenberg_kagome_36: a sampled cluster extended twice (K ~ 1e4), 1024 replicas
   config 4  heisenberg_pyrochlore_2x2x2: cluster extension with CUTOFF = 2e-6, replicas in two
             shards (global replica ids) equal to one call
+  config 5  sk_32_1 + NOISE = 0.79: a sampled cluster of the real model extended once — its
+            basis states and noisy amplitudes are a committed fixture (the 6.0e8-state ground
+            state takes four minutes of GPU time: tests/golden/generate_config_fixtures.py) —, couplings
+            rebuilt here, 4096 replicas
 
 Each test goes model YAML -> exact ground state -> make_ising_model (GPU) -> sa.anneal (GPU)
 through the package's reference-named entry points and compares with the CPU oracle bit for
@@ -178,3 +182,55 @@ def test_config4_pyrochlore_real_cluster_cutoff_and_replica_shards(models):
     hi = sa.anneal_raw(h, 435834, betas, 256, 256)
     assert np.array_equal(np.concatenate([lo[0], hi[0]]), xs)
     assert np.concatenate([lo[1], hi[1]]).tobytes() == es.tobytes()
+
+
+def test_config5_sk32_real_cluster_noise_4096_replicas(models):
+    """BASELINE config 5 on the REAL model (reference Makefile:129-141, physical_systems/
+    sk_32_1.yaml:1-4, NOISE = 0.79): the order-1 model of a sampled cluster, K = 5e4 spins with up
+    to 256 couplings each.  The fixture holds the model's inputs (basis states, noisy
+    cluster-normalised amplitudes); the couplings are rebuilt from them with asp_operator_ising
+    and must be the ones of the run that made the fixture and the oracle's, the colour-ordered
+    and the shuffled chains equal the oracle's bit for bit, and 4096 replicas satisfy the
+    size-independent properties."""
+    import hashlib
+
+    import scipy.sparse
+
+    from annealing_sign_problem_amd import annealer as sa
+    from annealing_sign_problem_amd import operators
+    from conftest import golden
+
+    data = golden("config5_sk32_cluster.npz")
+    spins, psi = data["spins"], data["psi"]
+    k = spins.shape[0]
+    assert k > 20000 and abs(np.linalg.norm(psi) - 1.0) < 1e-12 and float(data["noise"]) == 0.79
+    op = operators.Operator.from_config(models["sk_32_1"])
+    assert op.basis.number_spins == 32 and len(op.bond_table()[0]) == 496
+    row, col, val = op.device().ising(spins, psi)
+    assert val.shape[0] == int(data["nnz"])
+    assert hashlib.sha256(row.tobytes() + col.tobytes() + val.tobytes()).hexdigest() == str(data["sha256"])
+    qrow, qcol, qval = oracle.operator_ising(op.bond_table(), spins, psi)
+    assert np.array_equal(row, qrow) and np.array_equal(col, qcol) and val.tobytes() == qval.tobytes()
+    J = scipy.sparse.coo_matrix((val, (row, col)), shape=(k, k)).tocsr()
+    h = sa.Hamiltonian(J, np.zeros(k))
+    info = h.info()
+    assert info.max_degree >= 200 and J.nnz / k > 30  # the dense rows of an all-to-all model
+    _chains_vs_oracle(h, 435834, 12, 8, 8)
+    # the reference annealer's visiting order on rows of 64 quads (they stream past the registers)
+    betas = sa.make_schedule(info.beta0_auto, info.beta1_auto, 6)
+    xs, es = sa.anneal_raw(h, 435834, betas, 4, 0, None, shuffled=True)
+    oxs, oes, _, _ = oracle.sa_anneal_shuffled(J, h.field, 435834, betas, 4, 0, None,
+                                               info.energy_scale_exp, num_threads=4)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    # 4096 replicas (the configuration's size): reported energies are those of the returned
+    # configurations, no chain ends above its random start on average, shards are the one call
+    betas = sa.make_schedule(info.beta0_auto, info.beta1_auto, 64)
+    xs, es = sa.anneal_raw(h, 783494, betas, 4096)
+    signs = [sa.bits_to_signs(x, k) for x in xs[:64]]
+    again = np.array([v @ (J @ v) for v in signs])  # E = s^T J s (common.py:757-760), numpy
+    assert np.allclose(again, es[:64], rtol=1e-12, atol=0)
+    lo = sa.anneal_raw(h, 783494, betas, 64, 0)
+    hi = sa.anneal_raw(h, 783494, betas, 64, 4032)
+    assert np.array_equal(lo[0], xs[:64]) and np.array_equal(hi[0], xs[4032:])
+    assert lo[1].tobytes() == es[:64].tobytes() and hi[1].tobytes() == es[4032:].tobytes()
+    assert es.min() < es.mean() <= 0.0  # sign-problem couplings: annealed energies are negative
