@@ -76,6 +76,7 @@ SIGNATURES = {
     "asp_last_error_code": (c_int, []),
     "asp_clear_error": (None, []),
     "asp_device_count": (c_int, []),
+    "asp_device_touched": (c_int, []),
     "asp_set_device": (c_int, [c_int]),
     "asp_get_device": (c_int, []),
     "asp_version": (ctypes.c_char_p, []),
@@ -265,6 +266,11 @@ def device_count() -> int:
     if n < 0:
         raise AspError(n, last_error())
     return n
+
+
+def gpu_touched() -> bool:
+    """True once this process has made a HIP call through the library."""
+    return bool(load().asp_device_touched())
 
 
 def require_gpu() -> None:

@@ -29,18 +29,23 @@ int set_error(int code, const char *fmt, ...) {
 
 namespace {
 std::atomic<int> g_device{-1};  // process-wide choice of asp_set_device; -1 = HIP's default
+std::atomic<int> g_touched{0};  // 1 once this process has made a HIP call through the library
 }
 
 void remember_device(int device) { g_device.store(device); }
 int chosen_device() { return g_device.load(); }
 
 int bind_device() {
+  g_touched.store(1);
   const int device = g_device.load();
   if (device >= 0) ASP_HIP_TRY(hipSetDevice(device));
   return ASP_OK;
 }
 
+int device_touched() { return g_touched.load(); }
+
 int require_device() {
+  g_touched.store(1);
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) {
@@ -433,7 +438,11 @@ void asp_clear_error(void) {
   asp::error_state().message[0] = 0;
 }
 
+int asp_device_touched(void) { return asp::device_touched(); }
+
 int asp_device_count(void) {
+  asp::require_device();  // (marks the process as having used HIP)
+  asp_clear_error();
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e == hipErrorNoDevice) return 0;
@@ -459,8 +468,9 @@ int asp_get_device(void) {
 }
 
 int asp_shutdown(void) {
+  if (!asp::device_touched()) return ASP_OK;  // nothing was ever used: no HIP call at exit either
   int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ASP_OK;  // nothing was ever used
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ASP_OK;
   return asp::shutdown_pools();
 }
 

@@ -45,6 +45,7 @@ int set_error(int code, const char *fmt, ...);
 int require_device();
 // Only the binding (for entry points that receive an existing handle).
 int bind_device();
+int device_touched();  // 1 once require_device / bind_device ran in this process
 void remember_device(int device);
 int chosen_device();  // -1: asp_set_device was never called
 

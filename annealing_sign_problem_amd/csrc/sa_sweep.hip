@@ -1284,6 +1284,14 @@ asp_sa_plan *asp_sa_plan_create(uint64_t num_spins, int64_t const *indptr, int32
     return nullptr;
   }
   const asp::SaHostLayout &L = p->host;
+  // ASP_SA_TEAM=0: no team sweeps in this process — several processes share the device (worker
+  // processes or ranks of the pipeline on one GPU), and a team launch needs all its workgroups
+  // resident together, which another process's kernels can prevent (the watchdog then costs
+  // seconds before the rerun without teams)
+  if (const char *env = std::getenv("ASP_SA_TEAM")) {
+    const int team = std::atoi(env);
+    if (team == 0 || team == 2 || team == 4 || team == 8) p->team_mode = team;
+  }
   bool ok = asp::stream_acquire(&p->stream) == ASP_OK;
   for (auto &e : p->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
   if (!ok) asp::set_error(ASP_ERR_HIP, "could not create HIP stream/events");

@@ -54,6 +54,9 @@ def init_from_env(backend: Optional[str] = None) -> bool:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("ASP_SINGLE_DEVICE") == "1":
         local_rank = 0
+        if int(os.environ["WORLD_SIZE"]) > 1:
+            # several ranks on one GPU: a team sweep needs all its workgroups resident together
+            os.environ.setdefault("ASP_SA_TEAM", "0")
     gpus = _lib.device_count()
     backend = backend or os.environ.get("ASP_DIST_BACKEND") or ("nccl" if gpus > 0 else "gloo")
     if gpus > 0:

@@ -21,6 +21,8 @@ from __future__ import annotations
 
 import argparse
 import os
+import sys
+import time
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -246,6 +248,13 @@ def parse_command_line(argv=None):
                         help="visiting order of the annealing sweeps: 'colour' (this package's "
                              "default, fixed) or 'shuffled' (a fresh random order every sweep: the "
                              "reference annealer's statistics)")
+    parser.add_argument("--workers", type=int, default=0,
+                        help="worker PROCESSES (forked after the inputs are loaded, so the ground state "
+                             "is shared, not read once per rank); worker k computes on GPU k mod "
+                             "(number of GPUs) and runs --jobs threads: one command for a multi-GPU "
+                             "node.  On ONE GPU it does not pay (the device multiplexes processes at "
+                             "a higher cost than the interpreter lock: profiles/r03_pipeline_workers.txt)."
+                             "  The output does not depend on it")
     parser.add_argument("--jobs", type=int, default=1,
                         help="host threads building / solving clusters concurrently (independent "
                              "plans and HIP streams on one GPU; the output does not depend on it)")
@@ -281,10 +290,136 @@ def load_input(args):
     return hamiltonian, np.ascontiguousarray(ground_state[order])
 
 
+_WORKER = {}
+
+
+def _generate_in_child(conn, hamiltonian, ground_state, args):
+    """Cluster growth uses the GPU action; done in a child so that the parent stays free of
+    any HIP state and can fork its workers afterwards."""
+    try:
+        clusters = generate_clusters(hamiltonian, ground_state, args.number_samples, args.sampled_power,
+                                     args.min_cluster_size, args.max_cluster_size, args.keep_probability)
+        conn.send(("ok", clusters))
+    except BaseException as error:  # noqa: BLE001 - reported to the parent
+        conn.send(("error", "%s: %s" % (type(error).__name__, error)))
+    finally:
+        conn.close()
+        os._exit(0)  # no interpreter teardown in a forked child that used the GPU
+
+
+def _worker_init():
+    """Worker k computes on GPU k mod (number of GPUs): on a multi-GPU node one command fills all
+    of them from one copy of the inputs; on a one-GPU box the workers share the device."""
+    import multiprocessing
+
+    from . import _lib
+
+    identity = multiprocessing.current_process()._identity
+    index = (identity[0] - 1) if identity else 0
+    devices = _lib.device_count()
+    if devices > 1:
+        _lib.check(_lib.load().asp_set_device(index % devices))
+    if devices <= 1 or _WORKER["args"].workers > devices:
+        os.environ.setdefault("ASP_SA_TEAM", "0")  # several processes share a device
+
+
+def _worker_chunk(indices):
+    """CSV lines of clusters[indices], computed in a worker process (inputs inherited by fork)."""
+    w = _WORKER
+    started = time.perf_counter()
+    if "log_coeff_fn" not in w:
+        w["log_coeff_fn"] = common.ground_state_to_log_coeff_fn(w["noisy_ground_state"], w["hamiltonian"].basis)
+    args = w["args"]
+    if os.environ.get("ASP_WORKER_TIMING"):  # development aid
+        import atexit  # noqa: F401
+
+        def report(lines, t0=started, first=indices[0]):
+            sys.stderr.write("worker %d: clusters %d..%d in %.2f s\n" % (
+                os.getpid(), first, indices[-1], time.perf_counter() - t0))
+            return lines
+    else:
+        report = lambda lines: lines  # noqa: E731
+    some = [w["clusters"][c] for c in indices]
+    if args.batch > 1 and args.annealing:
+        chunk = process_clusters_batched(some, w["hamiltonian"], w["ground_state"], w["noisy_ground_state"],
+                                         w["log_coeff_fn"], args.order, args.global_cutoff, args.annealing,
+                                         jobs=args.jobs, sweep_order=args.sweep_order)
+        return report([",".join(r.to_csv_str() for r in columns) for columns in chunk])
+
+    def work(cluster):
+        return process_cluster(cluster, w["hamiltonian"], w["ground_state"], w["noisy_ground_state"],
+                               w["log_coeff_fn"], args.order, args.global_cutoff, args.annealing,
+                               args.sweep_order)
+
+    if args.jobs > 1 and len(some) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=args.jobs) as pool:
+            return report([",".join(r.to_csv_str() for r in columns) for columns in pool.map(work, some)])
+    return report([",".join(r.to_csv_str() for r in work(c)) for c in some])
+
+
+def _write_header(args):
+    with open(args.output, "w") as f:
+        f.write("# Generated by annealing_sign_problem_amd.sampled_components\n")
+        for key in ["seed", "order", "noise", "global_cutoff", "sampled_power",
+                    "min_cluster_size", "max_cluster_size", "keep_probability",
+                    "number_sweeps", "repetitions"]:
+            f.write("# {} = {}\n".format(key, getattr(args, key)))
+        f.write("# {}\n".format(OptimizationResult.csv_header()))
+
+
+def _main_with_workers(args):
+    """One command, several worker processes on the GPU.  The parent loads the inputs (no GPU
+    call), a first child grows the clusters (GPU), then ``--workers`` children are FORKED: the
+    ground state (0.5 GB for kagome_36, 10 GB for sk_32_1) is shared copy-on-write instead of
+    read once per rank, every worker has its own interpreter (no lock shared between them), its
+    own HIP context and streams, and takes rounds of ``--batch`` clusters from a common queue;
+    the parent appends the lines in cluster order as the rounds come back.  Same file as the
+    single process: all random draws happen before the first cluster is solved."""
+    import multiprocessing
+
+    if os.path.exists(args.output):
+        raise SystemExit("Output file '{}' already exists: refusing to overwrite".format(args.output))
+    np.random.seed(args.seed)
+    hamiltonian, ground_state = load_input(args)
+    noisy_ground_state = (common.add_noise_to_amplitudes(ground_state, args.noise) if args.noise > 0
+                          else ground_state)
+    ctx = multiprocessing.get_context("fork")
+    receiver, sender = ctx.Pipe(False)
+    child = ctx.Process(target=_generate_in_child, args=(sender, hamiltonian, ground_state, args))
+    child.start()
+    sender.close()
+    status, clusters = receiver.recv()
+    child.join()
+    if status != "ok":
+        raise SystemExit("cluster generation failed: " + clusters)
+    _write_header(args)
+    _WORKER.update(hamiltonian=hamiltonian, ground_state=ground_state,
+                   noisy_ground_state=noisy_ground_state, args=args, clusters=clusters)
+    step = max(args.batch, 1) if args.annealing else max(1, min(16, args.batch))
+    rounds = [list(range(start, min(start + step, len(clusters)))) for start in range(0, len(clusters), step)]
+    with ctx.Pool(processes=args.workers, initializer=_worker_init) as pool:
+        for lines in pool.imap(_worker_chunk, rounds):  # (in order: the file grows round by round)
+            with open(args.output, "a") as f:
+                for line in lines:
+                    f.write(line + "\n")
+
+
 def main(argv=None):
     from . import distributed as asp_dist
 
     args = parse_command_line(argv)
+    if args.workers > 1 and "RANK" not in os.environ:
+        from . import _lib
+
+        if _lib.gpu_touched():
+            import warnings
+
+            warnings.warn("--workers needs a process that has not used the GPU yet: running with "
+                          "--jobs threads instead")
+        else:
+            return _main_with_workers(args)
     # under `python -m torch.distributed.run -m ...sampled_components`: bind this rank's GPU for
     # torch and for libasp_hip and join the process group before anything touches a device
     created_group = asp_dist.init_from_env()
@@ -309,13 +444,7 @@ def main(argv=None):
                                      args.max_cluster_size, args.keep_probability)
     clusters = asp_dist.broadcast_object(clusters)
     if writer:
-        with open(args.output, "w") as f:
-            f.write("# Generated by annealing_sign_problem_amd.sampled_components\n")
-            for key in ["seed", "order", "noise", "global_cutoff", "sampled_power",
-                        "min_cluster_size", "max_cluster_size", "keep_probability",
-                        "number_sweeps", "repetitions"]:
-                f.write("# {} = {}\n".format(key, getattr(args, key)))
-            f.write("# {}\n".format(OptimizationResult.csv_header()))
+        _write_header(args)
     def work(cluster):
         return process_cluster(cluster, hamiltonian, ground_state, noisy_ground_state,
                                noisy_log_coeff_fn, args.order, args.global_cutoff, args.annealing,

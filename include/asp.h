@@ -41,6 +41,10 @@ void asp_clear_error(void);
 
 /* Number of HIP devices (>= 0) or a negative asp_status. */
 int asp_device_count(void);
+/* 1 once this process has made a HIP call through the library (any entry point that needs the
+ * device), 0 before: a process that has not may still fork workers that each open the device
+ * (sampled_components --workers). */
+int asp_device_touched(void);
 /* Select the device used by this library in the whole process (every entry point binds
  * its calling thread to it). */
 int asp_set_device(int device);

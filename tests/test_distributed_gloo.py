@@ -220,3 +220,39 @@ def test_pipeline_main_initialises_ranks_from_env(tmp_path):
                           for l in open(path).read().splitlines()]
     assert strip(single) == strip(out)
     mp.spawn(_main_worker, args=(2, _free_port(), out, True), nprocs=2, join=True)
+
+
+def test_pipeline_worker_processes_write_the_single_process_file(tmp_path, monkeypatch):
+    """--workers N: the parent loads the inputs without touching the GPU, a child grows the
+    clusters, N forked workers share the inputs and take rounds of clusters from a queue, the
+    parent appends the lines in cluster order.  Device stages replaced by a deterministic
+    stand-in (no GPU here); the file must be the one a single process writes."""
+    sys.path.insert(0, ROOT)
+    from annealing_sign_problem_amd import sampled_components as sc
+
+    def fake_clusters(hamiltonian, ground_state, number_samples, *args):
+        states = hamiltonian.basis.states
+        draws = np.random.randint(0, 50, size=number_samples)  # consumes the seeded stream like the real one
+        return [states[int(d): int(d) + 4 + c].copy() for c, d in enumerate(draws)]
+
+    def fake_process(cluster, hamiltonian, ground_state, noisy, fn, order, cutoff, annealing,
+                     sweep_order=None):
+        assert fn(cluster).shape == (cluster.size,)  # the workers' own log-amplitude closure works
+        return [sc.OptimizationResult(int(cluster.size) + i, float(cluster[0] % 97) / 97.0,
+                                      float(np.abs(noisy[3])), 0.25, 0.125, float(os.getpid() != 0))
+                for i in range(order + 1)]
+
+    monkeypatch.setattr(sc, "generate_clusters", fake_clusters)
+    monkeypatch.setattr(sc, "process_cluster", fake_process)
+    monkeypatch.setattr(sc, "process_clusters_batched",
+                        lambda clusters, *rest, jobs=1, sweep_order=None: [
+                            fake_process(c, *rest, sweep_order=sweep_order) for c in clusters])
+    common = ["--model", "heisenberg_kagome_16", "--order", "1", "--number-samples", "9", "--seed", "11",
+              "--noise", "0.3", "--no-annealing"]
+    single, forked = str(tmp_path / "single.csv"), str(tmp_path / "forked.csv")
+    sc.main(common + ["--output", single])
+    sc.main(common + ["--output", forked, "--workers", "3", "--batch", "2"])
+    assert open(single).read() == open(forked).read()
+    assert len([l for l in open(forked) if not l.startswith("#")]) == 9
+    with pytest.raises(SystemExit):
+        sc.main(common + ["--output", forked, "--workers", "3"])  # refuses to overwrite
