@@ -5,7 +5,7 @@ import *`` (annealing_sign_problem/__init__.py:1-4): it re-exports the entry
 points of :mod:`.common`.  ``annealer`` stands in for ``ising_glass_annealer`` and
 ``_build_matrix`` for the reference's cffi extension of the same name.
 """
-__version__ = "0.1.0"
+__version__ = "0.4.0"  # = asp_version() of libasp_hip.so
 
 from .common import *  # noqa: F401,F403
 from . import annealer  # noqa: F401

@@ -474,6 +474,6 @@ int asp_shutdown(void) {
   return asp::shutdown_pools();
 }
 
-const char *asp_version(void) { return "0.3.0"; }
+const char *asp_version(void) { return "0.4.0"; }
 
 }  // extern "C"

@@ -56,6 +56,7 @@ struct asp_sa_plan {
   asp::DeviceBuffer<double> field_dev;  // [K]
   uint32_t rq_quads = 0, rq_max_quads = 0;
   int shuffled_m = 0, shuffled_waves = 0;  // asp_sa_set_shuffled_launch (0 = automatic)
+  int shuffled_teams = 0;                  // asp_sa_set_shuffled_teams (0 = automatic)
   int last_shuffled_levels = 0;            // largest number of levels of the last shuffled call
   float last_order_ms = 0.0f;              // device time of the last call's order kernels
 };

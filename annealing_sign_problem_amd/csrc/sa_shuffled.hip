@@ -532,11 +532,20 @@ constexpr int kHeldQuads = 12;  // quads of a block kept in registers (wider blo
 // requested as soon as the k-loop has consumed the registers that held the current block's, and
 // arrive during the accept phase and the level barrier.  Per level the critical path is then
 // LDS gathers + FMAs + accept, not a chain of global-memory round trips.
-template <int M, int LAYOUT>
+//
+// TEAMS = 2 (asp_sa_set_shuffled_teams; never chosen automatically): the wavefronts of a workgroup
+// form two teams; both visit the same blocks at the same time, team t for chains t M .. t M + M - 1
+// of the group (its half of every LDS spin word or byte) — two busy wavefronts per SIMD and
+// level on half the instructions per visit.  Built to test whether a visit is bound by the issue
+// rate of its lone wavefront; it is not (the fill rate from L2 binds: DESIGN.md §4.9), and this
+// form is slower.  Kept because it is cheap and its parity is tested.
+template <int M, int LAYOUT, int TEAMS>
 __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
   constexpr bool WIDE = LAYOUT == kWide;
+  constexpr int MT = M * TEAMS;  // chains of the workgroup
   static_assert(LAYOUT == kWide || LAYOUT == kBytes, "spins are LDS words or LDS bytes");
-  static_assert(!WIDE || M <= 4, "the wide layout holds up to four chains");
+  static_assert(!WIDE || MT <= 4, "the wide layout holds up to four chains");
+  static_assert(MT <= 8 && (TEAMS == 1 || TEAMS == 2), "a byte holds eight chains");
   extern __shared__ __align__(16) uint8_t lds[];
   if (a.status[kStatBad] != 0u) return;  // an order kernel ran out of room: the host repeats the call
 #if ASP_ABS_LDS
@@ -557,9 +566,15 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
   uint2 *meta = reinterpret_cast<uint2 *>(improved_flag + 4);             // [block_cap]
   uint32_t *level_block = reinterpret_cast<uint32_t *>(meta + a.block_cap);  // [level_cap + 2]
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), waves = blockDim.x >> 6;
+  // (`wave` / `waves`: this wavefront's index inside its team and the team's size)
+  const uint32_t all_waves = blockDim.x >> 6, waves = all_waves / TEAMS;
+  const uint32_t team = TEAMS == 1 ? 0u : __builtin_amdgcn_readfirstlane(tid >> 6) / waves;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6) - team * waves;
   const uint32_t group = blockIdx.x;
-  const uint32_t r0 = a.replica_first + group * M;
+  const uint32_t r0 = a.replica_first + group * MT;  // first chain of the group
+  const uint32_t c0 = team * M;                      // first chain of this wavefront's team
+  // this team's chains inside a spin's LDS word (byte per chain) or byte (bit per chain)
+  const uint32_t team_shift = team * (WIDE ? 8u * M : static_cast<uint32_t>(M));
   const uint32_t key0 = static_cast<uint32_t>(a.seed), key1 = static_cast<uint32_t>(a.seed >> 32);
   uint8_t *state = a.state + static_cast<uint64_t>(group) * K;
 
@@ -569,13 +584,13 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
     if (!a.initialise) {
       mask = state[i];
     } else if (a.x0 != nullptr) {
-      mask = ((a.x0[i >> 6] >> (i & 63u)) & 1ull) ? 0u : ((1u << M) - 1u);
+      mask = ((a.x0[i >> 6] >> (i & 63u)) & 1ull) ? 0u : ((1u << MT) - 1u);
     } else {
       mask = 0;
       Philox4 rnd{};
       uint32_t have = 0xFFFFFFFFu;
 #pragma unroll
-      for (int m = 0; m < M; ++m) {
+      for (int m = 0; m < MT; ++m) {
         const uint32_t r = r0 + m;
         if (m == 0 || (r >> 2) != have) {
           have = r >> 2;
@@ -594,8 +609,8 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
     long long v = 0;
     if (!a.initialise && tid >= 8) {
       const uint32_t m = tid & 7u;
-      if (m < M) {
-        const uint64_t at = static_cast<uint64_t>(group) * M + m;
+      if (m < MT) {
+        const uint64_t at = static_cast<uint64_t>(group) * MT + m;
         v = tid < 16 ? a.e_cur[at] : (tid < 24 ? a.e_best[at] : static_cast<long long>(a.accepted[at]));
       }
     }
@@ -604,7 +619,7 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
   if (tid == 0) *improved_flag = 0;
   __syncthreads();
   if (a.initialise) {
-    snapshot_original<M, LAYOUT>(spins, a, group, (1u << M) - 1u);
+    snapshot_original<MT, LAYOUT>(spins, a, group, (1u << MT) - 1u);
     __syncthreads();
   }
 
@@ -713,6 +728,10 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
             if (static_cast<uint32_t>(j) < quads) {
               if (j + 1 < kHeldQuads) gather_quad<LAYOUT>(hq[j + 1], (j & 1) ? sa : sb);
               __builtin_amdgcn_sched_barrier(0);
+              if constexpr (TEAMS > 1) {  // this team's chains to the low end (a plain VOP2 shift)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ((j & 1) ? sb : sa)[k] >>= team_shift;
+              }
               apply_quad<M, LAYOUT>(hq[j], (j & 1) ? sb : sa, acc, one_hi);
             }
           }
@@ -726,6 +745,10 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
               load_quad_buffer(qb, stream, held_first + 1024u + (j + 1u) * 3072u, lane16);
               __builtin_amdgcn_sched_barrier(0);
               gather_quad<LAYOUT>(qa, sa);
+              if constexpr (TEAMS > 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sa[k] >>= team_shift;
+              }
               apply_quad<M, LAYOUT>(qa, sa, acc, one_hi);
               qa = qb;
             }
@@ -740,7 +763,8 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         ASP_TICK(1);
         if (busy && ASP_SHUF_ABL != 2) {
-          const uint32_t own = WIDE ? wide[me] : static_cast<uint32_t>(spins[me]);
+          // (this team's chains only: the partner team owns the other half of the word / byte)
+          const uint32_t own = (WIDE ? wide[me] : static_cast<uint32_t>(spins[me])) >> team_shift;
           bool need = false;  // some proposal of this lane needs a random number
           double de[M];
 #pragma unroll
@@ -757,7 +781,7 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
             uint32_t have = 0xFFFFFFFFu;
 #pragma unroll
             for (int m = 0; m < M; ++m) {
-              const uint32_t r = r0 + m;
+              const uint32_t r = r0 + c0 + m;
               if (m == 0 || (r >> 2) != have) {
                 have = r >> 2;
 #if ASP_SHUF_ABL == 5
@@ -789,8 +813,18 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
             }
           }
           if (flip) {  // no neighbour of this spin is in the level: nobody reads it before the barrier
-            if constexpr (WIDE) {
+            if constexpr (WIDE && TEAMS == 2) {
+              // this team's half of the word: the partner wavefront may be writing the other half
+              if constexpr (M == 2) {
+                reinterpret_cast<uint16_t *>(wide + me)[team] = static_cast<uint16_t>(own ^ spread_mask(flip));
+              } else {
+                reinterpret_cast<uint8_t *>(wide + me)[team] = static_cast<uint8_t>(own ^ spread_mask(flip));
+              }
+            } else if constexpr (WIDE) {
               wide[me] = own ^ spread_mask(flip);
+            } else if constexpr (TEAMS == 2) {
+              // bits of two teams in one byte: an LDS atomic keeps the partner's flips
+              atomicXor(reinterpret_cast<uint32_t *>(spins) + (me >> 2), (flip << team_shift) << (8u * (me & 3u)));
             } else {
               spins[me] = static_cast<uint8_t>(own ^ flip);
             }
@@ -817,12 +851,12 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
       const long long v = wave_sum_i64(q_acc[m]);
       const long long n = wave_sum_i64(static_cast<long long>(n_acc[m]));
       if (lane == 0 && n != 0) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(&delta[m]), static_cast<unsigned long long>(v));
-        atomicAdd(reinterpret_cast<unsigned long long *>(&book[16 + m]), static_cast<unsigned long long>(n));
+        atomicAdd(reinterpret_cast<unsigned long long *>(&delta[c0 + m]), static_cast<unsigned long long>(v));
+        atomicAdd(reinterpret_cast<unsigned long long *>(&book[16 + c0 + m]), static_cast<unsigned long long>(n));
       }
     }
     __syncthreads();
-    if (tid < M) {
+    if (tid < MT) {
       const long long e = book[tid] + delta[tid];
       book[tid] = e;
       delta[tid] = 0;
@@ -833,7 +867,7 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
     }
     __syncthreads();
     const uint32_t improved = *improved_flag;
-    if (improved) snapshot_original<M, LAYOUT>(spins, a, group, improved);
+    if (improved) snapshot_original<MT, LAYOUT>(spins, a, group, improved);
     __syncthreads();
     if (tid == 0) *improved_flag = 0;  // next write to it is two barriers away
     ASP_TICK(4);
@@ -849,8 +883,8 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
   for (uint32_t i = tid; i < K; i += blockDim.x) {
     state[i] = static_cast<uint8_t>(from_lds<LAYOUT>(WIDE ? wide[i] : static_cast<uint32_t>(spins[i])));
   }
-  if (tid < M) {
-    const uint64_t at = static_cast<uint64_t>(group) * M + tid;
+  if (tid < MT) {
+    const uint64_t at = static_cast<uint64_t>(group) * MT + tid;
     a.e_cur[at] = book[tid];
     a.e_best[at] = book[8 + tid];
     a.accepted[at] = static_cast<unsigned long long>(book[16 + tid]);
@@ -859,20 +893,35 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
 
 using ShuffledKernel = void (*)(ShuffledArgs);
 
-ShuffledKernel shuffled_kernel_for(int m, bool wide) {
+// m = chains per workgroup; teams = 2: two teams of m / 2 chains (wide: m = 4 or 2; bytes: m = 8 or 4)
+ShuffledKernel shuffled_kernel_for(int m, bool wide, int teams = 1) {
+  if (teams == 2) {
+    if (wide) {
+      switch (m) {
+        case 2: return k_sa_sweep_shuffled<1, kWide, 2>;
+        case 4: return k_sa_sweep_shuffled<2, kWide, 2>;
+        default: return nullptr;
+      }
+    }
+    switch (m) {
+      case 4: return k_sa_sweep_shuffled<2, kBytes, 2>;
+      case 8: return k_sa_sweep_shuffled<4, kBytes, 2>;
+      default: return nullptr;
+    }
+  }
   if (wide) {
     switch (m) {
-      case 1: return k_sa_sweep_shuffled<1, kWide>;
-      case 2: return k_sa_sweep_shuffled<2, kWide>;
-      case 4: return k_sa_sweep_shuffled<4, kWide>;
+      case 1: return k_sa_sweep_shuffled<1, kWide, 1>;
+      case 2: return k_sa_sweep_shuffled<2, kWide, 1>;
+      case 4: return k_sa_sweep_shuffled<4, kWide, 1>;
       default: return nullptr;
     }
   }
   switch (m) {
-    case 1: return k_sa_sweep_shuffled<1, kBytes>;
-    case 2: return k_sa_sweep_shuffled<2, kBytes>;
-    case 4: return k_sa_sweep_shuffled<4, kBytes>;
-    case 8: return k_sa_sweep_shuffled<8, kBytes>;
+    case 1: return k_sa_sweep_shuffled<1, kBytes, 1>;
+    case 2: return k_sa_sweep_shuffled<2, kBytes, 1>;
+    case 4: return k_sa_sweep_shuffled<4, kBytes, 1>;
+    case 8: return k_sa_sweep_shuffled<8, kBytes, 1>;
     default: return nullptr;
   }
 }
@@ -934,7 +983,7 @@ struct ShuffledRun {
   uint64_t K = 0;
   uint32_t words = 0, groups = 0, waves = 1, level_cap = 0, quad_cap = 0, order_threads = 64, lanes_per_row = 1;
   uint64_t padded = 0;
-  int m = 1, attempt = 0;
+  int m = 1, teams = 1, attempt = 0;
   bool trivial = false;  // nothing to launch (no spins or no chains)
   uint32_t status[kStatWords] = {0, 0, 0, 0};
 
@@ -1011,6 +1060,12 @@ struct ShuffledRun {
       waves = static_cast<uint32_t>(std::ceil(static_cast<double>(K) / levels_guess / 64.0)) + 1u;
       waves = std::max(1u, std::min(8u, waves));
     }
+    // Two teams of m / 2 chains (k_sa_sweep_shuffled, TEAMS): only on request.  Measured at
+    // K = 12 870 (profiles/r03_shuffled_scan.txt): 59 against 63-66 G flips/s with 1024 chains, 66
+    // against 100 with 2048 — a visit is bound by the compute unit's fill rate from L2 (a block is
+    // 22 KiB, four or five blocks per level and CU), not by the issue rate of its wavefront, and
+    // the partner team adds load instructions without adding bandwidth.
+    teams = p->shuffled_teams == 2 && m >= 2 && waves <= 4 ? 2 : 1;
     groups = (repetitions + m - 1) / m;
     padded = static_cast<uint64_t>(groups) * m;
     level_cap = static_cast<uint32_t>(std::min<double>(static_cast<double>(K), 2.0 * levels_guess + 32.0));
@@ -1061,7 +1116,11 @@ struct ShuffledRun {
       return asp::set_error(ASP_ERR_TOO_LARGE, "the shuffled sweep keeps a byte per spin in LDS: %llu "
                                                "spins do not fit", (unsigned long long)K);
     }
-    ShuffledKernel kernel = shuffled_kernel_for(m, wide);
+    ShuffledKernel kernel = shuffled_kernel_for(m, wide, teams);
+    if (!kernel) {  // (no two-team form of this width and layout)
+      teams = 1;
+      kernel = shuffled_kernel_for(m, wide, 1);
+    }
     if (lds > 64 * 1024) {
       ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
@@ -1171,7 +1230,7 @@ struct ShuffledRun {
       a.first_sweep = done;
       a.chunk_sweeps = now;
       a.initialise = first_launch ? 1u : 0u;
-      hipLaunchKernelGGL(kernel, dim3(groups), dim3(waves * 64), lds, s, a);
+      hipLaunchKernelGGL(kernel, dim3(groups), dim3(waves * teams * 64), lds, s, a);
       ASP_HIP_TRY(hipGetLastError());
       ASP_HIP_TRY(hipEventRecord(swept[which], s));
       first_launch = false;
@@ -1244,7 +1303,7 @@ struct ShuffledRun {
     ASP_HIP_TRY(hipStreamSynchronize(p->stream));
     p->last_m = m;
     p->last_layout = 5;
-    p->last_threads = static_cast<int>(waves * 64);
+    p->last_threads = static_cast<int>(waves * teams * 64);
     p->last_groups = static_cast<int>(groups);
     ASP_HIP_TRY(hipEventElapsedTime(&p->last_sweep_ms, p->ev[0], p->ev[2]));
     ASP_HIP_TRY(hipEventElapsedTime(&p->last_total_ms, p->ev[0], p->ev[3]));
@@ -1307,6 +1366,13 @@ int asp_sa_set_shuffled_launch(asp_sa_plan *p, int chains_per_group, int wavefro
   if (wavefronts < 0 || wavefronts > 8) return asp::set_error(ASP_ERR_INVALID, "wavefronts must be 0..8");
   p->shuffled_m = chains_per_group;
   p->shuffled_waves = wavefronts;
+  return ASP_OK;
+}
+
+int asp_sa_set_shuffled_teams(asp_sa_plan *p, int teams) {
+  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  if (teams < 0 || teams > 2) return asp::set_error(ASP_ERR_INVALID, "teams must be 0 (automatic), 1 or 2");
+  p->shuffled_teams = teams;
   return ASP_OK;
 }
 

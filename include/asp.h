@@ -423,6 +423,10 @@ int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, u
 /* Launch geometry of the shuffled sweep (0 = automatic): chains per workgroup in {1,2,4,8} and
  * wavefronts per workgroup in 1..8.  Results never depend on it. */
 int asp_sa_set_shuffled_launch(asp_sa_plan *p, int chains_per_group, int wavefronts);
+/* Teams of a shuffled-sweep workgroup (0 = automatic): with 2 the wavefronts split into two teams
+ * that visit the same blocks for one half of the group's chains each (`wavefronts` above is then
+ * per team, at most 4).  Results never depend on it. */
+int asp_sa_set_shuffled_teams(asp_sa_plan *p, int teams);
 /* Of the last asp_sa_anneal_shuffled call: the largest number of levels of a sweep. */
 int asp_sa_last_shuffled(asp_sa_plan const *p, uint32_t *levels, float *order_ms);
 

@@ -939,6 +939,30 @@ def test_shuffled_sweep_does_not_depend_on_the_launch_geometry(m, waves):
     assert np.array_equal(tracked, otracked) and np.array_equal(accepted, oaccepted)
 
 
+@pytest.mark.parametrize("m,waves", [(2, 2), (4, 4), (4, 1), (8, 3)])
+def test_shuffled_sweep_two_teams_per_workgroup(m, waves):
+    """asp_sa_set_shuffled_teams(2): two teams of wavefronts share a workgroup's blocks, each for
+    half of its chains (half of every LDS spin word, or four bits of every spin byte).  Same
+    chains as the oracle."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    J, h, ham, info, betas = _shuffled_case(1700, 10.0, 12)
+    lib = _lib.load()
+    _lib.check(lib.asp_sa_set_shuffled_launch(ham.plan(), m, waves))
+    _lib.check(lib.asp_sa_set_shuffled_teams(ham.plan(), 2))
+    xs, es = sa.anneal_raw(ham, 41, betas, 13, 2, None, shuffled=True)
+    got_m, got_threads, got_groups = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.asp_sa_last_launch(ham.plan(), ctypes.byref(got_m), ctypes.byref(got_threads),
+                                      ctypes.byref(got_groups)))
+    assert (got_m.value, got_threads.value) == (m, 128 * waves)
+    tracked, accepted = _stats(ham, 13)
+    oxs, oes, otracked, oaccepted = oracle.sa_anneal_shuffled(J, h, 41, betas, 13, 2, None,
+                                                             info.energy_scale_exp, num_threads=4)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    assert np.array_equal(tracked, otracked) and np.array_equal(accepted, oaccepted)
+
+
 def test_shuffled_sweep_rows_wider_than_the_held_quads():
     """Rows of more than 48 couplings (a dense SK-like cluster: 120 per row) do not fit the
     registers a wavefront keeps a block in: the rest of the row streams.  Same bits."""

@@ -24,6 +24,7 @@ def main():
     p.add_argument("--sweeps", type=int, default=128)
     p.add_argument("--groups", default="0", help="comma list of chains per workgroup (0 = automatic)")
     p.add_argument("--waves", default="0", help="comma list of wavefronts per workgroup (0 = automatic)")
+    p.add_argument("--teams", default="0", help="comma list: 0 automatic, 1, 2 teams per workgroup")
     p.add_argument("--degree", type=float, default=23.0)
     p.add_argument("--repeat", type=int, default=2)
     p.add_argument("--colour", action="store_true", help="also time the colour-ordered sweep")
@@ -51,8 +52,9 @@ def main():
                 print("  colour order: chains=%d  %8.2f ms  %7.2f Gflips/s" % (
                     chains, ms, k * chains * a.sweeps / ms / 1e6), flush=True)
             for m in [int(s) for s in a.groups.split(",")]:
-                for w in [int(s) for s in a.waves.split(",")]:
+                for w, teams in [(int(s), int(t)) for s in a.waves.split(",") for t in a.teams.split(",")]:
                     _lib.check(lib.asp_sa_set_shuffled_launch(ham.plan(), m, w))
+                    _lib.check(lib.asp_sa_set_shuffled_teams(ham.plan(), teams))
                     best, wall = None, None
                     for _ in range(a.repeat):
                         t0 = time.perf_counter()
@@ -66,8 +68,8 @@ def main():
                     mm, th, gr = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
                     lib.asp_sa_last_launch(ham.plan(), ctypes.byref(mm), ctypes.byref(th), ctypes.byref(gr))
                     flips = k * chains * a.sweeps
-                    print("  chains=%d M=%d waves=%d groups=%d levels<=%d: %8.2f ms  %7.2f Gflips/s  (wall %.1f ms)" % (
-                        chains, mm.value, th.value // 64, gr.value, levels.value, best, flips / best / 1e6,
+                    print("  chains=%d M=%d teams=%d waves(all)=%d groups=%d levels<=%d: %8.2f ms  %7.2f Gflips/s  (wall %.1f ms)" % (
+                        chains, mm.value, teams, th.value // 64, gr.value, levels.value, best, flips / best / 1e6,
                         wall * 1e3), flush=True)
 
 
