@@ -987,26 +987,33 @@ struct ShuffledRun {
   bool trivial = false;  // nothing to launch (no spins or no chains)
   uint32_t status[kStatWords] = {0, 0, 0, 0};
 
-  asp::ScopedStream order_stream;
-  hipEvent_t ordered[2] = {nullptr, nullptr}, swept[2] = {nullptr, nullptr};
+  // Order kernels of two chunks may be in flight at once (a stream and a scratch area each), beside
+  // the sweep kernel of a third: an order workgroup is a chain of dependent global accesses (23 ms
+  // for a sweep of 1e5 spins), so their THROUGHPUT is workgroups in flight / that latency, and a
+  // 128-sweep call has only 32 sweeps per chunk to offer.
+  static constexpr int kSets = 3, kLanes = 2;
+  asp::ScopedStream order_stream[kLanes];
+  hipEvent_t ordered[kSets] = {nullptr, nullptr, nullptr}, swept[kSets] = {nullptr, nullptr, nullptr};
   DeviceBuffer<double> d_betas, d_partial, d_e;
   DeviceBuffer<uint64_t> d_x0, d_best, d_perm;
   DeviceBuffer<uint8_t> d_state;
   DeviceBuffer<long long> d_ecur, d_ebest;
   DeviceBuffer<unsigned long long> d_accepted;
-  DeviceBuffer<uint32_t> d_status, d_prio, d_indeg, d_order;
+  DeviceBuffer<uint32_t> d_status, d_prio[kLanes], d_indeg[kLanes], d_order[kLanes];
   struct OrderSet {
     DeviceBuffer<uint32_t> level_block, num_levels, spin_of_pos;
     DeviceBuffer<uint2> block_meta;
     DeviceBuffer<uint8_t> stream;
-  } sets[2];
+  } sets[kSets];
 
   ShuffledRun() = default;
   ShuffledRun(const ShuffledRun &) = delete;
   ShuffledRun &operator=(const ShuffledRun &) = delete;
   ~ShuffledRun() {
     // (the buffers are released after this body: first wait for whatever still uses them)
-    if (order_stream.stream) (void)hipStreamSynchronize(order_stream.stream);
+    for (auto &o : order_stream) {
+      if (o.stream) (void)hipStreamSynchronize(o.stream);
+    }
     if (p && p->stream) (void)hipStreamSynchronize(p->stream);
     for (hipEvent_t e : ordered) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : swept) if (e) (void)hipEventDestroy(e);
@@ -1078,8 +1085,8 @@ struct ShuffledRun {
         1u, static_cast<uint32_t>(std::ceil(mean_degree / 4.0))))));
     if (const char *env = std::getenv("ASP_SHUFFLED_BYTES")) budget = std::strtoull(env, nullptr, 10);
 
-    ASP_TRY(order_stream.acquire());
-    for (int i = 0; i < 2; ++i) {
+    for (auto &o : order_stream) ASP_TRY(o.acquire());
+    for (int i = 0; i < kSets; ++i) {
       ASP_HIP_TRY(hipEventCreateWithFlags(&ordered[i], hipEventDisableTiming));
       ASP_HIP_TRY(hipEventCreateWithFlags(&swept[i], hipEventDisableTiming));
     }
@@ -1150,10 +1157,14 @@ struct ShuffledRun {
       ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shuffled_orders),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(order_lds)));
     }
-    ASP_TRY(d_prio.ensure(static_cast<uint64_t>(chunk) * K));
-    ASP_TRY(d_indeg.ensure(static_cast<uint64_t>(chunk) * K));
-    ASP_TRY(d_order.ensure(static_cast<uint64_t>(chunk) * K));
-    const int nsets = num_sweeps > chunk ? 2 : 1;
+    const uint32_t chunks = num_sweeps ? (num_sweeps + chunk - 1) / chunk : 1;
+    const int nsets = static_cast<int>(std::min<uint32_t>(kSets, chunks));
+    const int nlanes = static_cast<int>(std::min<uint32_t>(kLanes, chunks));
+    for (int i = 0; i < nlanes; ++i) {
+      ASP_TRY(d_prio[i].ensure(static_cast<uint64_t>(chunk) * K));
+      ASP_TRY(d_indeg[i].ensure(static_cast<uint64_t>(chunk) * K));
+      ASP_TRY(d_order[i].ensure(static_cast<uint64_t>(chunk) * K));
+    }
     for (int i = 0; i < nsets; ++i) {
       OrderSet &o = sets[i];
       ASP_TRY(o.level_block.ensure(static_cast<uint64_t>(chunk) * (level_cap + 1)));
@@ -1164,7 +1175,9 @@ struct ShuffledRun {
     }
     ASP_HIP_TRY(hipMemsetAsync(d_status.ptr, 0, (kStatWords + 2 * kTimingSlots * kTimingWaves) * sizeof(uint32_t), s));
     ASP_HIP_TRY(hipEventRecord(p->ev[0], s));
-    ASP_HIP_TRY(hipStreamWaitEvent(order_stream.stream, p->ev[0], 0));  // status zeroed, buffers ours
+    for (int i = 0; i < nlanes; ++i) {
+      ASP_HIP_TRY(hipStreamWaitEvent(order_stream[i].stream, p->ev[0], 0));  // status zeroed, buffers ours
+    }
 
     OrderArgs oa{};
     oa.rq_ptr = p->rq_ptr.ptr;
@@ -1179,9 +1192,6 @@ struct ShuffledRun {
     oa.stream_kib = stream_kib;
     oa.lanes_per_row = lanes_per_row;
     oa.col_shift = wide ? 2u : 0u;
-    oa.prio = d_prio.ptr;
-    oa.indeg = d_indeg.ptr;
-    oa.order = d_order.ptr;
     oa.status = d_status.ptr;
     ShuffledArgs a{};
     a.status = d_status.ptr;
@@ -1205,12 +1215,17 @@ struct ShuffledRun {
     uint32_t turn = 0;
     for (uint32_t done = 0; done < num_sweeps || first_launch; done += chunk, ++turn) {
       const uint32_t now = num_sweeps > done ? std::min(chunk, num_sweeps - done) : 0u;
-      const int which = static_cast<int>(turn & 1u);
-      OrderSet &o = sets[nsets == 2 ? which : 0];
+      const int which = static_cast<int>(turn % static_cast<uint32_t>(nsets));
+      const int lane = static_cast<int>(turn % static_cast<uint32_t>(nlanes));
+      hipStream_t os = order_stream[lane].stream;
+      OrderSet &o = sets[which];
       if (now) {
-        // the orders of this chunk: after the sweep kernel of two chunks ago has let go of the set
-        // (one scratch area: the order kernels of consecutive chunks run one after the other)
-        if (turn >= 2) ASP_HIP_TRY(hipStreamWaitEvent(order_stream.stream, swept[which], 0));
+        // the orders of this chunk: after the sweep kernel that last read this buffer set has let
+        // go of it; chunks alternate between the two order streams (a scratch area each)
+        if (turn >= static_cast<uint32_t>(nsets)) ASP_HIP_TRY(hipStreamWaitEvent(os, swept[which], 0));
+        oa.prio = d_prio[lane].ptr;
+        oa.indeg = d_indeg[lane].ptr;
+        oa.order = d_order[lane].ptr;
         oa.first_sweep = done;
         oa.count = now;
         oa.level_block = o.level_block.ptr;
@@ -1218,9 +1233,9 @@ struct ShuffledRun {
         oa.block_meta = o.block_meta.ptr;
         oa.spin_of_pos = o.spin_of_pos.ptr;
         oa.stream = o.stream.ptr;
-        hipLaunchKernelGGL(k_shuffled_orders, dim3(now), dim3(order_threads), order_lds, order_stream.stream, oa);
+        hipLaunchKernelGGL(k_shuffled_orders, dim3(now), dim3(order_threads), order_lds, os, oa);
         ASP_HIP_TRY(hipGetLastError());
-        ASP_HIP_TRY(hipEventRecord(ordered[which], order_stream.stream));
+        ASP_HIP_TRY(hipEventRecord(ordered[which], os));
         ASP_HIP_TRY(hipStreamWaitEvent(s, ordered[which], 0));
       }
       a.level_block = o.level_block.ptr;
@@ -1247,7 +1262,7 @@ struct ShuffledRun {
     *again = false;
     if (trivial) return ASP_OK;
     ASP_HIP_TRY(hipStreamSynchronize(p->stream));
-    ASP_HIP_TRY(hipStreamSynchronize(order_stream.stream));
+    for (auto &o : order_stream) ASP_HIP_TRY(hipStreamSynchronize(o.stream));
     if (status[kStatBad] == 0) return ASP_OK;
     if (++attempt > 4) {
       return asp::set_error(ASP_ERR_TOO_LARGE, "visiting orders of %u levels / %u quads per sweep do not fit",

@@ -278,8 +278,11 @@ def lanczos_two_pass(matrix, tol: float = 1e-9, max_iterations: int = 1000, seed
             if combine is None:
                 done = beta < 1e-13 or j + 1 == steps
                 if (j + 1) % 10 == 0 or done:
-                    theta, s = scipy.linalg.eigh_tridiagonal(np.asarray(alphas), np.asarray(betas),
-                                                             select="i", select_range=(0, 0))
+                    if len(alphas) == 1:  # a one-dimensional Krylov space (see lanczos_ground_state)
+                        theta, s = np.array([alphas[0]]), np.ones((1, 1))
+                    else:
+                        theta, s = scipy.linalg.eigh_tridiagonal(np.asarray(alphas), np.asarray(betas),
+                                                                 select="i", select_range=(0, 0))
                     residual = abs(beta * s[-1, 0])
                     if log and ((j + 1) % 50 == 0 or done or residual < tol * max(1.0, abs(theta[0]))):
                         log("  Lanczos step %d: E = %.12f, residual %.2e  [%.1f s]" % (
@@ -383,6 +386,10 @@ def main(argv=None):
     parser.add_argument("--tol", type=float, default=1e-9)
     parser.add_argument("--max-iterations", type=int, default=400)
     parser.add_argument("--seed", type=int, default=0)
+    parser.add_argument("--allow-unconverged", action="store_true",
+                        help="write the file even when the eigen-residual misses --tol (the step budget "
+                             "ran out); without it that is an error: the sampled-cluster pipeline would "
+                             "silently consume a wrong ground state")
     args = parser.parse_args(argv)
     if (args.model is None) == (args.yaml is None):
         raise SystemExit("give exactly one of --model and --yaml")
@@ -392,6 +399,12 @@ def main(argv=None):
         operator = operators.Operator.from_config(synthetic.load_models()[args.model])
     energy, psi, representatives, info = ground_state(operator, args.tol, args.max_iterations, args.seed,
                                                       log=lambda s: print(s, flush=True))
+    # (the Ritz estimate; the residual with the matrix is bounded below by the f64 product's
+    # own rounding, ~1e-8 * |E| for these sectors, so the criterion is the one the iteration used)
+    if info["ritz_residual"] > args.tol * max(1.0, abs(energy)) and not args.allow_unconverged:
+        raise SystemExit("Lanczos did not converge: residual %.2e after %d steps against --tol %.1e "
+                         "(raise --max-iterations, or pass --allow-unconverged)"
+                         % (info["ritz_residual"], info["iterations"], args.tol))
     write_spined_hdf5(args.output, energy, psi, representatives)
     print("wrote %s: K = %d, E0 = %.12f (%.10f per spin)" % (
         args.output, info["dimension"], energy, energy / operator.basis.number_spins), flush=True)

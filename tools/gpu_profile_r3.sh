@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 TAG=${1:-r03}; shift
 CASES=${@:-"colour_10000 colour_30000 colour_100000 shuffled_10000 shuffled_30000 shuffled_100000 shuffled64_10000 batch team real_kagome_36"}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof3
-rm -rf $OUT; mkdir -p $OUT/cases
+mkdir -p $OUT/cases
 cd $GRAFT_REPO_ROOT
 SQ="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
 hipcc --offload-arch=gfx950 -O3 tools/fetch_calibrate.hip -o /tmp/fetch_calibrate > $OUT/calib_build.log 2>&1 || exit 6
@@ -21,8 +21,8 @@ for c in $CASES; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/$c/fetch -- python3 $ARGS > $OUT/$c.fetch.log 2>&1 || { tail -5 $OUT/$c.fetch.log; exit 3; }
   rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/$c/l2 -- python3 $ARGS > $OUT/$c.l2.log 2>&1 || { tail -5 $OUT/$c.l2.log; exit 4; }
 done
-python3 tools/summarise_roofline.py $OUT $TAG > $OUT/summary.log 2>&1 || { tail -20 $OUT/summary.log; exit 5; }
-mkdir -p $OUT/profiles && cp profiles/${TAG}_* profiles/traffic.json profiles/sweep_counters.json $OUT/profiles/
-# the raw counter CSVs are large: keep the summaries and logs only
-find $OUT -name "*_counter_collection.csv" -delete; find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "*.db" -delete
-tail -40 $OUT/summary.log
+# The box is fresh for every call and the cases take more than one call: the counter CSVs travel back
+# (a few dispatches each, small) and tools/summarise_roofline.py runs where they have all arrived:
+#   python tools/summarise_roofline.py gpurun_out/prof3 r03
+find $OUT -name "*.db" -delete; find $OUT -name "*agent_info.csv" -delete
+ls $OUT/cases
