@@ -123,12 +123,14 @@ __device__ __forceinline__ bool comes_before(uint32_t pa, uint32_t a, uint32_t p
   return pa < pb || (pa == pb && a < b);
 }
 
-__global__ __launch_bounds__(kOrderThreads) void k_shuffled_orders(OrderArgs a) {
+// (`Args` is OrderArgs, or OrderArgs in the constant address space: the batched kernel reads its
+// problem's descriptor from a table, like k_sa_sweep_batch does; `s` = sweep of the chunk)
+template <typename Args>
+__device__ __forceinline__ void shuffled_orders_body(const Args &a, const uint32_t s) {
   extern __shared__ __align__(16) uint8_t lds[];
   const uint32_t K = a.num_spins;
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), waves = blockDim.x >> 6;
-  const uint32_t s = blockIdx.x;
   const uint32_t t = a.first_sweep + s;
   // ctl: [0] tail of the order, [1..2] level ends (ping-pong), [3] carry of the scans
   uint32_t *ctl = reinterpret_cast<uint32_t *>(lds);
@@ -345,6 +347,18 @@ __global__ __launch_bounds__(kOrderThreads) void k_shuffled_orders(OrderArgs a) 
   }
 }
 
+__global__ __launch_bounds__(kOrderThreads) void k_shuffled_orders(OrderArgs a) {
+  shuffled_orders_body(a, blockIdx.x);
+}
+
+// Many problems, `count` sweeps of each: workgroup -> (problem, sweep).
+__global__ __launch_bounds__(kOrderThreads) void k_shuffled_orders_batch(const OrderArgs *problems, uint32_t count) {
+  using ConstArgs = const OrderArgs __attribute__((address_space(4)));
+  const uint32_t problem = blockIdx.x / count;
+  ConstArgs *a = reinterpret_cast<ConstArgs *>(reinterpret_cast<uintptr_t>(problems + problem));
+  shuffled_orders_body(*a, blockIdx.x - problem * count);
+}
+
 // ---------------------------------------------------------------------------
 // Sweep kernel
 // ---------------------------------------------------------------------------
@@ -382,8 +396,8 @@ __device__ __forceinline__ uint32_t from_lds(uint32_t v) {
   }
 }
 
-template <int M, int LAYOUT>
-__device__ __forceinline__ void snapshot_original(const uint8_t *spins, const ShuffledArgs &a,
+template <int M, int LAYOUT, typename Args>
+__device__ __forceinline__ void snapshot_original(const uint8_t *spins, const Args &a,
                                                   uint32_t group, uint32_t mask) {
   const uint32_t lane = threadIdx.x & 63u;
   for (uint32_t w = threadIdx.x >> 6; w < a.words; w += blockDim.x >> 6) {
@@ -539,8 +553,8 @@ constexpr int kHeldQuads = 12;  // quads of a block kept in registers (wider blo
 // level on half the instructions per visit.  Built to test whether a visit is bound by the issue
 // rate of its lone wavefront; it is not (the fill rate from L2 binds: DESIGN.md §4.9), and this
 // form is slower.  Kept because it is cheap and its parity is tested.
-template <int M, int LAYOUT, int TEAMS>
-__global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
+template <int M, int LAYOUT, int TEAMS, typename Args>
+__device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_t group) {
   constexpr bool WIDE = LAYOUT == kWide;
   constexpr int MT = M * TEAMS;  // chains of the workgroup
   static_assert(LAYOUT == kWide || LAYOUT == kBytes, "spins are LDS words or LDS bytes");
@@ -570,7 +584,6 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
   const uint32_t all_waves = blockDim.x >> 6, waves = all_waves / TEAMS;
   const uint32_t team = TEAMS == 1 ? 0u : __builtin_amdgcn_readfirstlane(tid >> 6) / waves;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6) - team * waves;
-  const uint32_t group = blockIdx.x;
   const uint32_t r0 = a.replica_first + group * MT;  // first chain of the group
   const uint32_t c0 = team * M;                      // first chain of this wavefront's team
   // this team's chains inside a spin's LDS word (byte per chain) or byte (bit per chain)
@@ -893,6 +906,26 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
 
 using ShuffledKernel = void (*)(ShuffledArgs);
 
+template <int M, int LAYOUT, int TEAMS>
+__global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
+  shuffled_sweep_body<M, LAYOUT, TEAMS>(a, blockIdx.x);
+}
+
+// Many problems in one launch: workgroup -> (problem, group of M chains) through a slot table,
+// the problem's arguments through a descriptor table (csrc/sa_sweep.hip: k_sa_sweep_batch).
+struct ShuffledSlot {
+  uint32_t problem, group;
+};
+template <int M, int LAYOUT>
+__global__ __launch_bounds__(512) void k_sa_sweep_shuffled_batch(const ShuffledArgs *problems,
+                                                                 const ShuffledSlot *slots) {
+  using ConstArgs = const ShuffledArgs __attribute__((address_space(4)));
+  const ShuffledSlot slot = slots[blockIdx.x];
+  ConstArgs *a = reinterpret_cast<ConstArgs *>(
+      reinterpret_cast<uintptr_t>(problems + __builtin_amdgcn_readfirstlane(slot.problem)));
+  shuffled_sweep_body<M, LAYOUT, 1>(*a, __builtin_amdgcn_readfirstlane(slot.group));
+}
+
 // m = chains per workgroup; teams = 2: two teams of m / 2 chains (wide: m = 4 or 2; bytes: m = 8 or 4)
 ShuffledKernel shuffled_kernel_for(int m, bool wide, int teams = 1) {
   if (teams == 2) {
@@ -984,6 +1017,8 @@ struct ShuffledRun {
   uint32_t words = 0, groups = 0, waves = 1, level_cap = 0, quad_cap = 0, order_threads = 64, lanes_per_row = 1;
   uint64_t padded = 0;
   int m = 1, teams = 1, attempt = 0;
+  int forced_m = 0;      // chains per workgroup chosen by the batched driver (0: by this run)
+  bool batched = false;  // launched by the batched driver: no timing events of its own
   bool trivial = false;  // nothing to launch (no spins or no chains)
   uint32_t status[kStatWords] = {0, 0, 0, 0};
 
@@ -1045,7 +1080,9 @@ struct ShuffledRun {
     ASP_TRY(ensure_static(p));
     // chains per workgroup: as many as still leave a workgroup per compute unit
     m = 1;
-    if (p->shuffled_m) {
+    if (forced_m) {
+      m = forced_m;
+    } else if (p->shuffled_m) {
       m = p->shuffled_m;
     } else {
       for (int cand : {8, 4, 2}) {
@@ -1109,28 +1146,25 @@ struct ShuffledRun {
     return ASP_OK;
   }
 
-  // Queues one whole attempt (all chunks) on the two streams; returns without waiting.
-  int enqueue() {
-    if (trivial) return ASP_OK;
-    const asp::SaHostLayout &L = p->host;
-    hipStream_t s = p->stream;
+  // ---- one attempt: plan (capacities -> kernels, buffers, argument templates), then launches ----
+  uint32_t block_cap = 0, stream_kib = 0, chunk = 0;
+  bool wide = false;
+  size_t lds = 0, order_lds = 0;
+  ShuffledKernel kernel = nullptr;
+  int nsets = 1, nlanes = 1;
+  OrderArgs oa{};
+  ShuffledArgs sa{};
+
+  // Sweeps per chunk this run would choose by itself for its present capacities.
+  int plan_sizes() {
     const uint32_t max_quads = p->rq_max_quads;
-    const uint32_t block_cap = words + level_cap;
+    block_cap = words + level_cap;
     // a word per spin (the one-instruction sign) when that fits the LDS beside the sweep's tables
-    const bool wide = m <= 4 && sweep_lds_bytes(K, true, level_cap, block_cap) <= p->max_lds;
-    const size_t lds = sweep_lds_bytes(K, wide, level_cap, block_cap);
+    wide = m <= 4 && sweep_lds_bytes(K, true, level_cap, block_cap) <= p->max_lds;
+    lds = sweep_lds_bytes(K, wide, level_cap, block_cap);
     if (lds > p->max_lds) {
       return asp::set_error(ASP_ERR_TOO_LARGE, "the shuffled sweep keeps a byte per spin in LDS: %llu "
                                                "spins do not fit", (unsigned long long)K);
-    }
-    ShuffledKernel kernel = shuffled_kernel_for(m, wide, teams);
-    if (!kernel) {  // (no two-team form of this width and layout)
-      teams = 1;
-      kernel = shuffled_kernel_for(m, wide, 1);
-    }
-    if (lds > 64 * 1024) {
-      ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     }
     if (!quad_cap) {
       // exact class sort (rows below 63 quads): a block is no wider than every row of the block
@@ -1143,23 +1177,28 @@ struct ShuffledRun {
     }
     // KiB of one sweep's stream: a header per block, 3 KiB per quad, and slack for the sweep
     // kernel's read of one quad past a wide block (< 4 GiB: 32-bit scalar offsets)
-    const uint32_t stream_kib = block_cap + 3u * (quad_cap + 2u);
+    stream_kib = block_cap + 3u * (quad_cap + 2u);
     const uint64_t per_sweep = static_cast<uint64_t>(stream_kib) * 1024 + static_cast<uint64_t>(block_cap) * (256 + 8) +
                                (level_cap + 1ull) * 4 + 12ull * K;
-    uint32_t chunk = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(256, budget / per_sweep)));
+    chunk = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(256, budget / per_sweep)));
     chunk = std::max(1u, std::min(chunk, (num_sweeps + 3) / 4));  // at least four chunks: the pipeline needs them
-    const size_t order_lds = order_lds_bytes(level_cap, block_cap, order_threads / 64);
+    order_lds = order_lds_bytes(level_cap, block_cap, order_threads / 64);
     if (order_lds > p->max_lds) {
       return asp::set_error(ASP_ERR_TOO_LARGE, "%u levels x %u blocks do not fit the order kernel's LDS",
                             level_cap, block_cap);
     }
-    if (order_lds > 64 * 1024) {
-      ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shuffled_orders),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(order_lds)));
-    }
+    return ASP_OK;
+  }
+
+  // Buffers of the attempt for `use_chunk` sweeps per chunk, status words zeroed (on the plan's
+  // stream, p->ev[0] recorded behind that), argument templates filled.
+  int plan_buffers(uint32_t use_chunk) {
+    const asp::SaHostLayout &L = p->host;
+    hipStream_t s = p->stream;
+    chunk = use_chunk;
     const uint32_t chunks = num_sweeps ? (num_sweeps + chunk - 1) / chunk : 1;
-    const int nsets = static_cast<int>(std::min<uint32_t>(kSets, chunks));
-    const int nlanes = static_cast<int>(std::min<uint32_t>(kLanes, chunks));
+    nsets = static_cast<int>(std::min<uint32_t>(kSets, chunks));
+    nlanes = static_cast<int>(std::min<uint32_t>(kLanes, chunks));
     for (int i = 0; i < nlanes; ++i) {
       ASP_TRY(d_prio[i].ensure(static_cast<uint64_t>(chunk) * K));
       ASP_TRY(d_indeg[i].ensure(static_cast<uint64_t>(chunk) * K));
@@ -1175,11 +1214,7 @@ struct ShuffledRun {
     }
     ASP_HIP_TRY(hipMemsetAsync(d_status.ptr, 0, (kStatWords + 2 * kTimingSlots * kTimingWaves) * sizeof(uint32_t), s));
     ASP_HIP_TRY(hipEventRecord(p->ev[0], s));
-    for (int i = 0; i < nlanes; ++i) {
-      ASP_HIP_TRY(hipStreamWaitEvent(order_stream[i].stream, p->ev[0], 0));  // status zeroed, buffers ours
-    }
-
-    OrderArgs oa{};
+    oa = OrderArgs{};
     oa.rq_ptr = p->rq_ptr.ptr;
     oa.rq_col = reinterpret_cast<const uint4 *>(p->rq_col.ptr);
     oa.rq_val = reinterpret_cast<const double2 *>(p->rq_val.ptr);
@@ -1193,59 +1228,96 @@ struct ShuffledRun {
     oa.lanes_per_row = lanes_per_row;
     oa.col_shift = wide ? 2u : 0u;
     oa.status = d_status.ptr;
-    ShuffledArgs a{};
-    a.status = d_status.ptr;
-    a.betas = d_betas.ptr;
-    a.x0 = x0 ? d_x0.ptr : nullptr;
-    a.state = d_state.ptr;
-    a.best = d_best.ptr;
-    a.e_cur = d_ecur.ptr;
-    a.e_best = d_ebest.ptr;
-    a.accepted = d_accepted.ptr;
-    a.seed = seed;
-    a.scale = std::ldexp(1.0, L.energy_scale_exp);
-    a.num_spins = static_cast<uint32_t>(K);
-    a.words = words;
-    a.level_cap = level_cap;
-    a.block_cap = block_cap;
-    a.stream_kib = stream_kib;
-    a.replica_first = replica_offset;
+    sa = ShuffledArgs{};
+    sa.status = d_status.ptr;
+    sa.betas = d_betas.ptr;
+    sa.x0 = x0 ? d_x0.ptr : nullptr;
+    sa.state = d_state.ptr;
+    sa.best = d_best.ptr;
+    sa.e_cur = d_ecur.ptr;
+    sa.e_best = d_ebest.ptr;
+    sa.accepted = d_accepted.ptr;
+    sa.seed = seed;
+    sa.scale = std::ldexp(1.0, L.energy_scale_exp);
+    sa.num_spins = static_cast<uint32_t>(K);
+    sa.words = words;
+    sa.level_cap = level_cap;
+    sa.block_cap = block_cap;
+    sa.stream_kib = stream_kib;
+    sa.replica_first = replica_offset;
+    return ASP_OK;
+  }
 
+  // The arguments of chunk `turn` (sweeps done .. done + now): buffer set turn % nsets, scratch area
+  // turn % nlanes.
+  void chunk_args(uint32_t turn, uint32_t done, uint32_t now, bool first_launch, OrderArgs *o_out,
+                  ShuffledArgs *s_out) const {
+    const OrderSet &o = sets[turn % static_cast<uint32_t>(nsets)];
+    const uint32_t lane = turn % static_cast<uint32_t>(nlanes);
+    OrderArgs x = oa;
+    x.prio = d_prio[lane].ptr;
+    x.indeg = d_indeg[lane].ptr;
+    x.order = d_order[lane].ptr;
+    x.first_sweep = done;
+    x.count = now;
+    x.level_block = o.level_block.ptr;
+    x.num_levels = o.num_levels.ptr;
+    x.block_meta = o.block_meta.ptr;
+    x.spin_of_pos = o.spin_of_pos.ptr;
+    x.stream = o.stream.ptr;
+    *o_out = x;
+    ShuffledArgs y = sa;
+    y.level_block = o.level_block.ptr;
+    y.num_levels = o.num_levels.ptr;
+    y.block_meta = o.block_meta.ptr;
+    y.stream = o.stream.ptr;
+    y.first_sweep = done;
+    y.chunk_sweeps = now;
+    y.initialise = first_launch ? 1u : 0u;
+    *s_out = y;
+  }
+
+  // Queues one whole attempt (all chunks) on the run's streams; returns without waiting.
+  int enqueue() {
+    if (trivial) return ASP_OK;
+    hipStream_t s = p->stream;
+    ASP_TRY(plan_sizes());
+    kernel = shuffled_kernel_for(m, wide, teams);
+    if (!kernel) {  // (no two-team form of this width and layout)
+      teams = 1;
+      kernel = shuffled_kernel_for(m, wide, 1);
+    }
+    if (lds > 64 * 1024) {
+      ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    }
+    if (order_lds > 64 * 1024) {
+      ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shuffled_orders),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(order_lds)));
+    }
+    ASP_TRY(plan_buffers(chunk));
+    for (int i = 0; i < nlanes; ++i) {
+      ASP_HIP_TRY(hipStreamWaitEvent(order_stream[i].stream, p->ev[0], 0));  // status zeroed, buffers ours
+    }
     bool first_launch = true;
     uint32_t turn = 0;
     for (uint32_t done = 0; done < num_sweeps || first_launch; done += chunk, ++turn) {
       const uint32_t now = num_sweeps > done ? std::min(chunk, num_sweeps - done) : 0u;
       const int which = static_cast<int>(turn % static_cast<uint32_t>(nsets));
-      const int lane = static_cast<int>(turn % static_cast<uint32_t>(nlanes));
-      hipStream_t os = order_stream[lane].stream;
-      OrderSet &o = sets[which];
+      hipStream_t os = order_stream[turn % static_cast<uint32_t>(nlanes)].stream;
+      OrderArgs o_args;
+      ShuffledArgs s_args;
+      chunk_args(turn, done, now, first_launch, &o_args, &s_args);
       if (now) {
         // the orders of this chunk: after the sweep kernel that last read this buffer set has let
         // go of it; chunks alternate between the two order streams (a scratch area each)
         if (turn >= static_cast<uint32_t>(nsets)) ASP_HIP_TRY(hipStreamWaitEvent(os, swept[which], 0));
-        oa.prio = d_prio[lane].ptr;
-        oa.indeg = d_indeg[lane].ptr;
-        oa.order = d_order[lane].ptr;
-        oa.first_sweep = done;
-        oa.count = now;
-        oa.level_block = o.level_block.ptr;
-        oa.num_levels = o.num_levels.ptr;
-        oa.block_meta = o.block_meta.ptr;
-        oa.spin_of_pos = o.spin_of_pos.ptr;
-        oa.stream = o.stream.ptr;
-        hipLaunchKernelGGL(k_shuffled_orders, dim3(now), dim3(order_threads), order_lds, os, oa);
+        hipLaunchKernelGGL(k_shuffled_orders, dim3(now), dim3(order_threads), order_lds, os, o_args);
         ASP_HIP_TRY(hipGetLastError());
         ASP_HIP_TRY(hipEventRecord(ordered[which], os));
         ASP_HIP_TRY(hipStreamWaitEvent(s, ordered[which], 0));
       }
-      a.level_block = o.level_block.ptr;
-      a.num_levels = o.num_levels.ptr;
-      a.block_meta = o.block_meta.ptr;
-      a.stream = o.stream.ptr;
-      a.first_sweep = done;
-      a.chunk_sweeps = now;
-      a.initialise = first_launch ? 1u : 0u;
-      hipLaunchKernelGGL(kernel, dim3(groups), dim3(waves * teams * 64), lds, s, a);
+      hipLaunchKernelGGL(kernel, dim3(groups), dim3(waves * teams * 64), lds, s, s_args);
       ASP_HIP_TRY(hipGetLastError());
       ASP_HIP_TRY(hipEventRecord(swept[which], s));
       first_launch = false;
@@ -1263,6 +1335,12 @@ struct ShuffledRun {
     if (trivial) return ASP_OK;
     ASP_HIP_TRY(hipStreamSynchronize(p->stream));
     for (auto &o : order_stream) ASP_HIP_TRY(hipStreamSynchronize(o.stream));
+    return grow(again);
+  }
+
+  // After an attempt whose status words are in `status`: nothing to do, or larger capacities.
+  int grow(bool *again) {
+    *again = false;
     if (status[kStatBad] == 0) return ASP_OK;
     if (++attempt > 4) {
       return asp::set_error(ASP_ERR_TOO_LARGE, "visiting orders of %u levels / %u quads per sweep do not fit",
@@ -1320,23 +1398,234 @@ struct ShuffledRun {
     p->last_layout = 5;
     p->last_threads = static_cast<int>(waves * teams * 64);
     p->last_groups = static_cast<int>(groups);
-    ASP_HIP_TRY(hipEventElapsedTime(&p->last_sweep_ms, p->ev[0], p->ev[2]));
-    ASP_HIP_TRY(hipEventElapsedTime(&p->last_total_ms, p->ev[0], p->ev[3]));
+    if (!batched) {
+      ASP_HIP_TRY(hipEventElapsedTime(&p->last_sweep_ms, p->ev[0], p->ev[2]));
+      ASP_HIP_TRY(hipEventElapsedTime(&p->last_total_ms, p->ev[0], p->ev[3]));
+    }
     return ASP_OK;
   }
 };
 
 }  // namespace
 
+namespace {
+
+using ShuffledBatchKernel = void (*)(const ShuffledArgs *, const ShuffledSlot *);
+
+ShuffledBatchKernel shuffled_batch_kernel_for(int m, bool wide) {
+  if (wide) {
+    switch (m) {
+      case 1: return k_sa_sweep_shuffled_batch<1, kWide>;
+      case 2: return k_sa_sweep_shuffled_batch<2, kWide>;
+      case 4: return k_sa_sweep_shuffled_batch<4, kWide>;
+      default: return nullptr;
+    }
+  }
+  switch (m) {
+    case 1: return k_sa_sweep_shuffled_batch<1, kBytes>;
+    case 2: return k_sa_sweep_shuffled_batch<2, kBytes>;
+    case 4: return k_sa_sweep_shuffled_batch<4, kBytes>;
+    default: return nullptr;
+  }
+}
+
+struct EventPool {
+  std::vector<hipEvent_t> events;
+  ~EventPool() {
+    for (hipEvent_t e : events) (void)hipEventDestroy(e);
+  }
+  int make(hipEvent_t *out, bool timing = false) {
+    ASP_HIP_TRY(hipEventCreateWithFlags(out, timing ? hipEventDefault : hipEventDisableTiming));
+    events.push_back(*out);
+    return ASP_OK;
+  }
+};
+
+// Problems with the same number of sweeps in SHARED launches: per chunk one order launch over
+// (problem, sweep) and one sweep launch per class of workgroup shape over (problem, group of
+// chains) — descriptors of every problem and chunk in one device table, uploaded once.  A launch
+// per problem and chunk does not overlap on the device however many streams it is spread over
+// (64 clusters: 21 s, as long as one after the other); the chip needs the workgroups of many
+// problems inside ONE grid.  Every chain is the one its own asp_sa_anneal_shuffled call produces.
+int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
+  const uint32_t P = static_cast<uint32_t>(runs.size());
+  const uint32_t num_sweeps = runs[0]->num_sweeps;
+  asp_sa_plan *first = runs[0]->p;
+  // one block size for the shared order launch: the largest any problem wants
+  uint32_t order_threads = 64;
+  for (ShuffledRun *r : runs) order_threads = std::max(order_threads, r->order_threads);
+  for (ShuffledRun *r : runs) {
+    r->order_threads = order_threads;
+    r->batched = true;
+    r->teams = 1;
+  }
+  asp::ScopedStream order_stream[ShuffledRun::kLanes];
+  for (auto &o : order_stream) ASP_TRY(o.acquire());
+  // classes of workgroup shape: (layout, wavefronts)
+  struct Class {
+    bool wide;
+    uint32_t waves;
+    std::vector<uint32_t> members;
+    asp::ScopedStream stream;
+    DeviceBuffer<ShuffledSlot> slots;
+    uint32_t num_slots = 0;
+    size_t lds = 0;
+    hipEvent_t swept[ShuffledRun::kSets] = {nullptr, nullptr, nullptr};
+  };
+  EventPool events;
+  hipEvent_t ordered[ShuffledRun::kSets], t_begin, t_end;
+  for (auto &e : ordered) ASP_TRY(events.make(&e));
+  ASP_TRY(events.make(&t_begin, true));
+  ASP_TRY(events.make(&t_end, true));
+  DeviceBuffer<OrderArgs> d_oargs;
+  DeviceBuffer<ShuffledArgs> d_sargs;
+  for (;;) {
+    // ---- plan: capacities, one chunk length for all, buffers ----
+    uint32_t chunk = 256;
+    for (ShuffledRun *r : runs) {
+      ASP_TRY(r->plan_sizes());
+      chunk = std::min(chunk, r->chunk);
+    }
+    size_t order_lds = 0;
+    for (ShuffledRun *r : runs) {
+      ASP_TRY(r->plan_buffers(chunk));
+      order_lds = std::max(order_lds, r->order_lds);
+    }
+    for (ShuffledRun *r : runs) ASP_HIP_TRY(hipStreamSynchronize(r->p->stream));  // schedules up, status zeroed
+    if (order_lds > 64 * 1024) {
+      ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shuffled_orders_batch),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(order_lds)));
+    }
+    std::vector<std::unique_ptr<Class>> classes;
+    for (uint32_t i = 0; i < P; ++i) {
+      ShuffledRun *r = runs[i];
+      Class *c = nullptr;
+      for (auto &k : classes) {
+        if (k->wide == r->wide && k->waves == r->waves) c = k.get();
+      }
+      if (!c) {
+        classes.emplace_back(new Class());
+        c = classes.back().get();
+        c->wide = r->wide;
+        c->waves = r->waves;
+        ASP_TRY(c->stream.acquire());
+        for (auto &e : c->swept) ASP_TRY(events.make(&e));
+      }
+      c->members.push_back(i);
+      c->lds = std::max(c->lds, r->lds);
+    }
+    const int m = runs[0]->m;
+    for (auto &c : classes) {
+      std::vector<ShuffledSlot> slots;
+      for (uint32_t i : c->members) {
+        for (uint32_t g = 0; g < runs[i]->groups; ++g) slots.push_back(ShuffledSlot{i, g});
+      }
+      c->num_slots = static_cast<uint32_t>(slots.size());
+      ASP_TRY(c->slots.alloc(slots.size()));
+      ASP_TRY(c->slots.upload(slots.data(), slots.size(), c->stream.stream));
+      ASP_HIP_TRY(hipStreamSynchronize(c->stream.stream));  // `slots` dies with this scope
+      ShuffledBatchKernel kernel = shuffled_batch_kernel_for(m, c->wide);
+      if (!kernel) return asp::set_error(ASP_ERR_INVALID, "no batched shuffled kernel for %d chains per group", m);
+      if (c->lds > 64 * 1024) {
+        ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(c->lds)));
+      }
+    }
+    // ---- descriptors of every (chunk, problem) ----
+    const uint32_t chunks = num_sweeps ? (num_sweeps + chunk - 1) / chunk : 1;
+    std::vector<OrderArgs> oargs(static_cast<size_t>(chunks) * P);
+    std::vector<ShuffledArgs> sargs(static_cast<size_t>(chunks) * P);
+    for (uint32_t turn = 0; turn < chunks; ++turn) {
+      const uint32_t done = turn * chunk;
+      const uint32_t now = num_sweeps > done ? std::min(chunk, num_sweeps - done) : 0u;
+      for (uint32_t i = 0; i < P; ++i) {
+        runs[i]->chunk_args(turn, done, now, turn == 0, &oargs[static_cast<size_t>(turn) * P + i],
+                            &sargs[static_cast<size_t>(turn) * P + i]);
+      }
+    }
+    hipStream_t os0 = order_stream[0].stream;
+    ASP_TRY(d_oargs.ensure(oargs.size()));
+    ASP_TRY(d_sargs.ensure(sargs.size()));
+    ASP_TRY(d_oargs.upload(oargs.data(), oargs.size(), os0));
+    ASP_TRY(d_sargs.upload(sargs.data(), sargs.size(), os0));
+    ASP_HIP_TRY(hipStreamSynchronize(os0));
+    // ---- the pipeline of runs' enqueue(), with shared launches ----
+    const uint32_t nsets = static_cast<uint32_t>(runs[0]->nsets), nlanes = static_cast<uint32_t>(runs[0]->nlanes);
+    ASP_HIP_TRY(hipEventRecord(t_begin, os0));
+    for (uint32_t turn = 0; turn < chunks; ++turn) {
+      const uint32_t done = turn * chunk;
+      const uint32_t now = num_sweeps > done ? std::min(chunk, num_sweeps - done) : 0u;
+      const uint32_t which = turn % nsets;
+      hipStream_t os = order_stream[turn % nlanes].stream;
+      if (now) {
+        if (turn >= nsets) {
+          for (auto &c : classes) ASP_HIP_TRY(hipStreamWaitEvent(os, c->swept[which], 0));
+        }
+        hipLaunchKernelGGL(k_shuffled_orders_batch, dim3(P * now), dim3(order_threads), order_lds, os,
+                           d_oargs.ptr + static_cast<size_t>(turn) * P, now);
+        ASP_HIP_TRY(hipGetLastError());
+        ASP_HIP_TRY(hipEventRecord(ordered[which], os));
+      }
+      for (auto &c : classes) {
+        hipStream_t cs = c->stream.stream;
+        if (now) ASP_HIP_TRY(hipStreamWaitEvent(cs, ordered[which], 0));
+        ShuffledBatchKernel kernel = shuffled_batch_kernel_for(m, c->wide);
+        hipLaunchKernelGGL(kernel, dim3(c->num_slots), dim3(c->waves * 64), c->lds, cs,
+                           d_sargs.ptr + static_cast<size_t>(turn) * P, c->slots.ptr);
+        ASP_HIP_TRY(hipGetLastError());
+        ASP_HIP_TRY(hipEventRecord(c->swept[which], cs));
+      }
+    }
+    for (auto &c : classes) ASP_HIP_TRY(hipStreamWaitEvent(os0, c->swept[(chunks - 1) % nsets], 0));
+    ASP_HIP_TRY(hipEventRecord(t_end, os0));
+    for (auto &o : order_stream) ASP_HIP_TRY(hipStreamSynchronize(o.stream));
+    for (auto &c : classes) ASP_HIP_TRY(hipStreamSynchronize(c->stream.stream));
+    // ---- status of every problem; larger capacities and once more if any ran out ----
+    bool again = false;
+    for (ShuffledRun *r : runs) {
+      ASP_HIP_TRY(hipMemcpy(r->status, r->d_status.ptr, sizeof r->status, hipMemcpyDeviceToHost));
+      bool mine = false;
+      ASP_TRY(r->grow(&mine));
+      again = again || mine;
+    }
+    if (!again) break;
+    (void)first;
+  }
+  float ms = 0.0f;
+  ASP_HIP_TRY(hipEventElapsedTime(&ms, t_begin, t_end));
+  if (sweep_ms) *sweep_ms += ms;
+  for (ShuffledRun *r : runs) {
+    r->p->last_sweep_ms = ms / static_cast<float>(P);
+    r->p->last_total_ms = ms / static_cast<float>(P);
+  }
+  return ASP_OK;
+}
+
+}  // namespace
+
 namespace asp {
 
 // The shuffled items of asp_sa_anneal_batch (csrc/sa_sweep.hip): every item is exactly its own
-// asp_sa_anneal_shuffled call; the attempts of all of them are queued before any is waited for.
+// asp_sa_anneal_shuffled call.  Items are grouped by their number of sweeps; the problems of a
+// group share launches (run_shuffled_group), a group of one takes the single-problem path.
 int sa_shuffled_batch(asp_sa_batch_item const *items, const uint32_t *which, uint32_t count, float *sweep_ms) {
   std::vector<std::unique_ptr<ShuffledRun>> runs;
   runs.reserve(count);
   uint64_t budget = 16ull << 30;  // bytes of visiting orders for the whole batch, per buffer set
   if (const char *env = std::getenv("ASP_SHUFFLED_BATCH_BYTES")) budget = std::strtoull(env, nullptr, 10);
+  // chains per workgroup for the whole batch: as many as still leave two workgroups per compute unit
+  int m = 1;
+  if (count > 1) {
+    const int num_cus = items[which[0]].plan ? items[which[0]].plan->num_cus : 256;
+    for (int cand : {4, 2}) {
+      uint64_t groups = 0;
+      for (uint32_t k = 0; k < count; ++k) groups += (items[which[k]].repetitions + cand - 1) / cand;
+      if (groups >= 2ull * static_cast<uint64_t>(num_cus)) {
+        m = cand;
+        break;
+      }
+    }
+  }
   for (uint32_t k = 0; k < count; ++k) {
     const asp_sa_batch_item &it = items[which[k]];
     runs.emplace_back(new ShuffledRun());
@@ -1350,21 +1639,38 @@ int sa_shuffled_batch(asp_sa_batch_item const *items, const uint32_t *which, uin
     r.out_x = it.out_x;
     r.out_e = it.out_e;
     r.budget = std::max<uint64_t>(64ull << 20, std::min<uint64_t>(3ull << 30, budget / count));
+    if (count > 1 && it.plan && !it.plan->shuffled_m) r.forced_m = m;
     ASP_TRY(r.setup());
   }
-  for (auto &r : runs) ASP_TRY(r->enqueue());
-  for (auto &r : runs) {
-    bool again = false;
-    ASP_TRY(r->collect(&again));
-    while (again) {
-      ASP_TRY(r->enqueue());
-      ASP_TRY(r->collect(&again));
+  // groups of equal ladder length (and equal chains per workgroup: a plan with a forced width
+  // keeps it and runs alone)
+  std::vector<bool> taken(runs.size(), false);
+  for (size_t i = 0; i < runs.size(); ++i) {
+    if (taken[i] || runs[i]->trivial) continue;
+    std::vector<ShuffledRun *> group;
+    for (size_t j = i; j < runs.size(); ++j) {
+      if (!taken[j] && !runs[j]->trivial && runs[j]->num_sweeps == runs[i]->num_sweeps && runs[j]->m == runs[i]->m &&
+          runs[j]->m <= 4) {
+        group.push_back(runs[j].get());
+        taken[j] = true;
+      }
+    }
+    taken[i] = true;
+    if (group.size() >= 2) {
+      ASP_TRY(run_shuffled_group(group, sweep_ms));
+    } else {
+      ShuffledRun &r = *runs[i];
+      bool again = true;
+      while (again) {
+        ASP_TRY(r.enqueue());
+        ASP_TRY(r.collect(&again));
+      }
     }
   }
   for (auto &r : runs) ASP_TRY(r->finish_enqueue());
   for (auto &r : runs) {
     ASP_TRY(r->finish_wait());
-    if (sweep_ms && r->p) *sweep_ms += r->p->last_sweep_ms;
+    if (sweep_ms && r->p && !r->batched) *sweep_ms += r->p->last_sweep_ms;
   }
   return ASP_OK;
 }

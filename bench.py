@@ -371,6 +371,15 @@ def bench_batched_clusters(num_problems=128, serial_every=8):
             raise RuntimeError("batched anneal disagrees with the per-cluster call")
     flips_all = float(sum(sizes)) * reps * sweeps
     flips_subset = float(sum(sizes[i] for i in subset)) * reps * sweeps
+    # the same batch with the reference annealer's visiting order (ASP_SA_BATCH_SHUFFLED: the
+    # problems share one order launch and one sweep launch per wavefront class and chunk)
+    sa.anneal_batch(hams[:4], seed=1, number_sweeps=8, repetitions=reps, sweep_order="shuffled")  # warm-up
+    t0 = time.perf_counter()
+    shuffled = sa.anneal_batch(hams, seed=12345, number_sweeps=sweeps, repetitions=reps, sweep_order="shuffled")
+    t_shuffled = time.perf_counter() - t0
+    x, e = sa.anneal(hams[subset[1]], seed=12345, number_sweeps=sweeps, repetitions=reps, sweep_order="shuffled")
+    if not (np.array_equal(x, shuffled[subset[1]][0]) and e == shuffled[subset[1]][1]):
+        raise RuntimeError("batched shuffled anneal disagrees with the per-cluster call")
     for ham in hams:
         ham.release()
     return {
@@ -386,6 +395,9 @@ def bench_batched_clusters(num_problems=128, serial_every=8):
         "serial_flips_per_s": flips_subset / t_serial,
         "serial_problems_per_s": len(subset) / t_serial,
         "speedup": (flips_all / t_batched) / (flips_subset / t_serial),
+        "shuffled_order_batched_s": t_shuffled,
+        "shuffled_order_batched_flips_per_s": flips_all / t_shuffled,
+        "shuffled_order_batched_problems_per_s": num_problems / t_shuffled,
     }
 
 

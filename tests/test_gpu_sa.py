@@ -1025,13 +1025,15 @@ def test_shuffled_batch_equals_the_single_calls():
     from annealing_sign_problem_amd import annealer as sa
 
     problems = []
-    for k, deg in ((90, 4.0), (700, 8.0), (2600, 14.0), (1, 1.0)):
-        J, h, ham, info, betas = _shuffled_case(k, min(deg, max(k / 3, 1.0)), 40 + k % 7, seed=k)
+    # four problems with one ladder length share their launches (two wavefront classes among
+    # them), the fifth has another length and runs by itself inside the same call
+    for k, deg, sweeps in ((90, 4.0, 40), (700, 8.0, 40), (2600, 14.0, 40), (1, 1.0, 40), (300, 6.0, 13)):
+        J, h, ham, info, betas = _shuffled_case(k, min(deg, max(k / 3, 1.0)), sweeps, seed=k)
         problems.append((J, h, ham, info, betas))
     hams = [p[2] for p in problems]
-    seeds = [5, 6, 7, 8]
-    reps = [6, 3, 9, 2]
-    offsets = [0, 4, 1, 0]
+    seeds = [5, 6, 7, 8, 9]
+    reps = [6, 3, 9, 2, 5]
+    offsets = [0, 4, 1, 0, 2]
     batch = sa.anneal_batch_raw(hams, seeds, [p[4] for p in problems], reps, offsets, shuffled=True)
     for (J, h, ham, info, betas), seed, r, off, (bx, be) in zip(problems, seeds, reps, offsets, batch):
         sx, se = sa.anneal_raw(ham, seed, betas, r, off, None, shuffled=True)
@@ -1039,6 +1041,11 @@ def test_shuffled_batch_equals_the_single_calls():
         ox, oe, _, _ = oracle.sa_anneal_shuffled(J, h, seed, betas, r, off, None, info.energy_scale_exp,
                                                  num_threads=4)
         assert np.array_equal(bx, ox) and be.tobytes() == oe.tobytes()
+    # many chains per problem: the batch packs four chains into a workgroup (the single call one)
+    big = sa.anneal_batch_raw(hams[:3], [1, 2, 3], [p[4] for p in problems[:3]], [300, 300, 300], shuffled=True)
+    for (J, h, ham, info, betas), seed, (bx, be) in zip(problems[:3], (1, 2, 3), big):
+        sx, se = sa.anneal_raw(ham, seed, betas, 300, 0, None, shuffled=True)
+        assert np.array_equal(bx, sx) and be.tobytes() == se.tobytes()
     # the public entry points: anneal_batch(sweep_order=...) == [anneal(..., sweep_order=...)]
     best = sa.anneal_batch(hams[:3], seed=12345, number_sweeps=30, repetitions=5, sweep_order="shuffled")
     for ham, (x, e) in zip(hams[:3], best):
