@@ -1450,7 +1450,6 @@ struct EventPool {
 int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
   const uint32_t P = static_cast<uint32_t>(runs.size());
   const uint32_t num_sweeps = runs[0]->num_sweeps;
-  asp_sa_plan *first = runs[0]->p;
   // one block size for the shared order launch: the largest any problem wants
   uint32_t order_threads = 64;
   for (ShuffledRun *r : runs) order_threads = std::max(order_threads, r->order_threads);
@@ -1459,6 +1458,10 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
     r->batched = true;
     r->teams = 1;
   }
+  // (declared before the streams: released after the streams have been waited for, also on an
+  // early error return)
+  DeviceBuffer<OrderArgs> d_oargs;
+  DeviceBuffer<ShuffledArgs> d_sargs;
   asp::ScopedStream order_stream[ShuffledRun::kLanes];
   for (auto &o : order_stream) ASP_TRY(o.acquire());
   // classes of workgroup shape: (layout, wavefronts)
@@ -1466,8 +1469,8 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
     bool wide;
     uint32_t waves;
     std::vector<uint32_t> members;
+    DeviceBuffer<ShuffledSlot> slots;  // (before the stream: released after it has been waited for)
     asp::ScopedStream stream;
-    DeviceBuffer<ShuffledSlot> slots;
     uint32_t num_slots = 0;
     size_t lds = 0;
     hipEvent_t swept[ShuffledRun::kSets] = {nullptr, nullptr, nullptr};
@@ -1477,8 +1480,6 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
   for (auto &e : ordered) ASP_TRY(events.make(&e));
   ASP_TRY(events.make(&t_begin, true));
   ASP_TRY(events.make(&t_end, true));
-  DeviceBuffer<OrderArgs> d_oargs;
-  DeviceBuffer<ShuffledArgs> d_sargs;
   for (;;) {
     // ---- plan: capacities, one chunk length for all, buffers ----
     uint32_t chunk = 256;
@@ -1589,7 +1590,6 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
       again = again || mine;
     }
     if (!again) break;
-    (void)first;
   }
   float ms = 0.0f;
   ASP_HIP_TRY(hipEventElapsedTime(&ms, t_begin, t_end));

@@ -187,6 +187,29 @@ def test_batched_annealing_gives_identical_output(tmp_path):
     assert np.all(np.isfinite(v[:, 3:5]))  # the SA columns are filled
 
 
+def test_pipeline_with_the_shuffled_visiting_order(tmp_path):
+    """--sweep-order shuffled: the annealing of the pipeline with the reference annealer's visiting
+    order, batched (shared launches) and per model: the same file; other SA columns than the
+    colour order's, the same greedy columns."""
+    from annealing_sign_problem_amd import sampled_components
+
+    common_args = ["--model", "heisenberg_kagome_16", "--order", "1", "--number-samples", "6",
+                   "--seed", "5", "--max-cluster-size", "300"]
+    a, b, c = tmp_path / "loop.csv", tmp_path / "batch.csv", tmp_path / "colour.csv"
+    sampled_components.main(common_args + ["--output", str(a), "--batch", "1", "--sweep-order", "shuffled"])
+    sampled_components.main(common_args + ["--output", str(b), "--sweep-order", "shuffled"])
+    sampled_components.main(common_args + ["--output", str(c)])
+    assert a.read_text() == b.read_text()
+    rows = lambda path: np.array([[float(t) for t in l.split(",")] for l in path.read_text().splitlines()
+                                  if not l.startswith("#")])
+    shuffled, colour = rows(a), rows(c)
+    sa_columns = [3, 4, 9, 10]
+    greedy_and_sizes = [0, 1, 2, 5, 6, 7, 8, 11]
+    assert np.array_equal(shuffled[:, greedy_and_sizes], colour[:, greedy_and_sizes])
+    assert np.all(np.isfinite(shuffled[:, sa_columns]))
+    assert np.all(shuffled[:, [3, 9]] >= 0.5 - 1e-12) and np.all(shuffled[:, [4, 10]] <= 1.0 + 1e-12)
+
+
 def test_pipeline_from_yaml_and_hdf5_inputs(tmp_path, models):
     """The reference's own inputs (driver :755-757, common.py:791-803): --yaml names the operator,
     --hdf5 holds the ground state and the basis representatives (here in shuffled order, which
