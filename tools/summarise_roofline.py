@@ -33,7 +33,8 @@ def counters(directory, match):
         for r in csv.DictReader(open(f)):
             if match in r["Kernel_Name"]:
                 total[r["Counter_Name"]] += float(r["Counter_Value"])
-                seen[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                # (per file: two runs of one command number their dispatches alike)
+                seen[(f, r["Dispatch_Id"])] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     return dict(total), len(seen), float(sum(seen.values()))
 
 
