@@ -383,6 +383,13 @@ def _main_with_workers(args):
         raise SystemExit("Output file '{}' already exists: refusing to overwrite".format(args.output))
     np.random.seed(args.seed)
     hamiltonian, ground_state = load_input(args)
+    from . import _lib
+
+    if _lib.gpu_touched():
+        # (a ground state computed on the GPU on the spot: --model of a 32-/36-site system without --hdf5)
+        raise SystemExit("--workers forks after the inputs are loaded and needs them loaded WITHOUT the "
+                         "GPU: write the ground state first (python -m annealing_sign_problem_amd.sector_ed) "
+                         "and pass it with --hdf5")
     noisy_ground_state = (common.add_noise_to_amplitudes(ground_state, args.noise) if args.noise > 0
                           else ground_state)
     ctx = multiprocessing.get_context("fork")
