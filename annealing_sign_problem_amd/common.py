@@ -37,6 +37,7 @@ __all__ = [
     "monte_carlo_sampling",
     "add_noise_to_amplitudes",
     "ground_state_to_log_coeff_fn",
+    "norm2",
     "SamplingResult",
 ]
 
@@ -55,6 +56,34 @@ class IsingModel:
     @property
     def size(self) -> int:
         return self.spins.shape[0]
+
+
+BLAS_THREADING_THRESHOLD = 10000  # OpenBLAS splits dot products longer than this over its threads
+
+
+def dot(a: np.ndarray, b: np.ndarray) -> float:
+    """``np.dot`` of two real vectors, kept off the BLAS thread pool.  Up to 10 000 elements it
+    IS ``np.dot`` (one BLAS kernel on the calling thread: the reference's arithmetic).  Longer
+    vectors OpenBLAS hands to its thread pool: the summation order then depends on the number of
+    its threads, the call takes the library's global lock, so that the pipeline's --jobs threads
+    queue up behind it, and the pool's workers keep spinning on the cores afterwards — measured
+    on the sampled-cluster pipeline: 5 to 30 ms per call and every OTHER stage 2.5x slower
+    (profiles/r03_pipeline_stages.txt).  Those go through numpy's pairwise summation: the same
+    value to the last bit or two, on every machine, in 0.03 ms."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.shape[0] <= BLAS_THREADING_THRESHOLD:
+        return float(np.dot(a, b))
+    return float(np.add.reduce(a * b))
+
+
+def norm2(x: np.ndarray) -> float:
+    """Euclidean norm of a real vector: ``np.linalg.norm`` (= sqrt(dot(x, x)), common.py:166)
+    through :func:`dot`."""
+    x = np.asarray(x, dtype=np.float64)
+    if x.shape[0] <= BLAS_THREADING_THRESHOLD:
+        return float(np.linalg.norm(x))
+    return float(np.sqrt(np.add.reduce(x * x)))
 
 
 def _normalize_spins(spins) -> np.ndarray:
@@ -148,11 +177,13 @@ def make_ising_model(
         raise NotImplementedError("external_field=True is not implemented by the reference")
 
     spins = np.asarray(spins, dtype=np.uint64)
-    spins, first, multiplicity = np.unique(spins, return_index=True, return_counts=True, axis=0)
-    if np.any(multiplicity != 1):
-        warnings.warn("'spins' were not unique, are you sure this is what you want?")
-        if log_psi is not None:
-            log_psi = np.asarray(log_psi)[first]
+    if not (spins.ndim == 1 and (spins.shape[0] < 2 or bool(np.all(spins[1:] > spins[:-1])))):
+        # (the pipeline's clusters and extensions arrive sorted and unique: no sort for them)
+        spins, first, multiplicity = np.unique(spins, return_index=True, return_counts=True, axis=0)
+        if np.any(multiplicity != 1):
+            warnings.warn("'spins' were not unique, are you sure this is what you want?")
+            if log_psi is not None:
+                log_psi = np.asarray(log_psi)[first]
     if log_psi is None:
         log_psi = log_psi_fn(spins)
     if spins.ndim > 1:
@@ -163,7 +194,7 @@ def make_ising_model(
     if not np.allclose(psi.imag, 0, atol=1e-6):
         raise ValueError("expected all wavefunction coefficients to be real")
     psi = np.ascontiguousarray(psi.real)
-    psi /= np.linalg.norm(psi)
+    psi /= norm2(psi)
 
     matrix = None
     ising_hamiltonian = None
@@ -221,7 +252,7 @@ def binary_search(haystack, needles) -> np.ndarray:
     (common.py:544-548)."""
     haystack = np.asarray(haystack)
     needles = np.asarray(needles)
-    assert np.all(np.sort(haystack) == haystack)
+    assert haystack.shape[0] < 2 or np.all(haystack[1:] >= haystack[:-1])  # (sorted)
     indices = np.searchsorted(haystack, needles)
     assert np.all(haystack[np.minimum(indices, haystack.shape[0] - 1)] == needles)
     return indices

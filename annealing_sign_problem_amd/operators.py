@@ -460,7 +460,9 @@ class DeviceOperator:
             _lib.check(rc)
             break
         z = int(nnz.value)
-        return row[:z].copy(), col[:z].copy(), val[:z].copy()
+        # views: only the pages the library wrote are resident, and a copy of 10 MB per model
+        # is time under the interpreter lock
+        return row[:z], col[:z], val[:z]
 
     def extend(self, keys) -> np.ndarray:
         """Sorted unique union of the targets of ``keys`` (their own states included)."""

@@ -138,7 +138,8 @@ def amplitude_overlap(cluster, ground_state, noisy_ground_state, basis) -> float
     where = np.asarray(basis.batched_index(cluster), dtype=np.int64)
     a = np.abs(ground_state[where])
     b = np.abs(noisy_ground_state[where])
-    return float(np.dot(a, b) / np.linalg.norm(a) / np.linalg.norm(b))
+    # (common.dot / norm2: np.dot and np.linalg.norm kept off the BLAS thread pool)
+    return float(common.dot(a, b) / common.norm2(a) / common.norm2(b))
 
 
 def process_cluster(cluster, hamiltonian, ground_state, noisy_ground_state, noisy_log_coeff_fn,

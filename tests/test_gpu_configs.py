@@ -55,12 +55,13 @@ def test_full_space_coupling_build_and_energy_identity(models, name):
         j2 = np.asarray(models[name]["hamiltonian"]["terms"][1]["matrix"], dtype=float)
         assert j2[3, 3] == 1.0 and j2[0, 0] == 0.55  # the YAML's quirk is part of the config
     # the amplitudes exactly as make_ising_model forms them (common.py:178-181): exp of the
-    # log-amplitudes, real part, L2-normalised
+    # log-amplitudes, real part, L2-normalised (common.norm2: np.linalg.norm up to 10 000
+    # elements, numpy's pairwise sum beyond, where BLAS would split the sum over its threads)
     from annealing_sign_problem_amd import common
 
     log_psi = common.ground_state_to_log_coeff_fn(psi, op.basis)(op.basis.states)
     amp = np.ascontiguousarray(np.exp(log_psi, dtype=np.complex128).real)
-    amp /= np.linalg.norm(amp)
+    amp /= common.norm2(amp)
     want = reference_route_ising(op, op.basis.states, amp)
     got = scipy.sparse.coo_matrix(model.ising_hamiltonian.exchange)
     assert np.array_equal(got.row, want.row) and np.array_equal(got.col, want.col)
