@@ -114,6 +114,8 @@ SIGNATURES = {
                                    ctypes.POINTER(c_u64)]),
     "asp_operator_ising": (c_int, [c_void_p, c_u64, c_void_p, c_void_p, c_u64, c_void_p, c_void_p,
                                    c_void_p, ctypes.POINTER(c_u64)]),
+    "asp_operator_ising_csr": (c_int, [c_void_p, c_u64, c_void_p, c_void_p, c_u64, c_void_p, c_void_p,
+                                       c_void_p, ctypes.POINTER(c_u64)]),
     "asp_operator_extend": (c_int, [c_void_p, c_u64, c_void_p, c_u64, c_void_p,
                                     ctypes.POINTER(c_u64)]),
     "asp_operator_last_ms": (c_float, []),

@@ -52,6 +52,10 @@ class IsingModel:
     quantum_hamiltonian: Any
     ising_hamiltonian: sa.Hamiltonian
     initial_signs: np.ndarray
+    # (not in the reference) positions of `spins` in the basis, when the amplitude closure that
+    # built the model looked them up: later stages of the pipeline reuse them instead of asking
+    # the basis again
+    basis_index: Optional[np.ndarray] = None
 
     @property
     def size(self) -> int:
@@ -184,8 +188,13 @@ def make_ising_model(
             warnings.warn("'spins' were not unique, are you sure this is what you want?")
             if log_psi is not None:
                 log_psi = np.asarray(log_psi)[first]
+    basis_index = None
     if log_psi is None:
-        log_psi = log_psi_fn(spins)
+        if hasattr(log_psi_fn, "index_of"):  # (ground_state_to_log_coeff_fn's closure)
+            basis_index = log_psi_fn.index_of(spins)
+            log_psi = log_psi_fn.at_index(basis_index)
+        else:
+            log_psi = log_psi_fn(spins)
     if spins.ndim > 1:
         spins = np.ascontiguousarray(spins[:, 0])
     n = spins.shape[0]
@@ -204,10 +213,8 @@ def make_ising_model(
         # states, the duplicate-keeping passes for symmetry-adapted bases.  Rows with duplicates
         # AND one-directional matrix elements are refused: host route below.
         try:
-            row, col, val = quantum_hamiltonian.device().ising(spins, psi)
-            # row-major, columns ascending, no duplicates (csrc/operator_apply.hip): CSR by counting
-            indptr = np.zeros(n + 1, dtype=np.int32 if val.shape[0] < 2**31 else np.int64)
-            np.cumsum(np.bincount(row, minlength=n), out=indptr[1:])
+            # row-major, columns ascending, no duplicates (csrc/operator_apply.hip): canonical CSR
+            indptr, col, val = quantum_hamiltonian.device().ising_csr(spins, psi)
             ising_hamiltonian = sa.Hamiltonian.from_canonical_csr(indptr, col, val, np.zeros(n))
         except _lib.AspError as error:
             if error.code != -3:
@@ -222,7 +229,7 @@ def make_ising_model(
         matrix = matrix.tocoo()
         ising_hamiltonian = sa.Hamiltonian(matrix, np.zeros(n, dtype=np.float64))
     x0 = sa.signs_to_bits(np.sign(psi))
-    return IsingModel(spins, quantum_hamiltonian, ising_hamiltonian, x0)
+    return IsingModel(spins, quantum_hamiltonian, ising_hamiltonian, x0, basis_index)
 
 
 def compute_accuracy_and_overlap(
@@ -373,7 +380,8 @@ def sparsify_using_global_cutoff(model: IsingModel, reltol: float, frozen_spins)
     signs = sa.bits_to_signs(model.initial_signs, model.size)[keep]
     field = model.ising_hamiltonian.field[keep]
     hamiltonian = sa.Hamiltonian.from_canonical_csr(exchange.indptr, exchange.indices, exchange.data, field)
-    return IsingModel(spins, model.quantum_hamiltonian, hamiltonian, sa.signs_to_bits(signs))
+    basis_index = None if model.basis_index is None else model.basis_index[keep]
+    return IsingModel(spins, model.quantum_hamiltonian, hamiltonian, sa.signs_to_bits(signs), basis_index)
 
 
 def invert_permutation(p) -> np.ndarray:
@@ -530,11 +538,19 @@ def ground_state_to_log_coeff_fn(ground_state, basis):
         log_amplitude = np.log(np.abs(ground_state))
     phase = np.where(ground_state >= 0, 0, np.pi)
 
-    def log_coeff_fn(spins: np.ndarray) -> np.ndarray:
+    def index_of(spins: np.ndarray) -> np.ndarray:
         spins = np.asarray(spins, dtype=np.uint64, order="C")
         if spins.ndim > 1:
             spins = spins[:, 0]
-        where = np.asarray(basis.batched_index(spins), dtype=np.int64)
+        return np.asarray(basis.batched_index(spins), dtype=np.int64)
+
+    def at_index(where: np.ndarray) -> np.ndarray:
         return log_amplitude[where] + 1j * phase[where]
 
+    def log_coeff_fn(spins: np.ndarray) -> np.ndarray:
+        return at_index(index_of(spins))
+
+    # the two halves of the closure, for callers that keep the positions (make_ising_model)
+    log_coeff_fn.index_of = index_of
+    log_coeff_fn.at_index = at_index
     return log_coeff_fn

@@ -72,7 +72,7 @@ struct Pool {
   std::unordered_map<void *, PoolBlock> live;                 // handed out
   std::map<std::pair<int, size_t>, std::vector<void *>> idle;  // (device, class) -> blocks
   size_t idle_bytes = 0;
-  size_t cap = 1ull << 30;
+  size_t cap = 16ull << 30;  // of 288 GB: sixteen pipeline threads each recycle ~0.3 GB of buffers
   Pool() {
     if (const char *env = std::getenv("ASP_POOL_BYTES")) cap = std::strtoull(env, nullptr, 10);
   }

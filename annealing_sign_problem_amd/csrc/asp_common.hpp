@@ -53,7 +53,7 @@ int chosen_device();  // -1: asp_set_device was never called
 // hipMalloc/hipFree cost ~0.1-0.5 ms each and hipFree synchronises the device; a sampled-
 // cluster run builds and drops three plans per cluster, tens of thousands of times.  Freed
 // blocks are therefore kept per device in size classes (four per octave) up to a cap
-// (ASP_POOL_BYTES, default 1 GiB; 0 disables) and handed out again.  Every entry point
+// (ASP_POOL_BYTES, default 16 GiB; 0 disables) and handed out again.  Every entry point
 // synchronises its stream before returning, so a block is idle when it comes back.
 int pool_alloc(size_t bytes, void **out);
 void pool_free(void *ptr);

@@ -612,8 +612,8 @@ int symmetrise_batch(const asp_operator *op, uint64_t n, const ApplyBatch &w, ui
 // asp_operator_ising for operators whose rows may reach a state twice; `missing` receives the
 // number of entries without a mirror (non-zero: the caller must not use the result).
 int ising_with_duplicates(const asp_operator *op, uint64_t K, const uint64_t *keys,
-                          const double *psi, uint64_t capacity, int32_t *row, int32_t *col,
-                          double *val, uint64_t *nnz, hipStream_t stream) {
+                          const double *psi, uint64_t capacity, int32_t *row, int64_t *indptr,
+                          int32_t *col, double *val, uint64_t *nnz, hipStream_t stream) {
   Timer timer;
   ApplyBatch w;
   DeviceBuffer<uint64_t> d_other;
@@ -704,13 +704,13 @@ int ising_with_duplicates(const asp_operator *op, uint64_t K, const uint64_t *ke
                           "use the host route", missing);
   }
   *nnz = static_cast<uint64_t>(total);
-  if (capacity == 0 && !row && !col && !val) {  // sizing call
+  if (capacity == 0 && !row && !indptr && !col && !val) {  // sizing call
     ASP_TRY(timer.stop());
     ASP_HIP_TRY(hipStreamSynchronize(stream));
     timer.finish();
     return ASP_OK;
   }
-  if (*nnz > capacity || !row || !col || !val) {
+  if (*nnz > capacity || (!row && !indptr) || !col || !val) {
     return asp::set_error(ASP_ERR_INVALID, "%llu couplings do not fit capacity %llu",
                           (unsigned long long)*nnz, (unsigned long long)capacity);
   }
@@ -724,7 +724,8 @@ int ising_with_duplicates(const asp_operator *op, uint64_t K, const uint64_t *ke
   hipLaunchKernelGGL(k_sym_rows<true>, dim3(grid_for(K, kWaves)), dim3(kThreads), 0, stream, y);
   ASP_HIP_TRY(hipGetLastError());
   ASP_TRY(timer.stop());
-  ASP_TRY(d_row.download(row, *nnz, stream));
+  if (row) ASP_TRY(d_row.download(row, *nnz, stream));
+  if (indptr) ASP_TRY(d_row_start.download(indptr, K + 1, stream));
   ASP_TRY(d_col.download(col, *nnz, stream));
   ASP_TRY(d_val.download(val, *nnz, stream));
   ASP_HIP_TRY(hipStreamSynchronize(stream));
@@ -957,9 +958,11 @@ int asp_operator_apply(asp_operator const *op, uint64_t n, uint64_t const *keys,
   return ASP_OK;
 }
 
-int asp_operator_ising(asp_operator const *op, uint64_t num_spins, uint64_t const *keys,
-                       double const *psi, uint64_t capacity, int32_t *row, int32_t *col,
-                       double *val, uint64_t *nnz) {
+namespace {
+
+int operator_ising(asp_operator const *op, uint64_t num_spins, uint64_t const *keys,
+                   double const *psi, uint64_t capacity, int32_t *row, int64_t *indptr, int32_t *col,
+                   double *val, uint64_t *nnz) {
   asp_clear_error();
   ASP_TRY(check_operator(op));
   if (!nnz) return asp::set_error(ASP_ERR_INVALID, "null nnz pointer");
@@ -979,7 +982,7 @@ int asp_operator_ising(asp_operator const *op, uint64_t num_spins, uint64_t cons
   if (!op->unique_targets) {
     // rows may reach a state twice (symmetry-adapted bases, single-site flips): the variant that
     // keeps the reference's duplicate arithmetic
-    return ising_with_duplicates(op, K, keys, psi, capacity, row, col, val, nnz, stream);
+    return ising_with_duplicates(op, K, keys, psi, capacity, row, indptr, col, val, nnz, stream);
   }
   uint64_t slots_n = 1024;
   while (slots_n < 2 * K) slots_n <<= 1;
@@ -1021,13 +1024,13 @@ int asp_operator_ising(asp_operator const *op, uint64_t num_spins, uint64_t cons
                              stream));
   ASP_HIP_TRY(hipStreamSynchronize(stream));
   *nnz = static_cast<uint64_t>(total);
-  if (capacity == 0 && !row && !col && !val) {  // sizing call
+  if (capacity == 0 && !row && !indptr && !col && !val) {  // sizing call
     ASP_TRY(timer.stop());
     ASP_HIP_TRY(hipStreamSynchronize(stream));
     timer.finish();
     return ASP_OK;
   }
-  if (*nnz > capacity || !row || !col || !val) {
+  if (*nnz > capacity || (!row && !indptr) || !col || !val) {
     return asp::set_error(ASP_ERR_INVALID, "%llu couplings do not fit capacity %llu",
                           (unsigned long long)*nnz, (unsigned long long)capacity);
   }
@@ -1055,12 +1058,27 @@ int asp_operator_ising(asp_operator const *op, uint64_t num_spins, uint64_t cons
   hipLaunchKernelGGL(k_ising_rows<true>, dim3(grid_for(K, kWaves)), dim3(kThreads), lds, stream, a);
   ASP_HIP_TRY(hipGetLastError());
   ASP_TRY(timer.stop());
-  ASP_TRY(d_row.download(row, *nnz, stream));
+  if (row) ASP_TRY(d_row.download(row, *nnz, stream));
+  if (indptr) ASP_TRY(d_row_start.download(indptr, K + 1, stream));
   ASP_TRY(d_col.download(col, *nnz, stream));
   ASP_TRY(d_val.download(val, *nnz, stream));
   ASP_HIP_TRY(hipStreamSynchronize(stream));
   timer.finish();
   return ASP_OK;
+}
+
+}  // namespace
+
+int asp_operator_ising(asp_operator const *op, uint64_t num_spins, uint64_t const *keys,
+                       double const *psi, uint64_t capacity, int32_t *row, int32_t *col,
+                       double *val, uint64_t *nnz) {
+  return operator_ising(op, num_spins, keys, psi, capacity, row, nullptr, col, val, nnz);
+}
+
+int asp_operator_ising_csr(asp_operator const *op, uint64_t num_spins, uint64_t const *keys,
+                           double const *psi, uint64_t capacity, int64_t *indptr, int32_t *col,
+                           double *val, uint64_t *nnz) {
+  return operator_ising(op, num_spins, keys, psi, capacity, nullptr, indptr, col, val, nnz);
 }
 
 int asp_operator_extend(asp_operator const *op, uint64_t n, uint64_t const *keys,

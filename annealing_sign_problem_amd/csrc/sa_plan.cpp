@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <limits>
 #include <numeric>
@@ -112,12 +113,51 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
   }
 
   stage("validate");
+  // ---- is J exactly symmetric?  (What asp_operator_ising and asp_sparsify_component deliver: the
+  //      sampled-cluster pipeline's every model.)  Then J^T = J, row i of A is row i of J without its
+  //      diagonal and with x + x for x + y — the same bits as the merge below produces — and the
+  //      transposition and the merge, 40 % of this function, are not needed.  Decided by two 64-bit
+  //      multiset hashes of the entries above and below the diagonal, keyed by (min, max, bits of
+  //      the value): equal multisets cancel exactly; unequal ones cancel in BOTH sums with
+  //      probability 2^-128, and only then would a matrix be taken for symmetric that is not.
+  bool symmetric = true;
+  {
+    auto mix = [](uint64_t x) {  // splitmix64 finaliser
+      x ^= x >> 30;
+      x *= 0xBF58476D1CE4E5B9ull;
+      x ^= x >> 27;
+      x *= 0x94D049BB133111EBull;
+      x ^= x >> 31;
+      return x;
+    };
+    uint64_t sum_a = 0, sum_b = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+      for (int64_t k = indptr[i]; k < indptr[i + 1]; ++k) {
+        const uint64_t j = static_cast<uint64_t>(indices[k]);
+        if (j == i) continue;
+        uint64_t bits;
+        std::memcpy(&bits, &data[k], sizeof bits);
+        const uint64_t lo = i < j ? i : j, hi = i < j ? j : i;
+        const uint64_t pair = mix((lo << 32) | hi);
+        const uint64_t a = mix(pair ^ bits), b = mix((pair + 0x9E3779B97F4A7C15ull) ^ (bits * 3 + 1));
+        if (i < j) {
+          sum_a += a;
+          sum_b += b;
+        } else {
+          sum_a -= a;
+          sum_b -= b;
+        }
+      }
+    }
+    symmetric = sum_a == 0 && sum_b == 0;
+  }
+  stage("symmetry");
   // ---- J^T by rows (bucket the entries by column; rows are visited in order so
   //      every bucket ends up sorted by original row) --------------------------
   const unsigned parts = host_threads(n);
-  std::vector<int64_t> t_ptr(n + 1, 0);
-  std::vector<Entry> t_entries(static_cast<size_t>(nnz));
-  {
+  std::vector<int64_t> t_ptr(symmetric ? 0 : n + 1, 0);
+  std::vector<Entry> t_entries(symmetric ? 0 : static_cast<size_t>(nnz));
+  if (!symmetric) {
     // parallel counting sort by column: part p owns a contiguous range of rows, so writing the
     // parts' entries of a column one after the other keeps every column sorted by row
     std::vector<int64_t> cursor(static_cast<size_t>(parts) * n, 0);
@@ -151,6 +191,17 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
   // Row i of A is the merge of row i of J and row i of J^T; two passes (count, fill) so that
   // the rows can be produced in parallel.  emit(col, value) is called in column order.
   auto merge_row = [&](uint64_t i, auto emit, double *diagonal) {
+    if (symmetric) {  // J_ji is J_ij
+      for (int64_t k = indptr[i]; k < indptr[i + 1]; ++k) {
+        if (static_cast<uint64_t>(indices[k]) == i) {
+          if (diagonal) *diagonal = data[k];
+          continue;
+        }
+        const double v = data[k] + data[k];
+        if (v != 0.0) emit(indices[k], v);
+      }
+      return;
+    }
     const Entry *t = t_entries.data() + t_ptr[i];
     const Entry *t_end = t_entries.data() + t_ptr[i + 1];
     int64_t k = indptr[i];

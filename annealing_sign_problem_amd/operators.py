@@ -464,6 +464,33 @@ class DeviceOperator:
         # is time under the interpreter lock
         return row[:z], col[:z], val[:z]
 
+    def ising_csr(self, keys, psi) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """The matrix of :meth:`ising` as canonical CSR ``(indptr i64[K + 1], col i32, val f64)``."""
+        import ctypes
+
+        _lib = self._lib_module
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        psi = np.ascontiguousarray(psi, dtype=np.float64)
+        if psi.shape != keys.shape:
+            raise ValueError("psi and keys differ in length")
+        k = keys.shape[0]
+        capacity = k * self.max_connections
+        nnz = ctypes.c_uint64(0)
+        indptr = np.zeros(k + 1, dtype=np.int64)
+        while True:
+            col = np.empty(max(capacity, 1), dtype=np.int32)
+            val = np.empty(max(capacity, 1), dtype=np.float64)
+            rc = self._lib.asp_operator_ising_csr(self._handle, k, _lib.ptr(keys), _lib.ptr(psi),
+                                                  capacity, _lib.ptr(indptr), _lib.ptr(col),
+                                                  _lib.ptr(val), ctypes.byref(nnz))
+            if rc != 0 and int(nnz.value) > capacity:
+                capacity = int(nnz.value)
+                continue
+            _lib.check(rc)
+            break
+        z = int(nnz.value)
+        return indptr, col[:z], val[:z]  # (views: see ising)
+
     def extend(self, keys) -> np.ndarray:
         """Sorted unique union of the targets of ``keys`` (their own states included)."""
         import ctypes

@@ -32,45 +32,76 @@ from . import annealer as sa
 from . import common, operators, synthetic
 
 
+def _in_sorted(values: np.ndarray, haystack: np.ndarray) -> np.ndarray:
+    """Membership of ``values`` in the ascending array ``haystack``."""
+    if haystack.shape[0] == 0:
+        return np.zeros(values.shape[0], dtype=bool)
+    at = np.minimum(np.searchsorted(haystack, values), haystack.shape[0] - 1)
+    return haystack[at] == values
+
+
 def create_small_cluster_around_point(s0: int, hamiltonian, required_size: int = 20,
                                       keep_probability: float = 0.5) -> List[int]:
     """Breadth-first growth: each new neighbour is kept with ``keep_probability``
-    (common.py:481-513)."""
+    (common.py:481-513).
+
+    The reference walks a frontier state by state: add the state to the cluster, stop when the
+    cluster is large enough, otherwise apply the Hamiltonian to it and draw one random number per
+    target that is not in the cluster yet.  Here a whole pass over the frontier is one step: the
+    state at which the pass stops follows from the frontier alone, so the states before it are
+    applied in ONE call (the GPU action for this package's operators), membership of every
+    target at the moment the reference would test it is ``in the cluster before the pass, or
+    earlier in the frontier``, and the random numbers of the pass are one draw of as many
+    doubles from the same legacy stream.  Same clusters, same stream position afterwards
+    (tests/test_host_logic.py checks it against the state-by-state loop); 4096 clusters of
+    kagome_36 take seconds instead of 35 s of interpreter loops."""
     assert hamiltonian.basis.number_spins <= 64
     s0 = int(s0)
     members = {s0}
 
     def connections(states):
-        """Targets of every state (own state first), one array per state.  The action does not
-        depend on the cluster grown so far, so a whole frontier is applied in one call — the
-        GPU action for this package's operators, ``batched_apply`` for foreign ones — instead
-        of the reference's one ``hamiltonian.apply`` per state (common.py:492)."""
+        """Targets of every state (own state first), flat, with the number per state."""
         flat, _, counts = common._batched_apply(hamiltonian, np.asarray(states, dtype=np.uint64))
-        return np.split(flat, np.cumsum(counts)[:-1])
+        return np.asarray(flat, dtype=np.uint64).reshape(-1), np.asarray(counts, dtype=np.int64)
 
-    def children_of(targets):
-        kept = []
-        for x in targets:
-            if x in members:
-                continue
-            if np.random.rand() <= keep_probability:
-                kept.append(int(x))
-        return kept
+    def draw(targets, is_member):
+        """The targets that survive: not a member, and one uniform draw each, in order."""
+        candidates = np.flatnonzero(~is_member)
+        kept = candidates[np.random.rand(candidates.shape[0]) <= keep_probability]
+        return kept  # positions into `targets`
 
-    frontier = children_of(connections([s0])[0])
+    targets, _ = connections([s0])
+    frontier = targets[draw(targets, targets == np.uint64(s0))].tolist()
     while len(members) < required_size and len(frontier) > 0:
-        upcoming = set()
         order = list(frontier)
-        # applied lazily in chunks: the loop usually stops long before a big frontier is used up
-        chunk, at = [], 0
-        for k, child in enumerate(order):
-            members.add(child)
-            if len(members) >= required_size:
-                break
-            if k >= at + len(chunk):
-                at = k
-                chunk = connections(order[k:k + 256])
-            upcoming |= set(children_of(chunk[k - at]))
+        order_arr = np.asarray(order, dtype=np.uint64)
+        before = np.fromiter(members, dtype=np.uint64, count=len(members))
+        before.sort()
+        # the pass adds order[0], order[1], ... and stops at the state that fills the cluster
+        unique, first = np.unique(order_arr, return_index=True)
+        grows = np.zeros(len(order), dtype=bool)
+        grows[first[~_in_sorted(unique, before)]] = True
+        full = np.flatnonzero(len(members) + np.cumsum(grows) >= required_size)
+        if full.shape[0]:
+            stop = int(full[0])  # added, then the pass (and the growth) ends
+            members.update(order[:stop + 1])
+        else:
+            stop = len(order)
+            members.update(order)
+        upcoming = set()
+        if stop > 0:
+            targets, counts = connections(order_arr[:stop])
+            child = np.repeat(np.arange(stop), counts)
+            # position of a target in the frontier (first occurrence), len(order) = not there
+            at = np.minimum(np.searchsorted(unique, targets), unique.shape[0] - 1)
+            position = np.where(unique[at] == targets, first[at], len(order))
+            kept = draw(targets, _in_sorted(targets, before) | (position <= child))
+            # the sets are built exactly as the reference builds them (one union per state, in
+            # order): the next pass iterates over the result
+            bounds = np.searchsorted(child[kept], np.arange(1, stop))
+            for part in np.split(targets[kept], bounds):
+                if part.shape[0]:
+                    upcoming |= set(part.tolist())
         frontier = upcoming
     return sorted(members)
 
@@ -81,19 +112,25 @@ def random_cluster_size(min_size: float, max_size: float) -> int:
     return int(round(np.exp(np.log(min_size) + (np.log(max_size) - np.log(min_size)) * u)))
 
 
-def generate_clusters(hamiltonian, ground_state, number_samples: int, sampled_power: float,
-                      min_cluster_size: int, max_cluster_size: int,
-                      keep_probability: float) -> List[np.ndarray]:
-    """driver :652-669."""
+def iter_clusters(hamiltonian, ground_state, number_samples: int, sampled_power: float,
+                  min_cluster_size: int, max_cluster_size: int, keep_probability: float):
+    """driver :652-669, one cluster at a time (all draws from numpy's global stream, in the
+    reference's order: the seeds first, then size and growth of one cluster after the other)."""
     seeds = common.monte_carlo_sampling(hamiltonian.basis.states, ground_state,
                                         number_samples=number_samples, sampled_power=sampled_power)
-    clusters = []
     for s in seeds.spins:
         size = random_cluster_size(min_cluster_size, max_cluster_size)
         cluster = create_small_cluster_around_point(s, hamiltonian, required_size=size,
                                                     keep_probability=keep_probability)
-        clusters.append(np.asarray(cluster, dtype=np.uint64))
-    return clusters
+        yield np.asarray(cluster, dtype=np.uint64)
+
+
+def generate_clusters(hamiltonian, ground_state, number_samples: int, sampled_power: float,
+                      min_cluster_size: int, max_cluster_size: int,
+                      keep_probability: float) -> List[np.ndarray]:
+    """driver :652-669."""
+    return list(iter_clusters(hamiltonian, ground_state, number_samples, sampled_power,
+                              min_cluster_size, max_cluster_size, keep_probability))
 
 
 @dataclass
@@ -133,13 +170,27 @@ def solve_and_test_model(h: common.IsingModel, frozen_spins, exact_signs, weight
                               float("nan"))
 
 
-def amplitude_overlap(cluster, ground_state, noisy_ground_state, basis) -> float:
-    """driver :719-723."""
-    where = np.asarray(basis.batched_index(cluster), dtype=np.int64)
+def amplitude_overlap(cluster, ground_state, noisy_ground_state, basis, where=None) -> float:
+    """driver :719-723.  ``where``: the positions of ``cluster`` in the basis when the caller has
+    them already (IsingModel.basis_index)."""
+    if where is None:
+        where = np.asarray(basis.batched_index(cluster), dtype=np.int64)
     a = np.abs(ground_state[where])
     b = np.abs(noisy_ground_state[where])
     # (common.dot / norm2: np.dot and np.linalg.norm kept off the BLAS thread pool)
     return float(common.dot(a, b) / common.norm2(a) / common.norm2(b))
+
+
+def exact_signs_and_weights(cluster, model, ground_state, basis):
+    """Signs and normalised weights psi^2 of the exact ground state on the cluster (driver
+    :733-737); ``model`` is the order-0 model of the cluster, whose basis positions are reused."""
+    where = model.basis_index
+    if where is None or model.size != len(cluster):
+        where = np.asarray(basis.batched_index(cluster), dtype=np.int64)
+    exact_psi = ground_state[where]
+    weights = exact_psi ** 2
+    weights /= np.sum(weights)
+    return sa.signs_to_bits(np.sign(exact_psi)), weights
 
 
 def process_cluster(cluster, hamiltonian, ground_state, noisy_ground_state, noisy_log_coeff_fn,
@@ -147,20 +198,18 @@ def process_cluster(cluster, hamiltonian, ground_state, noisy_ground_state, nois
                     sweep_order: Optional[str] = None) -> List[OptimizationResult]:
     """driver :726-751."""
     basis = hamiltonian.basis
-    exact_psi = ground_state[np.asarray(basis.batched_index(cluster), dtype=np.int64)]
-    exact_signs = sa.signs_to_bits(np.sign(exact_psi))
-    weights = exact_psi ** 2
-    weights /= np.sum(weights)
     results = []
     h = None
     for i in range(order + 1):
         if i == 0:
             h = common.make_ising_model(cluster, hamiltonian, log_psi_fn=noisy_log_coeff_fn)
+            exact_signs, weights = exact_signs_and_weights(cluster, h, ground_state, basis)
         else:
             h = common.make_hamiltonian_extension(h, noisy_log_coeff_fn)
             h = common.sparsify_using_global_cutoff(h, global_cutoff, cluster)
         r = solve_and_test_model(h, cluster, exact_signs, weights, annealing, sweep_order)
-        r.amplitude_overlap = amplitude_overlap(h.spins, ground_state, noisy_ground_state, basis)
+        r.amplitude_overlap = amplitude_overlap(h.spins, ground_state, noisy_ground_state, basis,
+                                                h.basis_index)
         results.append(r)
     return results
 
@@ -178,20 +227,18 @@ def process_clusters_batched(clusters: Sequence[np.ndarray], hamiltonian, ground
     def stage(item):
         """Models of every order of one cluster, each with its greedy result."""
         index, cluster = item
-        exact_psi = ground_state[np.asarray(basis.batched_index(cluster), dtype=np.int64)]
-        exact_signs = sa.signs_to_bits(np.sign(exact_psi))
-        weights = exact_psi ** 2
-        weights /= np.sum(weights)
         h = None
         out = []
         for i in range(order + 1):
             if i == 0:
                 h = common.make_ising_model(cluster, hamiltonian, log_psi_fn=noisy_log_coeff_fn)
+                exact_signs, weights = exact_signs_and_weights(cluster, h, ground_state, basis)
             else:
                 h = common.make_hamiltonian_extension(h, noisy_log_coeff_fn)
                 h = common.sparsify_using_global_cutoff(h, global_cutoff, cluster)
             r = solve_and_test_model(h, cluster, exact_signs, weights, annealing=False)
-            r.amplitude_overlap = amplitude_overlap(h.spins, ground_state, noisy_ground_state, basis)
+            r.amplitude_overlap = amplitude_overlap(h.spins, ground_state, noisy_ground_state, basis,
+                                                    h.basis_index)
             out.append((index, h, exact_signs, weights, r))
         return out
 
@@ -308,6 +355,70 @@ def _generate_in_child(conn, hamiltonian, ground_state, args):
         os._exit(0)  # no interpreter teardown in a forked child that used the GPU
 
 
+def _stream_from_child(conn, hamiltonian, ground_state, args):
+    """Child of :func:`clusters_from_child`: grows the clusters and sends them as they come."""
+    try:
+        pending = []
+        for cluster in iter_clusters(hamiltonian, ground_state, args.number_samples, args.sampled_power,
+                                     args.min_cluster_size, args.max_cluster_size, args.keep_probability):
+            pending.append(cluster)
+            if len(pending) >= 16:
+                conn.send(("clusters", pending))
+                pending = []
+        if pending:
+            conn.send(("clusters", pending))
+        conn.send(("done", None))
+    except BaseException as error:  # noqa: BLE001 - reported to the parent
+        conn.send(("error", "%s: %s" % (type(error).__name__, error)))
+    finally:
+        conn.close()
+        os._exit(0)  # no interpreter teardown in a forked child that used the GPU
+
+
+def clusters_from_child(hamiltonian, ground_state, args):
+    """The clusters of :func:`iter_clusters`, grown in a FORKED child while the caller solves the
+    ones it has received.  Growth is one sequential chain of random draws (a fifth of the run
+    for 4096 greedy clusters of kagome_36) and needs the interpreter; the child has its own.  It
+    inherits the seeded random stream at the fork, so the clusters are the ones the caller would
+    have grown itself.  Only for a caller that has not used the GPU yet (a process that has must
+    not fork): otherwise, and where there is no fork, the clusters are grown in place."""
+    import multiprocessing
+
+    from . import _lib
+
+    # (under torch.distributed.run the rank has bound its GPU through torch already)
+    in_place = (_lib.gpu_touched() or "RANK" in os.environ
+                or "fork" not in multiprocessing.get_all_start_methods()
+                or os.environ.get("ASP_GROW_IN_PLACE") == "1")
+    if in_place:
+        yield from iter_clusters(hamiltonian, ground_state, args.number_samples, args.sampled_power,
+                                 args.min_cluster_size, args.max_cluster_size, args.keep_probability)
+        return
+    ctx = multiprocessing.get_context("fork")
+    receiver, sender = ctx.Pipe(False)
+    child = ctx.Process(target=_stream_from_child, args=(sender, hamiltonian, ground_state, args))
+    child.start()
+    sender.close()
+    try:
+        while True:
+            try:
+                kind, payload = receiver.recv()
+            except EOFError:
+                raise SystemExit("cluster generation ended without a result (child exit code %s)"
+                                 % child.exitcode)
+            if kind == "clusters":
+                yield from payload
+            elif kind == "done":
+                return
+            else:
+                raise SystemExit("cluster generation failed: " + payload)
+    finally:
+        receiver.close()
+        child.join(timeout=30)
+        if child.is_alive():
+            child.terminate()
+
+
 def _worker_init():
     """Worker k computes on GPU k mod (number of GPUs): on a multi-GPU node one command fills all
     of them from one copy of the inputs; on a one-GPU box the workers share the device."""
@@ -418,6 +529,12 @@ def main(argv=None):
     from . import distributed as asp_dist
 
     args = parse_command_line(argv)
+    started = time.perf_counter()
+
+    def phase(name):  # development aid: ASP_PIPELINE_TIMING=1 prints the wall time of the phases
+        if os.environ.get("ASP_PIPELINE_TIMING"):
+            sys.stderr.write("[pipeline] %-28s at %7.2f s\n" % (name, time.perf_counter() - started))
+
     if args.workers > 1 and "RANK" not in os.environ:
         from . import _lib
 
@@ -438,19 +555,30 @@ def main(argv=None):
     if refuse:
         raise SystemExit("Output file '{}' already exists: refusing to overwrite".format(args.output))
     hamiltonian, ground_state = load_input(args)
+    phase("inputs loaded")
     if args.noise > 0:
         noisy_ground_state = common.add_noise_to_amplitudes(ground_state, args.noise)
     else:
         noisy_ground_state = ground_state
     noisy_log_coeff_fn = common.ground_state_to_log_coeff_fn(noisy_ground_state, hamiltonian.basis)
+    phase("amplitude tables")
     # the clusters are grown once, by rank 0, and handed to the others (same file for any world
     # size: the draws come from rank 0's seeded stream either way)
-    clusters = None
-    if writer:
-        clusters = generate_clusters(hamiltonian, ground_state, args.number_samples,
-                                     args.sampled_power, args.min_cluster_size,
-                                     args.max_cluster_size, args.keep_probability)
-    clusters = asp_dist.broadcast_object(clusters)
+    if asp_dist.world_size() > 1:
+        clusters = None
+        if writer:
+            clusters = generate_clusters(hamiltonian, ground_state, args.number_samples,
+                                         args.sampled_power, args.min_cluster_size,
+                                         args.max_cluster_size, args.keep_probability)
+        clusters = asp_dist.broadcast_object(clusters)
+        phase("clusters grown")
+    else:
+        # one process: a forked child grows the clusters while this one solves them
+        clusters = clusters_from_child(hamiltonian, ground_state, args)
+    if args.jobs > 1:
+        # several plans are built at once: one host thread each (csrc/sa_plan.cpp starts four for
+        # a large model, which pays for one model at a time only)
+        os.environ.setdefault("ASP_HOST_THREADS", "1")
     if writer:
         _write_header(args)
     def work(cluster):
@@ -506,13 +634,27 @@ def main(argv=None):
     if args.jobs > 1 and (args.batch <= 1 or not args.annealing):
         from concurrent.futures import ThreadPoolExecutor
 
+        import collections
+
         with ThreadPoolExecutor(max_workers=args.jobs) as pool:
-            for columns in pool.map(work, clusters):
-                append([",".join(r.to_csv_str() for r in columns)])
+            # submitted as the child delivers them; written in cluster order as they finish
+            pending = collections.deque()
+            for cluster in clusters:
+                pending.append(pool.submit(work, cluster))
+                while pending and pending[0].done():
+                    append([",".join(r.to_csv_str() for r in pending.popleft().result())])
+            while pending:
+                append([",".join(r.to_csv_str() for r in pending.popleft().result())])
     else:
+        import itertools
+
         step = max(args.batch, 1)
-        for start in range(0, len(clusters), step):  # (written chunk by chunk: a long job's
-            append(work_many(clusters[start:start + step]))  # output grows as it runs)
+        while True:  # (written chunk by chunk: a long job's output grows as it runs)
+            some = list(itertools.islice(clusters, step))
+            if not some:
+                break
+            append(work_many(some))
+    phase("clusters solved")
 
 
 if __name__ == "__main__":

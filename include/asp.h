@@ -269,6 +269,12 @@ int asp_operator_apply(asp_operator const *op, uint64_t n, uint64_t const *keys,
 int asp_operator_ising(asp_operator const *op, uint64_t num_spins, uint64_t const *keys,
                        double const *psi, uint64_t capacity, int32_t *row, int32_t *col,
                        double *val, uint64_t *nnz);
+/* The same matrix as canonical CSR: indptr[num_spins + 1] instead of the row of every entry —
+ * what asp_sa_plan_create and asp_sparsify_component take, without a counting pass over the
+ * rows on the host (the sampled-cluster pipeline's form). */
+int asp_operator_ising_csr(asp_operator const *op, uint64_t num_spins, uint64_t const *keys,
+                           double const *psi, uint64_t capacity, int64_t *indptr, int32_t *col,
+                           double *val, uint64_t *nnz);
 
 /* make_hamiltonian_extension's state set (common.py:516-522): the sorted unique
  * union of every key's targets (its own diagonal entry included).  *count receives

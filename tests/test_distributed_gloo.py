@@ -182,6 +182,7 @@ def _main_worker(rank, world, port, out_path, expect_refusal):
         return fake_clusters(*args)
 
     sc.generate_clusters = fake_generate
+    sc.iter_clusters = lambda *args: iter(fake_generate(*args))  # (a single process grows them one by one)
     sc.process_cluster = fake_process
     sc.process_clusters_batched = lambda clusters, *rest, jobs=1, sweep_order=None: [
         fake_process(c, *rest, sweep_order=sweep_order) for c in clusters]
@@ -243,6 +244,8 @@ def test_pipeline_worker_processes_write_the_single_process_file(tmp_path, monke
                 for i in range(order + 1)]
 
     monkeypatch.setattr(sc, "generate_clusters", fake_clusters)
+    # (the single process streams them from a forked child, one by one: sc.clusters_from_child)
+    monkeypatch.setattr(sc, "iter_clusters", lambda *args: iter(fake_clusters(*args)))
     monkeypatch.setattr(sc, "process_cluster", fake_process)
     monkeypatch.setattr(sc, "process_clusters_batched",
                         lambda clusters, *rest, jobs=1, sweep_order=None: [

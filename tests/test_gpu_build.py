@@ -9,6 +9,14 @@ from conftest import golden
 
 pytestmark = pytest.mark.gpu
 
+
+def _norm2(x):
+    """The norm make_ising_model divides by (common.norm2: np.linalg.norm up to 10 000 elements,
+    numpy's pairwise sum beyond, where BLAS would split the sum over its threads)."""
+    from annealing_sign_problem_amd import common
+
+    return common.norm2(x)
+
 BUILD_CASES = ["hand", "word0", "multiword", "allmiss"]
 INPUTS = ["spins", "counts", "psi", "other_spins", "other_coeffs", "other_counts", "other_psi"]
 
@@ -132,7 +140,7 @@ def test_ising_elements_and_model_match_reference_golden(case):
     spins = g["spins"]
     psi = np.exp(g["log_psi"]).real
     psi = np.ascontiguousarray(psi)
-    psi /= np.linalg.norm(psi)
+    psi /= _norm2(psi)
     idx, member, elements, offsets = common.ising_elements(
         spins, psi, g["other_spins"], g["other_coeffs"], g["other_counts"])
     # numpy restatement of common.py:71-82,116-128,173

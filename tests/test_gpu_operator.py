@@ -11,6 +11,14 @@ from helpers import random_operator, reference_route_ising
 pytestmark = pytest.mark.gpu
 
 
+def _norm2(x):
+    """The norm make_ising_model divides by (common.norm2: np.linalg.norm up to 10 000 elements,
+    numpy's pairwise sum beyond, where BLAS would split the sum over its threads)."""
+    from annealing_sign_problem_amd import common
+
+    return common.norm2(x)
+
+
 def _same(a, b):
     a, b = np.asarray(a), np.asarray(b)
     assert a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
@@ -33,7 +41,7 @@ def test_device_operator_matches_reference_golden(case, name, models):
     flat = common._batched_apply(op, g["spins"])
     _same(flat[0], g["other_spins"])
     psi = np.ascontiguousarray(np.exp(g["log_psi"]).real)
-    psi /= np.linalg.norm(psi)
+    psi /= _norm2(psi)
     row, col, val = dev.ising(g["spins"], psi)
     _same(row, g["row"].astype(np.int32))
     _same(col, g["col"].astype(np.int32))
@@ -73,7 +81,7 @@ def test_device_operator_general_matrices(seed, kind, unique):
     op, keys, psi = random_operator(seed, kind, number_spins=14, num_bonds=20, num_keys=900)
     log_psi = np.log(psi.astype(np.complex128))
     psi = np.ascontiguousarray(np.exp(log_psi).real)  # what make_ising_model will see
-    psi /= np.linalg.norm(psi)
+    psi /= _norm2(psi)
     dev = op.device()
     assert dev.unique_targets == unique
     table = op.bond_table()
@@ -113,7 +121,7 @@ def test_fused_route_equals_reference_route_on_kagome36_cluster():
     log_psi = synthetic.hashed_log_amplitudes(keys)
     model = common.make_ising_model(keys, op, log_psi=log_psi)
     psi = np.ascontiguousarray(np.exp(log_psi).real)
-    psi /= np.linalg.norm(psi)
+    psi /= _norm2(psi)
     ref = reference_route_ising(op, keys, psi)
     m = scipy.sparse.coo_matrix(model.ising_hamiltonian.exchange)
     assert np.array_equal(m.row, ref.row) and np.array_equal(m.col, ref.col)
@@ -151,7 +159,7 @@ def test_device_operator_dense_sk32_rows():
     second, _, _ = op.batched_apply(first[:80, 0])
     keys = np.unique(np.concatenate([first[:, 0], second[:, 0]]))[:3000]
     psi = rng.normal(size=keys.size)
-    psi /= np.linalg.norm(psi)
+    psi /= _norm2(psi)
     dev = op.device()
     table = op.bond_table()
     row, col, val = dev.ising(keys, psi)
@@ -232,7 +240,7 @@ def test_raw_ctypes_binding_as_documented(models):
     g = golden("make_ising_kagome16_cluster.npz")
     spins = np.ascontiguousarray(g["spins"], dtype=np.uint64)
     psi = np.ascontiguousarray(np.exp(g["log_psi"]).real)
-    psi /= np.linalg.norm(psi)
+    psi /= _norm2(psi)
     capacity = g["data"].shape[0]
     row = np.zeros(capacity, np.int32)
     col = np.zeros(capacity, np.int32)
@@ -276,7 +284,7 @@ def test_device_operator_sixty_four_sites():
     keys = np.unique(np.concatenate([first[:, 0], second[:, 0]]))[:4000]
     assert keys.max() >= np.uint64(1) << np.uint64(63) and keys.min() < np.uint64(1) << np.uint64(63)
     psi = rng.normal(size=keys.size)
-    psi /= np.linalg.norm(psi)
+    psi /= _norm2(psi)
     dev, table = op.device(), op.bond_table()
     row, col, val = dev.ising(keys, psi)
     o_row, o_col, o_val = oracle.operator_ising(table, keys, psi)

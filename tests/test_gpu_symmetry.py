@@ -9,6 +9,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _norm2(x):
+    """The norm make_ising_model divides by (common.norm2: np.linalg.norm up to 10 000 elements,
+    numpy's pairwise sum beyond, where BLAS would split the sum over its threads)."""
+    from annealing_sign_problem_amd import common
+
+    return common.norm2(x)
+
+
 def _random_representatives(op, count, seed):
     rng = np.random.default_rng(seed)
     n, w = op.basis.number_spins, op.basis.hamming_weight
@@ -55,7 +63,7 @@ def test_state_info_apply_and_extension_equal_the_numpy_restatement(models, name
     from helpers import reference_route_ising
 
     psi = np.ascontiguousarray(np.exp(log_psi).real)
-    psi /= np.linalg.norm(psi)
+    psi /= _norm2(psi)
     want = reference_route_ising(op, keys, psi)
     row, col, val = dev.ising(keys, psi)
     assert np.array_equal(row, want.row) and np.array_equal(col, want.col)
@@ -82,7 +90,7 @@ def test_kagome_18_full_sector_energy_identity_and_chains(models):
     assert model.size == 24310
     h = model.ising_hamiltonian
     amp = np.exp(fn(op.basis.states)).real
-    amp /= np.linalg.norm(amp)
+    amp /= _norm2(amp)
     rayleigh = float(amp @ (op.to_sparse().real @ amp))
     e_signs = h.energy(model.initial_signs)
     assert abs(e_signs - rayleigh) <= 1e-12 * abs(rayleigh)

@@ -170,6 +170,33 @@ def test_plan_layout_matches_oracle_layout():
         assert len(set(pos.tolist())) == n and pos.max() < info.num_blocks * 64
         assert info.ell_entries % 256 == 0 and info.ell_entries >= nnz
         assert info.beta0_auto > 0 and info.beta1_auto >= info.beta0_auto or nnz == 0
+    # an exactly symmetric J takes a short cut (A = 2 offdiag(J) without transposing); the same
+    # couplings handed over as an upper triangle, or with ONE mirror element off by an ulp, go
+    # through the general merge: same layout, same greedy tree, bit for bit / as the oracle says
+    J, h, _ = synthetic.planted_cluster(3000, seed=3)
+    J = (J + scipy.sparse.diags(np.random.default_rng(0).normal(size=3000))).tocsr()
+    J.sort_indices()
+    assert abs(J - J.T).max() == 0
+    upper = (2.0 * scipy.sparse.triu(J, 1) + scipy.sparse.diags(J.diagonal())).tocsr()
+    upper.sort_indices()
+    nudged = J.copy()
+    k = int(np.flatnonzero(nudged.indices != np.repeat(np.arange(3000), np.diff(nudged.indptr)))[5])
+    nudged.data[k] = np.nextafter(nudged.data[k], np.inf)
+    results = []
+    for m in (J, upper, nudged):
+        info = _lib.SaInfo()
+        colors, pos, x = np.zeros(3000, np.int32), np.zeros(3000, np.uint32), np.zeros(47, np.uint64)
+        args = (3000, _lib.ptr(m.indptr.astype(np.int64)), _lib.ptr(m.indices.astype(np.int32)),
+                _lib.ptr(m.data), _lib.ptr(h))
+        _lib.check(lib.asp_sa_layout_host(*args, ctypes.byref(info), _lib.ptr(colors), _lib.ptr(pos)))
+        _lib.check(lib.asp_sa_greedy_tree_host(*args, _lib.ptr(x)))
+        ocolors, _, ncol, nnz, diag = oracle.sa_layout(m)
+        assert np.array_equal(colors, ocolors) and info.num_colors == ncol
+        assert info.nnz_offdiag == nnz and info.diag_sum == diag
+        assert np.array_equal(x, oracle.greedy_solve(m, h, relax=False)[0])
+        results.append((colors, pos, x, info.beta0_auto, info.beta1_auto, info.energy_scale_exp))
+    for a, b in zip(results[0], results[1]):
+        assert np.array_equal(a, b)
     # rejects non-canonical input loudly
     bad_indices = np.array([1, 0], np.int32)
     rc = lib.asp_sa_layout_host(2, _lib.ptr(np.array([0, 2, 2], np.int64)), _lib.ptr(bad_indices),
@@ -249,25 +276,8 @@ def test_greedy_solves_unfrustrated_instance_exactly():
     assert abs(e - planted @ (J @ planted)) <= 1e-12 * abs(e)
 
 
-def test_cluster_growth_is_connected_and_sized(models):
-    from annealing_sign_problem_amd import operators, sampled_components
-
-    op = operators.Operator.from_config(models["heisenberg_kagome_16"])
-    op.basis.build()
-    np.random.seed(5)
-    start = int(op.basis.states[1234])
-
-    class Foreign:  # not this package's Operator type: growth uses its batched_apply on the host
-        basis = op.basis
-
-        def batched_apply(self, x):
-            return op.batched_apply(x)
-
-    cluster = sampled_components.create_small_cluster_around_point(start, Foreign(),
-                                                                   required_size=120)
-    # the frontier-at-once growth consumes the random stream exactly like the reference's
-    # state-by-state loop (common.py:481-513), restated here
-    np.random.seed(5)
+def _state_by_state_growth(op, start, required_size, keep_probability):
+    """The reference's loop (common.py:481-513), restated."""
     members = {start}
 
     def children_of(state):
@@ -275,20 +285,53 @@ def test_cluster_growth_is_connected_and_sized(models):
         for x in op.apply(state)[0][:, 0]:
             if x in members:
                 continue
-            if np.random.rand() <= 0.5:
+            if np.random.rand() <= keep_probability:
                 kept.append(int(x))
         return kept
 
     frontier = children_of(start)
-    while len(members) < 120 and len(frontier) > 0:
+    while len(members) < required_size and len(frontier) > 0:
         upcoming = set()
         for child in frontier:
             members.add(child)
-            if len(members) >= 120:
+            if len(members) >= required_size:
                 break
             upcoming |= set(children_of(child))
         frontier = upcoming
-    assert cluster == sorted(members)
+    return sorted(members)
+
+
+def test_cluster_growth_is_connected_and_sized(models):
+    from annealing_sign_problem_amd import operators, sampled_components
+
+    op = operators.Operator.from_config(models["heisenberg_kagome_16"])
+    op.basis.build()
+
+    class Foreign:  # not this package's Operator type: growth uses its batched_apply on the host
+        basis = op.basis
+
+        def batched_apply(self, x):
+            return op.batched_apply(x)
+
+    # the pass-at-once growth consumes the random stream exactly like the reference's
+    # state-by-state loop: same clusters AND the same stream position afterwards, for clusters
+    # that fill up, for a frontier that dies out first (keep probability 0.02) and for a cluster
+    # that wants more states than the basis has
+    for seed, index, size, keep in [(5, 1234, 120, 0.5), (6, 17, 50, 0.5), (7, 9000, 1000, 0.5),
+                                    (8, 400, 300, 0.02), (9, 77, 2, 0.5), (10, 5000, 1, 0.5),
+                                    (11, 3, 20000, 0.9), (12, 12869, 700, 0.3)]:
+        start = int(op.basis.states[index])
+        np.random.seed(seed)
+        got = sampled_components.create_small_cluster_around_point(start, Foreign(), required_size=size,
+                                                                   keep_probability=keep)
+        after = np.random.rand()
+        np.random.seed(seed)
+        want = _state_by_state_growth(op, start, size, keep)
+        assert got == want and after == np.random.rand(), (seed, index, size, keep)
+        assert len(got) <= max(size, 1) or size <= 1
+    np.random.seed(5)
+    start = int(op.basis.states[1234])
+    cluster = sampled_components.create_small_cluster_around_point(start, Foreign(), required_size=120)
     assert cluster == sorted(cluster) and start in cluster and len(set(cluster)) == len(cluster)
     assert 60 <= len(cluster) <= 120
     # connected under the Hamiltonian's off-diagonal action
