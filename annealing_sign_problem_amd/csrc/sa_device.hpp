@@ -259,7 +259,10 @@ using LdsWord = __attribute__((address_space(3))) const uint32_t;
 //           up to ~4e4 spins): the +-1.0 multiplier of a term is then ONE SDWA instruction.
 //   kGlobal: the bit words of kBits kept in HBM (one replica): no LDS limit on the size, every
 //           neighbour gather is an L2 access — the slow path for clusters beyond ~1.3e6 spins.
-constexpr int kBytes = 0, kBits = 1, kWide = 2, kGlobal = 3;
+//   kNibbles: four bits per position — two positions share a byte — for M <= 4 replicas: twice the
+//           capacity of kBytes (~2.4e5 spins) at four replicas per workgroup instead of kBits'
+//           one; a flip is an LDS atomic XOR on the word that holds the nibble.
+constexpr int kBytes = 0, kBits = 1, kWide = 2, kGlobal = 3, kNibbles = 6;  // (4, 5: team / shuffled launches, as reported by asp_sa_last_layout)
 
 // kWide: byte m of `word` (0x00 / 0x80) OR 0x3F becomes byte 3 of `hi`, whose lower three bytes
 // keep 0xF00000 — i.e. hi = high word of +1.0 or -1.0 — in one v_or_b32_sdwa (byte select on
@@ -319,6 +322,17 @@ __device__ __forceinline__ void accumulate_quad(const Quad &q, const uint8_t *sp
     const uint32_t *words = reinterpret_cast<const uint32_t *>(spins);
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] = (words[cs[j] >> 5] >> (cs[j] & 31u)) & 1u;
+  } else if constexpr (LAYOUT == kNibbles) {
+    // position c: byte c / 2, nibble c % 2; the bits above replica m's are ignored by spin_factor
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#if ASP_ABS_LDS
+      const uint32_t byte = *reinterpret_cast<LdsByte *>(static_cast<uintptr_t>(cs[j] >> 1));
+#else
+      const uint32_t byte = spins[cs[j] >> 1];
+#endif
+      s[j] = byte >> ((cs[j] & 1u) << 2);
+    }
   } else {
 #if ASP_ABS_LDS
     // the spin bytes start at LDS address 0 (checked in the kernel prologue), so a position IS

@@ -116,6 +116,21 @@ __device__ __forceinline__ void snapshot(const uint8_t *spins, const Args &a, ui
     }
     return;
   }
+  if constexpr (LAYOUT == kNibbles) {  // a wavefront per block: one ballot per replica
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t b = threadIdx.x >> 6; b < a.num_blocks; b += blockDim.x >> 6) {
+      const uint32_t nibble = static_cast<uint32_t>(spins[b * 32u + (lane >> 1)]) >> ((lane & 1u) << 2);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        if (!((mask >> m) & 1u)) continue;  // workgroup-uniform
+        const uint64_t word = __ballot((nibble >> m) & 1u);
+        if (lane == 0) {
+          a.best_perm[(static_cast<uint64_t>(group) * M + m) * a.num_blocks + b] = word;
+        }
+      }
+    }
+    return;
+  }
   if constexpr (LAYOUT == kBits || LAYOUT == kGlobal) {  // the words already are the sign bits
     const uint64_t *words = reinterpret_cast<const uint64_t *>(spins);
     for (uint32_t w = threadIdx.x; w < a.num_blocks; w += blockDim.x) {
@@ -158,15 +173,17 @@ __device__ __forceinline__ void sa_sweep_body(const Args &a, const uint32_t grou
   constexpr bool GLOBAL = LAYOUT == kGlobal;
   constexpr bool PACKED = LAYOUT == kBits || GLOBAL;  // one bit per position
   constexpr bool WIDE = LAYOUT == kWide;
+  constexpr bool NIBBLES = LAYOUT == kNibbles;
   static_assert(!PACKED || M == 1, "the bit-packed layouts hold one replica");
+  static_assert(!NIBBLES || (M <= 4 && !DESCENT), "the nibble layout holds up to four replicas");
   static_assert(!WIDE || (M <= 4 && !DESCENT), "the wide layout holds up to four replicas");
   extern __shared__ __align__(16) uint8_t lds[];
   // kGlobal: this workgroup's bit words live in HBM, the LDS holds the bookkeeping only
   uint8_t *spins = GLOBAL ? reinterpret_cast<uint8_t *>(a.spin_words +
                                                        static_cast<uint64_t>(group) * a.num_blocks)
                           : lds;
-  // bytes of the spin area per block: 64 (a byte per position), 8 (a bit) or 256 (a word)
-  const uint32_t P = GLOBAL ? 0u : a.num_blocks * (PACKED ? 8u : (WIDE ? 256u : 64u));
+  // bytes of the spin area per block: 64 (a byte per position), 32 (a nibble), 8 (a bit) or 256 (a word)
+  const uint32_t P = GLOBAL ? 0u : a.num_blocks * (PACKED ? 8u : (WIDE ? 256u : (NIBBLES ? 32u : 64u)));
   // P is a multiple of 64.  Per replica m: delta[m] = energy change of the running
   // sweep, book[m] = current tracked energy, book[8+m] = best, book[16+m] = accepted flips
   long long *delta = reinterpret_cast<long long *>(lds + P);
@@ -229,6 +246,9 @@ __device__ __forceinline__ void sa_sweep_body(const Args &a, const uint32_t grou
       if ((tid & 63u) == 0) store_word<GLOBAL>(reinterpret_cast<uint64_t *>(spins) + b0, word);
     } else if constexpr (WIDE) {
       reinterpret_cast<uint32_t *>(spins)[p] = spread_mask(byte);
+    } else if constexpr (NIBBLES) {
+      const uint32_t upper = __shfl_xor(byte, 1);  // the odd lane's nibble, for the even lane
+      if ((tid & 1u) == 0) spins[p >> 1] = static_cast<uint8_t>(byte | (upper << 4));
     } else {
       spins[p] = static_cast<uint8_t>(byte);
     }
@@ -364,6 +384,8 @@ __device__ __forceinline__ void sa_sweep_body(const Args &a, const uint32_t grou
               (load_word<GLOBAL>(reinterpret_cast<const uint64_t *>(spins) + b) >> lane) & 1ull);
         } else if constexpr (WIDE) {
           own = reinterpret_cast<const uint32_t *>(spins)[p];
+        } else if constexpr (NIBBLES) {
+          own = (static_cast<uint32_t>(spins[p >> 1]) >> ((p & 1u) << 2)) & 15u;
         } else {
           own = spins[p];
         }
@@ -471,6 +493,10 @@ __device__ __forceinline__ void sa_sweep_body(const Args &a, const uint32_t grou
           }
         } else if constexpr (WIDE) {
           if (flip) reinterpret_cast<uint32_t *>(spins)[p] = own ^ spread_mask(flip);
+        } else if constexpr (NIBBLES) {
+          // the neighbouring lane owns the other nibble of the byte and may flip in the same
+          // instruction: an LDS atomic on the word (eight positions) instead of a byte store
+          if (flip) atomicXor(reinterpret_cast<uint32_t *>(spins) + (p >> 3), flip << ((p & 7u) << 2));
         } else {
           if (flip) spins[p] = static_cast<uint8_t>(own ^ flip);
         }
@@ -1147,6 +1173,7 @@ SweepKernel sweep_kernel_for(int m, bool descent, int layout) {
     return descent ? k_sa_sweep<1, true, kGlobal> : k_sa_sweep<1, false, kGlobal>;
   }
   if (layout == kWide) return m == 4 ? k_sa_sweep<4, false, kWide> : nullptr;
+  if (layout == kNibbles) return m == 4 ? k_sa_sweep<4, false, kNibbles> : nullptr;
   switch (m) {
     case 1: return descent ? k_sa_sweep<1, true, kBytes> : k_sa_sweep<1, false, kBytes>;
     case 2: return k_sa_sweep<2, false, kBytes>;
@@ -1162,7 +1189,7 @@ size_t sweep_lds_bytes(const asp::SaHostLayout &L, int layout) {
   // bit-packed: spin words | delta book | flag | cache_ctl only
   if (layout == kGlobal) return 34 * sizeof(long long) + 32;
   if (layout == kBits) return static_cast<size_t>(L.num_blocks) * 8 + 34 * sizeof(long long) + 32;
-  const size_t per_block = layout == kWide ? 256 : 64;
+  const size_t per_block = layout == kWide ? 256 : (layout == kNibbles ? 32 : 64);
   return static_cast<size_t>(L.num_blocks) * per_block + 34 * sizeof(long long) +
          static_cast<size_t>(L.num_blocks) * sizeof(uint2) + 16 +
          2 * (((static_cast<size_t>(L.num_blocks) + 15) / 16) * 16);
@@ -1433,14 +1460,24 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
   // One byte per position when that fits the LDS; otherwise one BIT per position, one replica
   // per workgroup (flips applied by wavefront ballot) — 8x the capacity.
   bool packed = p->force_packed != 0;
-  if (!packed && sweep_lds_bytes(L, kBytes) > p->max_lds) packed = true;
+  bool nibbles = false;
+  if (!packed && sweep_lds_bytes(L, kBytes) > p->max_lds) {
+    // ... or, with chains enough for four per workgroup, four bits per position: twice the
+    // capacity of bytes and still four replicas sharing every coupling load
+    if (!descent && !out_trace && m >= 4 && sweep_lds_bytes(L, kNibbles) <= p->max_lds) {
+      nibbles = true;
+      m = 4;
+    } else {
+      packed = true;
+    }
+  }
   // not even a bit per position fits the LDS: keep the words in HBM (no size limit, slow)
   const bool global = p->force_packed == 2 || (packed && sweep_lds_bytes(L, kBits) > p->max_lds);
   if (packed) m = 1;
   // A word per position (SDWA sign trick) when four replicas share the
   // workgroup and the words fit; results do not depend on the layout.
   // (measured: +2..12 % with four replicas per workgroup, nothing with two)
-  const bool wide = !packed && !descent && p->allow_wide && m == 4 &&
+  const bool wide = !packed && !nibbles && !descent && p->allow_wide && m == 4 &&
                     p->ell_col4.ptr != nullptr && sweep_lds_bytes(L, kWide) <= p->max_lds;
   // Few chains on a large cluster: spread each chain over a team of workgroups (k_sa_sweep_team).
   uint32_t team = 0;
@@ -1452,7 +1489,7 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
     const size_t team_lds = team_lds_bytes(L);
     // (one colour class only — a diagonal or field-only J —: the single barrier per sweep would
     // not separate a fast member's next publication from a slow member's read of this one)
-    const bool possible = !out_trace && !global && p->force_packed == 0 && L.num_colors >= 2 &&
+    const bool possible = !out_trace && !global && !nibbles && p->force_packed == 0 && L.num_colors >= 2 &&
                           p->force_m == 0 && team_lds <= p->max_lds &&
                           static_cast<uint64_t>(repetitions) * 2 <= static_cast<uint64_t>(p->num_cus);
     if (possible && p->team_mode >= 2) {
@@ -1467,7 +1504,8 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
   }
   if (team >= 2) m = 1;
   const int layout = team >= 2 ? kBits
-                               : (global ? kGlobal : (packed ? kBits : (wide ? kWide : kBytes)));
+                               : (global ? kGlobal
+                                         : (packed ? kBits : (nibbles ? kNibbles : (wide ? kWide : kBytes))));
   const size_t lds = team >= 2 ? team_lds_bytes(L) : sweep_lds_bytes(L, layout);
   if (lds > p->max_lds) {
     return asp::set_error(ASP_ERR_TOO_LARGE, "%zu B of LDS needed, %zu B available", lds,
@@ -1817,6 +1855,7 @@ uint32_t widest_color(const asp::SaHostLayout &L) {
 struct BatchEntry {
   uint32_t item;     // index into the caller's array
   uint32_t waves;    // wavefronts per workgroup this problem wants
+  int layout;        // kWide, kBytes or kBits
   double work;       // ~ time of one group: sweeps * ELL slabs
   uint64_t beta_at;  // offset of its ladder in the concatenated betas
 };
@@ -1868,6 +1907,9 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
   // streams (csrc/sa_shuffled.hip).
   std::vector<BatchEntry> entries;
   std::vector<uint32_t> alone, shuffled;
+  bool batch_bits = false, batch_nibbles = true;
+  if (const char *env = std::getenv("ASP_BATCH_BITS")) batch_bits = std::atoi(env) != 0;  // tests, measurements
+  if (const char *env = std::getenv("ASP_BATCH_NIBBLES")) batch_nibbles = std::atoi(env) != 0;
   for (uint32_t i = 0; i < count; ++i) {
     const asp_sa_batch_item &it = items[i];
     if (it.repetitions == 0) continue;
@@ -1877,19 +1919,38 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
     }
     const asp_sa_plan *p = it.plan;
     const asp::SaHostLayout &L = p->host;
-    const bool fits = L.num_spins > 0 && sweep_lds_bytes(L, kBytes) <= p->max_lds;
-    if (!fits || p->force_m || p->force_threads || p->force_packed) {
+    // A byte per position must fit the LDS, or (up to ~2.4e5 spins) four bits per position with
+    // four chains per workgroup.  Beyond that a chain would be one workgroup with a bit per
+    // position: as a class of the shared launches it was measured and
+    // LOSES against running those problems one after the other as team sweeps, every chain spread
+    // over four CUs (a round of 64 clusters of the pipeline, largest model 157 706 spins: 5.9 s
+    // against 4.05 s; ASP_BATCH_BITS=1 puts them into the shared launches all the same).
+    const bool bytes_fit = L.num_spins > 0 && sweep_lds_bytes(L, kBytes) <= p->max_lds;
+    const bool nibbles_fit = L.num_spins > 0 && sweep_lds_bytes(L, kNibbles) <= p->max_lds && batch_nibbles;
+    const bool bits_fit = L.num_spins > 0 && sweep_lds_bytes(L, kBits) <= p->max_lds && batch_bits;
+    if (!(bytes_fit || nibbles_fit || bits_fit) || p->force_m || p->force_threads || p->force_packed) {
       alone.push_back(i);
       continue;
     }
     const uint32_t widest = widest_color(L);
     BatchEntry e{};
     e.item = i;
-    // wavefronts per workgroup in a shared launch: 4 at most — small workgroups interleave
-    // better on a CU than the 16 a lone problem wants (cap 16 / 8 / 4 on the production mix, 128
-    // problems: 109 / 133 / 152 G flips/s, 512: 152 / 200 / 213; tools/tune_batch.py.  A
-    // register budget for 5 or 6 wavefronts per SIMD instead of 4 was also tried: no gain)
-    uint32_t cap = 4u;
+    // Layout and wavefronts per workgroup in a shared launch.  Small problems — several
+    // workgroups fit a CU — take the word layout (one-instruction signs) and 4 wavefronts: small
+    // workgroups interleave better than the 16 a lone problem wants (cap 16 / 8 / 4 on clusters of
+    // 1e2..1e4 spins, 128 problems: 109 / 133 / 152 G flips/s, 512: 152 / 200 / 213;
+    // tools/tune_batch.py).  Larger ones keep a byte per spin — the word layout would leave them
+    // one workgroup per CU — and take 16 wavefronts (the sampled-cluster pipeline's order-2 models,
+    // 1e4..2e5 spins, cap 4 / 8 / 16: 150 / 234 / 279 G flips/s; profiles/r03_batch_tune_real.txt).
+    uint64_t wide_max = 10000, small_max = 10000;
+    if (const char *env = std::getenv("ASP_BATCH_WIDE_MAX")) wide_max = std::strtoull(env, nullptr, 10);    // tuning aids
+    if (const char *env = std::getenv("ASP_BATCH_SMALL_MAX")) small_max = std::strtoull(env, nullptr, 10);
+    e.layout = !bytes_fit ? (nibbles_fit ? kNibbles : kBits)
+                          : (p->allow_wide && p->ell_col4.ptr && L.num_spins <= wide_max &&
+                                     sweep_lds_bytes(L, kWide) <= p->max_lds
+                                 ? kWide
+                                 : kBytes);
+    uint32_t cap = L.num_spins <= small_max ? 4u : 16u;
     if (const char *env = std::getenv("ASP_BATCH_WAVES")) cap = static_cast<uint32_t>(std::atoi(env));  // tuning aid
     e.waves = std::min<uint32_t>(widest, std::max(1u, std::min(16u, cap)));
     e.work = static_cast<double>(it.num_sweeps) * static_cast<double>(L.ell_off.back() + L.num_blocks);
@@ -1915,14 +1976,23 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
   const int num_cus = first->num_cus;
   const size_t max_lds = first->max_lds;
   // ---- size classes: workgroups of one launch have one thread count ----
-  static const uint32_t kClasses[] = {1, 2, 3, 4, 6, 8, 12, 16};
-  constexpr int kNumClasses = sizeof kClasses / sizeof kClasses[0];
-  auto class_of = [&](uint32_t waves) {
-    for (int c = 0; c < kNumClasses; ++c) {
-      if (waves <= kClasses[c]) return c;
+  // A launch class = (wavefront count, spin layout): kWaves[c / 4] wavefronts, layout c % 4.
+  static const uint32_t kWaves[] = {1, 2, 3, 4, 6, 8, 12, 16};
+  static const int kLayouts[] = {kWide, kBytes, kBits, kNibbles};
+  constexpr int kNumWaves = sizeof kWaves / sizeof kWaves[0];
+  constexpr int kNumClasses = 4 * kNumWaves;
+  auto class_of = [&](const BatchEntry &e) {
+    int w = kNumWaves - 1;
+    for (int c = 0; c < kNumWaves; ++c) {
+      if (e.waves <= kWaves[c]) {
+        w = c;
+        break;
+      }
     }
-    return kNumClasses - 1;
+    return 4 * w + (e.layout == kWide ? 0 : (e.layout == kBytes ? 1 : (e.layout == kBits ? 2 : 3)));
   };
+  auto waves_of_class = [&](int c) { return kWaves[c / 4]; };
+  auto layout_of_class = [&](int c) { return kLayouts[c % 4]; };
   // ---- replicas per workgroup, per class ----
   // Measured on the production mix (tools/tune_batch.py, K log-uniform in [1e2, 1e4], 64 chains x
   // 5120 sweeps): four replicas per workgroup — the word layout with its one-instruction signs —
@@ -1936,7 +2006,8 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
       uint64_t waves = 0;
       for (const BatchEntry &e : entries) {
         const uint32_t reps = items[e.item].repetitions;
-        waves += static_cast<uint64_t>((reps + cand - 1) / cand) * kClasses[class_of(e.waves)];
+        const int per_group = e.layout == kBits ? 1 : (e.layout == kNibbles ? 4 : cand);
+        waves += static_cast<uint64_t>((reps + per_group - 1) / per_group) * waves_of_class(class_of(e));
       }
       if (waves >= static_cast<uint64_t>(num_cus) * 4u) {
         m = cand;
@@ -1951,7 +2022,7 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
       const int forced = std::atoi(env);
       if (forced == 1 || forced == 2 || forced == 4 || forced == 8) {
         for (int c = 0; c < kNumClasses; ++c) {
-          if (kClasses[c] >= 8) m_of_class[c] = forced;
+          if (waves_of_class(c) >= 8) m_of_class[c] = forced;
         }
       }
     }
@@ -1961,8 +2032,16 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
         for (int c = 0; c < kNumClasses; ++c) m_of_class[c] = forced;
       }
     }
+    for (int c = 0; c < kNumClasses; ++c) {
+      if (layout_of_class(c) == kBits) m_of_class[c] = 1;  // a bit per position: one chain per workgroup
+      if (layout_of_class(c) == kNibbles) m_of_class[c] = 4;
+      // the word layout exists for four replicas: with another count its problems take bytes
+    }
   }
-  auto m_of = [&](const BatchEntry &e) { return m_of_class[class_of(e.waves)]; };
+  auto m_of = [&](const BatchEntry &e) { return m_of_class[class_of(e)]; };
+  for (BatchEntry &e : entries) {
+    if (e.layout == kWide && m_of(e) != 4) e.layout = kBytes;
+  }
   // ---- per-problem buffer offsets ----
   struct Offsets {
     uint64_t best, stat, cache, partial, e, x, groups, padded;
@@ -1979,7 +2058,7 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
     off[k] = Offsets{n_best, n_stat, n_cache, n_partial, n_e, n_x, groups, padded};
     n_best += padded * L.num_blocks;
     n_stat += padded;
-    n_cache += padded * L.num_blocks * 64ull;
+    if (entries[k].layout != kBits) n_cache += padded * L.num_blocks * 64ull;
     n_partial += static_cast<uint64_t>(it.repetitions) * L.num_blocks;
     n_e += it.repetitions;
     n_x += static_cast<uint64_t>(it.repetitions) * words;
@@ -2019,19 +2098,12 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
   std::vector<BatchSlot> h_chains;
   h_chains.reserve(n_e);
   size_t energy_lds = 0;
-  std::vector<bool> wide_ok(kNumClasses);
-  for (int c = 0; c < kNumClasses; ++c) wide_ok[c] = m_of_class[c] == 4;
-  for (size_t k = 0; k < entries.size(); ++k) {
-    const asp_sa_plan *p = items[entries[k].item].plan;
-    if (!(p->allow_wide && p->ell_col4.ptr && sweep_lds_bytes(p->host, kWide) <= max_lds)) {
-      wide_ok[class_of(entries[k].waves)] = false;
-    }
-  }
   for (size_t k = 0; k < entries.size(); ++k) {
     const asp_sa_batch_item &it = items[entries[k].item];
     const asp_sa_plan *p = it.plan;
     const asp::SaHostLayout &L = p->host;
-    const bool wide = wide_ok[class_of(entries[k].waves)];
+    const bool wide = entries[k].layout == kWide;
+    const bool packed = entries[k].layout == kBits;
     std::copy(it.betas, it.betas + it.num_sweeps, h_betas.begin() + entries[k].beta_at);
     SweepArgs a{};
     a.color_block_start = p->color_block_start.ptr;
@@ -2052,11 +2124,12 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
     a.num_blocks = L.num_blocks;
     a.num_sweeps = it.num_sweeps;
     a.replica_first = it.replica_offset;
-    a.field_cache = use_cache ? d_cache.ptr + off[k].cache : nullptr;
+    // (the bit-packed layout runs without the field cache, as in the single-problem launch)
+    a.field_cache = use_cache && !packed ? d_cache.ptr + off[k].cache : nullptr;
     const double degree =
         std::max(1.0, static_cast<double>(L.a_col.size()) / static_cast<double>(L.num_spins));
     a.cache_enter_flips =
-        static_cast<uint32_t>(std::max(1.0, 0.7 * static_cast<double>(L.num_blocks) / degree));
+        packed ? 0u : static_cast<uint32_t>(std::max(1.0, 0.7 * static_cast<double>(L.num_blocks) / degree));
     a.spin_words = nullptr;
     a.trace = nullptr;
     h_problems[k] = a;
@@ -2088,7 +2161,7 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
   for (int c = 0; c < kNumClasses; ++c) {
     std::vector<size_t> members;
     for (size_t k = 0; k < entries.size(); ++k) {
-      if (class_of(entries[k].waves) == c) members.push_back(k);
+      if (class_of(entries[k]) == c) members.push_back(k);
     }
     if (members.empty()) continue;
     std::stable_sort(members.begin(), members.end(),
@@ -2106,7 +2179,7 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
       }
       load[x] += off[k].groups;
       launches[c].lds = std::max(
-          launches[c].lds, sweep_lds_bytes(items[entries[k].item].plan->host, wide_ok[c] ? kWide : kBytes));
+          launches[c].lds, sweep_lds_bytes(items[entries[k].item].plan->host, layout_of_class(c)));
     }
     uint32_t most = 0;
     for (int x = 0; x < 8; ++x) most = std::max<uint32_t>(most, static_cast<uint32_t>(per_xcd[x].size()));
@@ -2149,8 +2222,12 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
     BatchArgs b{d_problems.ptr, d_slots.ptr + launches[c].slot_at, launches[c].slots_per_xcd};
     using BatchKernel = void (*)(BatchArgs);
     BatchKernel kernel = nullptr;
-    if (wide_ok[c]) {
+    if (layout_of_class(c) == kWide) {
       kernel = k_sa_sweep_batch<4, kWide>;
+    } else if (layout_of_class(c) == kBits) {
+      kernel = k_sa_sweep_batch<1, kBits>;
+    } else if (layout_of_class(c) == kNibbles) {
+      kernel = k_sa_sweep_batch<4, kNibbles>;
     } else {
       switch (m_of_class[c]) {
         case 1: kernel = k_sa_sweep_batch<1, kBytes>; break;
@@ -2164,7 +2241,7 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(launches[c].lds)));
     }
-    hipLaunchKernelGGL(kernel, dim3(8u * launches[c].slots_per_xcd), dim3(64u * kClasses[c]),
+    hipLaunchKernelGGL(kernel, dim3(8u * launches[c].slots_per_xcd), dim3(64u * waves_of_class(c)),
                        launches[c].lds, cs, b);
     ASP_HIP_TRY(hipGetLastError());
     ASP_HIP_TRY(hipEventRecord(ev[2 + c], cs));
@@ -2210,10 +2287,10 @@ int asp_sa_anneal_batch(asp_sa_batch_item const *items, uint32_t count) {
                            h_tracked.begin() + off[k].stat + it.repetitions);
     p->last_accepted.assign(h_accepted.begin() + off[k].stat,
                             h_accepted.begin() + off[k].stat + it.repetitions);
-    const int c = class_of(entries[k].waves);
+    const int c = class_of(entries[k]);
     p->last_m = m_of_class[c];
-    p->last_layout = wide_ok[c] ? kWide : kBytes;
-    p->last_threads = static_cast<int>(64u * kClasses[c]);
+    p->last_layout = layout_of_class(c);
+    p->last_threads = static_cast<int>(64u * waves_of_class(c));
     p->last_groups = static_cast<int>(off[k].groups);
     p->last_sweep_ms = p->last_total_ms = 0.0f;  // shared launches: see asp_sa_batch_last_ms
   }

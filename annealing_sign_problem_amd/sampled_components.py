@@ -214,14 +214,13 @@ def process_cluster(cluster, hamiltonian, ground_state, noisy_ground_state, nois
     return results
 
 
-def process_clusters_batched(clusters: Sequence[np.ndarray], hamiltonian, ground_state,
-                             noisy_ground_state, noisy_log_coeff_fn, order: int,
-                             global_cutoff: float, annealing: bool, jobs: int = 1,
-                             sweep_order: Optional[str] = None) -> List[List[OptimizationResult]]:
-    """``[process_cluster(c, ...) for c in clusters]`` with the annealing of ALL models — every
-    cluster at every order — in one batched device call.  The models of a cluster do not depend
-    on its solutions (the extension of order i grows from the model of order i-1, common.py:516),
-    so they can all be built first; the results are identical to the per-cluster loop."""
+def stage_clusters(clusters: Sequence[np.ndarray], hamiltonian, ground_state, noisy_ground_state,
+                   noisy_log_coeff_fn, order: int, global_cutoff: float, jobs: int = 1):
+    """First half of :func:`process_clusters_batched`: the models of every order of every cluster,
+    each with its greedy result — a list of ``(cluster index, model, exact_signs, weights, result
+    so far)`` in cluster order.  The models of a cluster do not depend on its solutions (the
+    extension of order i grows from the model of order i-1, common.py:516), so they can all be
+    built before anything is annealed."""
     basis = hamiltonian.basis
 
     def stage(item):
@@ -242,20 +241,33 @@ def process_clusters_batched(clusters: Sequence[np.ndarray], hamiltonian, ground
             out.append((index, h, exact_signs, weights, r))
         return out
 
-    # (cluster index, model, exact_signs, weights, result so far); the builds of different
-    # clusters are independent and their C calls release the GIL: --jobs host threads keep
-    # several in flight on the GPU (own streams); order of the list = cluster order either way
+    # the builds of different clusters are independent and their C calls release the GIL: --jobs
+    # host threads keep several in flight on the GPU (own streams); order of the list = cluster
+    # order either way
     if jobs > 1 and len(clusters) > 1:
         from concurrent.futures import ThreadPoolExecutor
 
         with ThreadPoolExecutor(max_workers=jobs) as pool:
-            staged = [entry for part in pool.map(stage, enumerate(clusters)) for entry in part]
-    else:
-        staged = [entry for item in enumerate(clusters) for entry in stage(item)]
+            return [entry for part in pool.map(stage, enumerate(clusters)) for entry in part]
+    return [entry for item in enumerate(clusters) for entry in stage(item)]
+
+
+def anneal_staged(staged, clusters: Sequence[np.ndarray], annealing: bool,
+                  sweep_order: Optional[str] = None) -> List[List[OptimizationResult]]:
+    """Second half: the annealing of ALL staged models — every cluster at every order — in one
+    batched device call, scored and sorted back into one list of results per cluster."""
     if annealing and staged:
+        started = time.perf_counter()
         solutions = common.solve_ising_models([m for _, m, _, _, _ in staged],
                                               [clusters[c] for c, _, _, _, _ in staged],
                                               sweep_order=sweep_order)
+        if os.environ.get("ASP_PIPELINE_TIMING"):  # development aid
+            spins = sum(m.size for _, m, _, _, _ in staged)
+            seconds = time.perf_counter() - started
+            sys.stderr.write("[pipeline] round of %d clusters: %d models, %d spins (largest %d) annealed "
+                             "in %.2f s = %.1f G flips/s\n" % (
+                                 len(clusters), len(staged), spins, max(m.size for _, m, _, _, _ in staged),
+                                 seconds, spins * 64 * 5120 / seconds * 1e-9))
         for (_, _, exact_signs, weights, r), x in zip(staged, solutions):
             r.sa_accuracy, r.sa_overlap = common.compute_accuracy_and_overlap(x, exact_signs, weights)
     results: List[List[OptimizationResult]] = [[] for _ in clusters]
@@ -263,6 +275,18 @@ def process_clusters_batched(clusters: Sequence[np.ndarray], hamiltonian, ground
         results[index].append(r)
         h.ising_hamiltonian.release()  # the device plan of a finished model
     return results
+
+
+def process_clusters_batched(clusters: Sequence[np.ndarray], hamiltonian, ground_state,
+                             noisy_ground_state, noisy_log_coeff_fn, order: int,
+                             global_cutoff: float, annealing: bool, jobs: int = 1,
+                             sweep_order: Optional[str] = None) -> List[List[OptimizationResult]]:
+    """``[process_cluster(c, ...) for c in clusters]`` with the annealing of ALL models — every
+    cluster at every order — in one batched device call (:func:`stage_clusters`, then
+    :func:`anneal_staged`); the results are identical to the per-cluster loop."""
+    staged = stage_clusters(clusters, hamiltonian, ground_state, noisy_ground_state, noisy_log_coeff_fn,
+                            order, global_cutoff, jobs)
+    return anneal_staged(staged, clusters, annealing, sweep_order)
 
 
 def parse_command_line(argv=None):
@@ -288,7 +312,7 @@ def parse_command_line(argv=None):
     parser.add_argument("--sampled-power", type=float, default=0.1)
     parser.add_argument("--keep-probability", type=float, default=0.5)
     parser.add_argument("--seed", type=int, default=12345)
-    parser.add_argument("--batch", type=int, default=64,
+    parser.add_argument("--batch", type=int, default=128,
                         help="clusters whose annealing chains share one batched device call "
                              "(asp_sa_anneal_batch); 1 = one call per model, as the reference's "
                              "loop.  The output does not depend on it")
@@ -647,13 +671,35 @@ def main(argv=None):
                 append([",".join(r.to_csv_str() for r in pending.popleft().result())])
     else:
         import itertools
+        from concurrent.futures import ThreadPoolExecutor
 
+        # Rounds of --batch clusters, written round by round (a long job's output grows as it
+        # runs).  While the chains of one round anneal on the GPU, a second thread builds the
+        # models of the next one (host work mostly, small kernels on streams of their own).
         step = max(args.batch, 1)
-        while True:  # (written chunk by chunk: a long job's output grows as it runs)
-            some = list(itertools.islice(clusters, step))
-            if not some:
-                break
-            append(work_many(some))
+        lines_of = lambda columns_of_clusters: [",".join(r.to_csv_str() for r in columns)  # noqa: E731
+                                                for columns in columns_of_clusters]
+        if step > 1 and args.annealing:
+            def next_round():
+                """(clusters, their staged models) of the next round; only this thread pulls clusters."""
+                some = list(itertools.islice(clusters, step))
+                return some, stage_clusters(some, hamiltonian, ground_state, noisy_ground_state,
+                                            noisy_log_coeff_fn, args.order, args.global_cutoff, args.jobs)
+
+            with ThreadPoolExecutor(max_workers=1) as builder:
+                upcoming = builder.submit(next_round)
+                while True:
+                    some, staged = upcoming.result()
+                    if not some:
+                        break
+                    upcoming = builder.submit(next_round)
+                    append(lines_of(anneal_staged(staged, some, args.annealing, args.sweep_order)))
+        else:
+            while True:
+                some = list(itertools.islice(clusters, step))
+                if not some:
+                    break
+                append(work_many(some))
     phase("clusters solved")
 
 

@@ -369,8 +369,11 @@ int asp_sa_set_packed(asp_sa_plan *p, int packed);
 /* With four replicas per workgroup and up to ~4e4 spins the kernel keeps a 32-bit word
  * per position (one byte per replica), which makes the sign of a coupling term a single SDWA
  * instruction.  allow = 0 keeps the byte layout (tests, measurements); default 1.
- * asp_sa_last_layout: 0 = bytes, 1 = bits in LDS, 2 = words, 3 = bits in HBM, for the last
- * anneal/greedy call. */
+ * Beyond the capacity of a byte per position (~1.4e5 spins) and with chains enough for four per
+ * workgroup, four bits per position (up to ~2.4e5 spins; flips are LDS atomics); otherwise a bit
+ * per position and one chain per workgroup.
+ * asp_sa_last_layout: 0 = bytes, 1 = bits in LDS, 2 = words, 3 = bits in HBM, 6 = nibbles, for
+ * the last anneal/greedy call. */
 int asp_sa_set_wide(asp_sa_plan *p, int allow);
 int asp_sa_last_layout(asp_sa_plan const *p);
 

@@ -764,6 +764,82 @@ def test_batch_many_small_clusters_fill_the_chip_and_match():
         assert np.array_equal(x, x1) and e == e1
 
 
+@pytest.mark.parametrize("mode", ["default", "bits", "alone"])
+def test_batch_mixes_the_spin_layouts(mode, monkeypatch):
+    """One batch with problems of every LDS layout — a word per spin (small), a byte per spin
+    (60 000 spins), four bits per spin (200 000 spins: the largest order-2 models of the
+    sampled-cluster pipeline) and beyond that (260 000 spins) a bit per spin.  The last kind runs
+    by itself as a team sweep by default, or as a class of the shared launches (ASP_BATCH_BITS=1);
+    ASP_BATCH_NIBBLES=0 sends the third kind the same way.  Every chain is the single-problem
+    call's and the oracle's."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+    from annealing_sign_problem_amd import synthetic
+
+    if mode != "default":
+        monkeypatch.setenv("ASP_BATCH_NIBBLES", "0")
+    if mode == "bits":
+        monkeypatch.setenv("ASP_BATCH_BITS", "1")
+    lib = _lib.load()
+    problems = []
+    for k, degree, sweeps, reps in ((200000, 6.0, 6, 5), (60000, 8.0, 8, 6), (9000, 10.0, 12, 8),
+                                    (300, 6.0, 15, 5), (260000, 5.0, 5, 2)):
+        J, h, _ = synthetic.planted_cluster(k, seed=k, mean_degree=degree)
+        ham = sa.Hamiltonian(J, h)
+        info = ham.info()
+        problems.append(dict(J=J, h=h, ham=ham, reps=reps, S=info.energy_scale_exp,
+                             betas=sa.make_schedule(info.beta0_auto, min(info.beta1_auto, 1e6), sweeps)))
+    results = sa.anneal_batch_raw([p["ham"] for p in problems], [31, 32, 33, 34, 35],
+                                  [p["betas"] for p in problems], [p["reps"] for p in problems])
+    layouts = [lib.asp_sa_last_layout(p["ham"].plan()) for p in problems]
+    # 0 bytes, 1 bits, 2 words (when four chains share a workgroup), 4 team sweep of a problem
+    # that ran by itself, 6 nibbles
+    assert layouts[0] == {"default": 6, "bits": 1, "alone": 4}[mode]
+    assert layouts[4] == (1 if mode == "bits" else 4)
+    assert layouts[1] == 0 and set(layouts[2:4]) <= {0, 2}
+    stats = [_stats(p["ham"], p["reps"]) for p in problems]
+    for seed, p, (xs, es), (tracked, accepted) in zip((31, 32, 33, 34, 35), problems, results, stats):
+        oxs, oes, otracked, oaccepted = oracle.sa_anneal(p["J"], p["h"], seed, p["betas"], p["reps"], 0,
+                                                        None, p["S"], num_threads=8)
+        assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+        assert np.array_equal(tracked, otracked) and np.array_equal(accepted, oaccepted)
+        sxs, ses = sa.anneal_raw(p["ham"], seed, p["betas"], p["reps"])
+        assert np.array_equal(xs, sxs) and es.tobytes() == ses.tobytes()
+
+
+def test_nibble_layout_single_problem_matches_oracle():
+    """170 000 spins — more than a byte per spin holds in LDS — with four chains per workgroup:
+    four bits per spin (layout 6), flips as LDS atomics, through a ladder that ends frozen (field
+    cache and inert blocks in use); chains, tracked energies and accepted flips equal the oracle's,
+    and the chain-per-workgroup bit layout's."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+    from annealing_sign_problem_amd import synthetic
+
+    lib = _lib.load()
+    J, h, _ = synthetic.planted_cluster(170000, seed=21, mean_degree=7.0)
+    ham = sa.Hamiltonian(J, h)
+    info = ham.info()
+    betas = sa.make_schedule(info.beta0_auto, info.beta1_auto, 40)
+    _set_launch(ham, 4, 1024)
+    xs, es = sa.anneal_raw(ham, 777, betas, 9, 3)
+    assert lib.asp_sa_last_layout(ham.plan()) == 6
+    tracked, accepted = _stats(ham, 9)
+    oxs, oes, otracked, oaccepted = oracle.sa_anneal(J, h, 777, betas, 9, 3, None, info.energy_scale_exp,
+                                                    num_threads=8)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    assert np.array_equal(tracked, otracked) and np.array_equal(accepted, oaccepted)
+    _set_launch(ham, 0, 0)
+    bxs, bes = sa.anneal_raw(ham, 777, betas, 9, 3)  # few chains: teams / a bit per spin
+    assert lib.asp_sa_last_layout(ham.plan()) in (1, 4)
+    assert np.array_equal(xs, bxs) and es.tobytes() == bes.tobytes()
+    # many chains: the launcher picks four per workgroup by itself
+    xs2, es2 = sa.anneal_raw(ham, 777, betas[:6], 1030)
+    assert lib.asp_sa_last_layout(ham.plan()) == 6
+    o2, oe2, _, _ = oracle.sa_anneal(J, h, 777, betas[:6], 6, 1024, None, info.energy_scale_exp, num_threads=8)
+    assert np.array_equal(xs2[1024:], o2) and es2[1024:].tobytes() == oe2.tobytes()
+
+
 def test_batch_rejects_bad_items():
     from annealing_sign_problem_amd import _lib
     from annealing_sign_problem_amd import annealer as sa

@@ -29,7 +29,10 @@ for n in counts:
     flips = float(sum(sizes)) * 64 * 5120
     sa.anneal_batch(hams[:4], seed=1, number_sweeps=8, repetitions=64)
     for waves in os.environ.get("TUNE_WAVES", "8,4").split(","):
-        os.environ["ASP_BATCH_WAVES"] = waves
+        if waves == "auto":  # the library's own choice (by LDS footprint)
+            os.environ.pop("ASP_BATCH_WAVES", None)
+        else:
+            os.environ["ASP_BATCH_WAVES"] = waves
         t0 = time.perf_counter()
         sa.anneal_batch(hams, seed=12345, number_sweeps=5120, repetitions=64)
         dt = time.perf_counter() - t0
