@@ -337,6 +337,32 @@ def bench_default_call():
     return out
 
 
+def bench_large_cluster(replicas, sweeps, k=200000):
+    """A cluster beyond the capacity of a byte per spin in LDS (~1.4e5 spins): four bits per spin,
+    four chains per workgroup (layout 6), against a bit per spin and one chain per workgroup, the
+    only choice before round 3.  The sampled-cluster pipeline's largest order-2 models."""
+    from annealing_sign_problem_amd import _lib, synthetic
+    from annealing_sign_problem_amd import annealer as sa
+
+    lib = _lib.load()
+    J, h, _ = synthetic.planted_cluster(k, seed=CLUSTER_SEED)
+    ham = sa.Hamiltonian(J, h)
+    info = ham.info()
+    betas = sa.make_schedule(info.beta0_auto, info.beta1_auto, sweeps)
+    out = {"workload": "K=%d, dbar=%.1f, %d chains x %d sweeps" % (k, J.nnz / k, replicas, sweeps)}
+    energies = []
+    for name, packed in (("nibbles", 0), ("bits", 1)):
+        _lib.check(lib.asp_sa_set_packed(ham.plan(), packed))
+        sa.anneal_raw(ham, 1, betas[:4], replicas)  # warm-up
+        _, es = sa.anneal_raw(ham, 12345, betas, replicas)
+        out[name + "_layout"] = int(lib.asp_sa_last_layout(ham.plan()))
+        out[name + "_kernel_flips_per_s"] = k * replicas * sweeps / (lib.asp_sa_last_sweep_ms(ham.plan()) * 1e-3)
+        energies.append(es)
+    if energies[0].tobytes() != energies[1].tobytes():
+        raise RuntimeError("the 4-bit and the 1-bit layout disagree")
+    return out
+
+
 def bench_batched_clusters(num_problems=128, serial_every=8):
     """The reference's production shape (experiments/sampled_connected_components.py:764-767,
     common.py:236-239): many sampled clusters, each solved with 64 chains x 5120 sweeps.  A
@@ -774,6 +800,9 @@ def main():
             out["build"] = bench_build(clusters[-1]["J"], 1)
             out["reference_default_call"] = bench_default_call()
             out["batched_small_clusters"] = bench_batched_clusters()
+            out["large_cluster"] = bench_large_cluster(replicas, args.sweeps)
+            out["large_cluster"]["valu_issue_frac"] = issue_fraction(
+                "colour_200000", counters, out["large_cluster"]["nibbles_kernel_flips_per_s"])
             out["batched_small_clusters"]["valu_issue_frac"] = issue_fraction(
                 "batch", counters, out["batched_small_clusters"]["batched_kernel_flips_per_s"])
             out["reference_default_call"]["team_valu_issue_frac"] = issue_fraction(

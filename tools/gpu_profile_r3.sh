@@ -6,7 +6,7 @@
 set -o pipefail
 export TMPDIR=/tmp
 TAG=${1:-r03}; shift
-CASES=${@:-"colour_10000 colour_30000 colour_100000 shuffled_10000 shuffled_30000 shuffled_100000 shuffled64_10000 batch team real_kagome_36"}
+CASES=${@:-"colour_10000 colour_30000 colour_100000 colour_200000 shuffled_10000 shuffled_30000 shuffled_100000 shuffled64_10000 batch team real_kagome_36"}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof3
 mkdir -p $OUT/cases
 cd $GRAFT_REPO_ROOT
