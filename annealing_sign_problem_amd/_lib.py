@@ -247,6 +247,30 @@ def load() -> ctypes.CDLL:
     return lib
 
 
+_wait_policy_applied = False
+
+
+def _apply_wait_policy() -> None:
+    """``$ASP_HIP_WAIT`` = ``spin`` | ``yield`` | ``block``: how a host thread waits for the device
+    (hipSetDeviceFlags, once, when the process first asks for the GPU — never earlier: it
+    initialises the HIP runtime, and a process that has done so must not fork).  HIP's default spins
+    on a core: the right thing for one thread, but sixteen pipeline threads waiting that way take
+    the cores away from the host stages of the other clusters."""
+    global _wait_policy_applied
+    if _wait_policy_applied:
+        return
+    _wait_policy_applied = True
+    mode = os.environ.get("ASP_HIP_WAIT", "").strip().lower()
+    flag = {"spin": 1, "yield": 2, "block": 4}.get(mode)
+    if flag is None:
+        return
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipSetDeviceFlags(ctypes.c_uint(flag))  # (an error — device in use already — is not fatal)
+    except OSError:
+        pass
+
+
 def last_error() -> str:
     return load().asp_last_error().decode("utf-8", "replace")
 
@@ -279,6 +303,7 @@ def gpu_touched() -> bool:
 def require_gpu() -> None:
     if device_count() <= 0:
         raise AspError(-1, "no HIP device visible; this package has no CPU fallback")
+    _apply_wait_policy()
 
 
 def ptr(a: Optional[np.ndarray]):

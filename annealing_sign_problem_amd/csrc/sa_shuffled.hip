@@ -382,10 +382,33 @@ struct ShuffledArgs {
   uint32_t first_sweep, chunk_sweeps, replica_first, initialise;
 };
 
+// Spins stay in LDS in ORIGINAL order, in one of four layouts: a 32-bit word per spin (kWide: byte
+// m = 0x80 * chain m is -1; up to four chains), a byte per spin (kBytes: bit m; up to eight), and —
+// for clusters beyond the capacity of bytes — four bits per spin (kNibbles: up to four chains,
+// ~2.5e5 spins) or one bit per spin (kBits: one chain, ~6e5 spins).  In the packed layouts several
+// spins share a word, so a flip is an LDS atomic XOR and a neighbour read is a byte load plus a
+// variable shift; the bits above chain m's are ignored by the sign instructions.
+template <int LAYOUT>
+inline constexpr bool kPackedLayout = LAYOUT == kNibbles || LAYOUT == kBits;
+template <int LAYOUT>
+inline constexpr uint32_t kSpinBits = LAYOUT == kNibbles ? 4u : (LAYOUT == kBits ? 1u : 8u);
+
 // Negative-spin mask of the M chains (bit m) <-> the LDS representation of one spin.
 template <int LAYOUT>
 __device__ __forceinline__ uint32_t to_lds(uint32_t mask) {
   return LAYOUT == kWide ? spread_mask(mask) : mask;
+}
+// The LDS representation of spin i.
+template <int LAYOUT>
+__device__ __forceinline__ uint32_t read_spin(const uint8_t *spins, uint32_t i) {
+  if constexpr (LAYOUT == kWide) {
+    return reinterpret_cast<const uint32_t *>(spins)[i];
+  } else if constexpr (kPackedLayout<LAYOUT>) {
+    constexpr uint32_t B = kSpinBits<LAYOUT>;
+    return (reinterpret_cast<const uint32_t *>(spins)[(i * B) >> 5] >> ((i * B) & 31u)) & ((1u << B) - 1u);
+  } else {
+    return spins[i];
+  }
 }
 template <int LAYOUT>
 __device__ __forceinline__ uint32_t from_lds(uint32_t v) {
@@ -404,8 +427,7 @@ __device__ __forceinline__ void snapshot_original(const uint8_t *spins, const Ar
     const uint32_t i = w * 64u + lane;
     uint32_t neg = (1u << M) - 1u;
     if (i < a.num_spins) {
-      neg = from_lds<LAYOUT>(LAYOUT == kWide ? reinterpret_cast<const uint32_t *>(spins)[i]
-                                             : static_cast<uint32_t>(spins[i]));
+      neg = from_lds<LAYOUT>(read_spin<LAYOUT>(spins, i));
     }
 #pragma unroll
     for (int m = 0; m < M; ++m) {
@@ -456,6 +478,12 @@ __device__ __forceinline__ void gather_quad(const HeldQuad &q, uint32_t (&s)[4])
     // columns are LDS byte addresses (sa_device.hpp: the spins start at LDS address 0)
     if constexpr (LAYOUT == kWide) {
       s[j] = *reinterpret_cast<LdsWord *>(static_cast<uintptr_t>(cs[j]));
+    } else if constexpr (LAYOUT == kNibbles) {  // (packed layouts: the column is the spin's index)
+      s[j] = static_cast<uint32_t>(*reinterpret_cast<LdsByte *>(static_cast<uintptr_t>(cs[j] >> 1))) >>
+             ((cs[j] & 1u) << 2);
+    } else if constexpr (LAYOUT == kBits) {
+      s[j] = static_cast<uint32_t>(*reinterpret_cast<LdsByte *>(static_cast<uintptr_t>(cs[j] >> 3))) >>
+             (cs[j] & 7u);
     } else {
       s[j] = *reinterpret_cast<LdsByte *>(static_cast<uintptr_t>(cs[j]));
     }
@@ -557,8 +585,11 @@ template <int M, int LAYOUT, int TEAMS, typename Args>
 __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_t group) {
   constexpr bool WIDE = LAYOUT == kWide;
   constexpr int MT = M * TEAMS;  // chains of the workgroup
-  static_assert(LAYOUT == kWide || LAYOUT == kBytes, "spins are LDS words or LDS bytes");
+  constexpr bool PACKED = kPackedLayout<LAYOUT>;
+  static_assert(LAYOUT == kWide || LAYOUT == kBytes || PACKED, "spins are LDS words, bytes, nibbles or bits");
   static_assert(!WIDE || MT <= 4, "the wide layout holds up to four chains");
+  static_assert(!PACKED || (TEAMS == 1 && M <= static_cast<int>(kSpinBits<LAYOUT>)),
+                "a packed layout holds as many chains as it has bits per spin, in one team");
   static_assert(MT <= 8 && (TEAMS == 1 || TEAMS == 2), "a byte holds eight chains");
   extern __shared__ __align__(16) uint8_t lds[];
   if (a.status[kStatBad] != 0u) return;  // an order kernel ran out of room: the host repeats the call
@@ -570,7 +601,7 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
   const uint32_t K = a.num_spins;
   uint8_t *spins = lds;  // original order: K words (byte m = 0x80 * chain m is -1) or K bytes
   uint32_t *wide = reinterpret_cast<uint32_t *>(lds);
-  const uint32_t P = ((WIDE ? K * 4u : K) + 15u) & ~15u;
+  const uint32_t P = ((WIDE ? K * 4u : (PACKED ? (K * kSpinBits<LAYOUT> + 7u) / 8u : K)) + 15u) & ~15u;
   long long *delta = reinterpret_cast<long long *>(lds + P);  // [8] energy change of the running sweep
   long long *book = delta + 8;  // [m] current tracked energy, [8 + m] best, [16 + m] accepted flips
   uint32_t *improved_flag = reinterpret_cast<uint32_t *>(book + 24);
@@ -592,6 +623,10 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
   uint8_t *state = a.state + static_cast<uint64_t>(group) * K;
 
   // ---- chain state: fresh, or where the previous chunk left it ----
+  if constexpr (PACKED) {  // spins of different threads share a word: OR them into zeroed words
+    for (uint32_t w = tid; w < P / 4u; w += blockDim.x) wide[w] = 0u;
+    __syncthreads();
+  }
   for (uint32_t i = tid; i < K; i += blockDim.x) {
     uint32_t mask;
     if (!a.initialise) {
@@ -614,6 +649,9 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
     }
     if constexpr (WIDE) {
       wide[i] = spread_mask(mask);
+    } else if constexpr (PACKED) {
+      constexpr uint32_t B = kSpinBits<LAYOUT>;
+      if (mask) atomicOr(wide + ((i * B) >> 5), mask << ((i * B) & 31u));
     } else {
       spins[i] = static_cast<uint8_t>(mask);
     }
@@ -777,7 +815,7 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
         ASP_TICK(1);
         if (busy && ASP_SHUF_ABL != 2) {
           // (this team's chains only: the partner team owns the other half of the word / byte)
-          const uint32_t own = (WIDE ? wide[me] : static_cast<uint32_t>(spins[me])) >> team_shift;
+          const uint32_t own = read_spin<LAYOUT>(spins, me) >> team_shift;
           bool need = false;  // some proposal of this lane needs a random number
           double de[M];
 #pragma unroll
@@ -835,6 +873,10 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
               }
             } else if constexpr (WIDE) {
               wide[me] = own ^ spread_mask(flip);
+            } else if constexpr (PACKED) {
+              // other lanes own the other spins of the word and may flip in the same instruction
+              constexpr uint32_t B = kSpinBits<LAYOUT>;
+              atomicXor(wide + ((me * B) >> 5), flip << ((me * B) & 31u));
             } else if constexpr (TEAMS == 2) {
               // bits of two teams in one byte: an LDS atomic keeps the partner's flips
               atomicXor(reinterpret_cast<uint32_t *>(spins) + (me >> 2), (flip << team_shift) << (8u * (me & 3u)));
@@ -894,7 +936,7 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
 #endif
 
   for (uint32_t i = tid; i < K; i += blockDim.x) {
-    state[i] = static_cast<uint8_t>(from_lds<LAYOUT>(WIDE ? wide[i] : static_cast<uint32_t>(spins[i])));
+    state[i] = static_cast<uint8_t>(from_lds<LAYOUT>(read_spin<LAYOUT>(spins, i)));
   }
   if (tid < MT) {
     const uint64_t at = static_cast<uint64_t>(group) * MT + tid;
@@ -927,22 +969,23 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled_batch(const ShuffledA
 }
 
 // m = chains per workgroup; teams = 2: two teams of m / 2 chains (wide: m = 4 or 2; bytes: m = 8 or 4)
-ShuffledKernel shuffled_kernel_for(int m, bool wide, int teams = 1) {
+ShuffledKernel shuffled_kernel_for(int m, int layout, int teams = 1) {
   if (teams == 2) {
-    if (wide) {
+    if (layout == kWide) {
       switch (m) {
         case 2: return k_sa_sweep_shuffled<1, kWide, 2>;
         case 4: return k_sa_sweep_shuffled<2, kWide, 2>;
         default: return nullptr;
       }
     }
+    if (layout != kBytes) return nullptr;
     switch (m) {
       case 4: return k_sa_sweep_shuffled<2, kBytes, 2>;
       case 8: return k_sa_sweep_shuffled<4, kBytes, 2>;
       default: return nullptr;
     }
   }
-  if (wide) {
+  if (layout == kWide) {
     switch (m) {
       case 1: return k_sa_sweep_shuffled<1, kWide, 1>;
       case 2: return k_sa_sweep_shuffled<2, kWide, 1>;
@@ -950,6 +993,15 @@ ShuffledKernel shuffled_kernel_for(int m, bool wide, int teams = 1) {
       default: return nullptr;
     }
   }
+  if (layout == kNibbles) {
+    switch (m) {
+      case 1: return k_sa_sweep_shuffled<1, kNibbles, 1>;
+      case 2: return k_sa_sweep_shuffled<2, kNibbles, 1>;
+      case 4: return k_sa_sweep_shuffled<4, kNibbles, 1>;
+      default: return nullptr;
+    }
+  }
+  if (layout == kBits) return m == 1 ? k_sa_sweep_shuffled<1, kBits, 1> : nullptr;
   switch (m) {
     case 1: return k_sa_sweep_shuffled<1, kBytes, 1>;
     case 2: return k_sa_sweep_shuffled<2, kBytes, 1>;
@@ -960,9 +1012,19 @@ ShuffledKernel shuffled_kernel_for(int m, bool wide, int teams = 1) {
 }
 
 // spins | delta[8] book[24] | flag (16 B) | meta[block_cap] | level_block[level_cap + 2]
-size_t sweep_lds_bytes(uint64_t K, bool wide, uint32_t level_cap, uint32_t block_cap) {
-  return (((wide ? K * 4 : K) + 15) & ~size_t{15}) + 32 * sizeof(long long) + 16 +
+size_t sweep_lds_bytes(uint64_t K, int layout, uint32_t level_cap, uint32_t block_cap) {
+  const uint64_t spin_bytes = layout == kWide ? K * 4 : (layout == kNibbles ? (K + 1) / 2 : (layout == kBits ? (K + 7) / 8 : K));
+  return ((spin_bytes + 15) & ~size_t{15}) + 32 * sizeof(long long) + 16 +
          static_cast<size_t>(block_cap) * sizeof(uint2) + (static_cast<size_t>(level_cap) + 2) * sizeof(uint32_t);
+}
+
+// The layout of a run with m chains per workgroup: the fastest that fits (-1: none does).
+int shuffled_layout_for(uint64_t K, int m, uint32_t level_cap, uint32_t block_cap, size_t max_lds) {
+  if (m <= 4 && sweep_lds_bytes(K, kWide, level_cap, block_cap) <= max_lds) return kWide;
+  if (sweep_lds_bytes(K, kBytes, level_cap, block_cap) <= max_lds) return kBytes;
+  if (m <= 4 && sweep_lds_bytes(K, kNibbles, level_cap, block_cap) <= max_lds) return kNibbles;
+  if (m == 1 && sweep_lds_bytes(K, kBits, level_cap, block_cap) <= max_lds) return kBits;
+  return -1;
 }
 
 size_t order_lds_bytes(uint32_t level_cap, uint32_t block_cap, uint32_t waves) {
@@ -1092,6 +1154,7 @@ struct ShuffledRun {
         }
       }
     }
+    const int wanted_m = m;
     const double mean_degree = std::max(1.0, static_cast<double>(L.a_col.size()) / static_cast<double>(K));
     // levels of a sweep: the longest descending-priority path, about 2.5 x the mean degree on
     // the clusters of this problem (measured: 29 at degree 8, 59-69 at degree 23); the last
@@ -1115,6 +1178,18 @@ struct ShuffledRun {
     level_cap = static_cast<uint32_t>(std::min<double>(static_cast<double>(K), 2.0 * levels_guess + 32.0));
     if (const char *env = std::getenv("ASP_SHUFFLED_LEVEL_CAP")) {  // test hook: provoke the retry
       level_cap = std::max(1u, static_cast<uint32_t>(std::strtoul(env, nullptr, 10)));
+    }
+    // Clusters beyond the capacity of a byte per spin: four bits per spin and at most four chains
+    // per workgroup, or a bit per spin and one chain (the largest order-2 models of the
+    // sampled-cluster pipeline: 1.5e5..3.2e5 spins)
+    while (m > 1 && shuffled_layout_for(K, m, level_cap, words + level_cap, p->max_lds) < 0) m >>= 1;
+    if (m != wanted_m) {
+      groups = (repetitions + m - 1) / m;
+      padded = static_cast<uint64_t>(groups) * m;
+    }
+    {
+      const int fits = shuffled_layout_for(K, m, level_cap, words + level_cap, p->max_lds);
+      if (fits == kNibbles || fits == kBits) teams = 1;  // (the packed layouts have one team)
     }
     quad_cap = 0;  // 0: derive from level_cap
     order_threads = K >= 4096 ? kOrderThreads : (K >= 512 ? 256u : 64u);
@@ -1148,7 +1223,7 @@ struct ShuffledRun {
 
   // ---- one attempt: plan (capacities -> kernels, buffers, argument templates), then launches ----
   uint32_t block_cap = 0, stream_kib = 0, chunk = 0;
-  bool wide = false;
+  int layout = kBytes;
   size_t lds = 0, order_lds = 0;
   ShuffledKernel kernel = nullptr;
   int nsets = 1, nlanes = 1;
@@ -1159,13 +1234,14 @@ struct ShuffledRun {
   int plan_sizes() {
     const uint32_t max_quads = p->rq_max_quads;
     block_cap = words + level_cap;
-    // a word per spin (the one-instruction sign) when that fits the LDS beside the sweep's tables
-    wide = m <= 4 && sweep_lds_bytes(K, true, level_cap, block_cap) <= p->max_lds;
-    lds = sweep_lds_bytes(K, wide, level_cap, block_cap);
-    if (lds > p->max_lds) {
-      return asp::set_error(ASP_ERR_TOO_LARGE, "the shuffled sweep keeps a byte per spin in LDS: %llu "
-                                               "spins do not fit", (unsigned long long)K);
+    // a word per spin (the one-instruction sign) when that fits the LDS beside the sweep's tables,
+    // else a byte, else four bits (m <= 4) or one (m = 1)
+    layout = shuffled_layout_for(K, m, level_cap, block_cap, p->max_lds);
+    if (layout < 0) {
+      return asp::set_error(ASP_ERR_TOO_LARGE, "the shuffled sweep keeps its spins in LDS: %llu spins with %d "
+                                               "chains per workgroup do not fit", (unsigned long long)K, m);
     }
+    lds = sweep_lds_bytes(K, layout, level_cap, block_cap);
     if (!quad_cap) {
       // exact class sort (rows below 63 quads): a block is no wider than every row of the block
       // before it in its level, so the blocks hold at most (sum of the row quads) / 64 + one
@@ -1226,7 +1302,7 @@ struct ShuffledRun {
     oa.quad_cap = quad_cap;
     oa.stream_kib = stream_kib;
     oa.lanes_per_row = lanes_per_row;
-    oa.col_shift = wide ? 2u : 0u;
+    oa.col_shift = layout == kWide ? 2u : 0u;
     oa.status = d_status.ptr;
     sa = ShuffledArgs{};
     sa.status = d_status.ptr;
@@ -1282,10 +1358,10 @@ struct ShuffledRun {
     if (trivial) return ASP_OK;
     hipStream_t s = p->stream;
     ASP_TRY(plan_sizes());
-    kernel = shuffled_kernel_for(m, wide, teams);
+    kernel = shuffled_kernel_for(m, layout, teams);
     if (!kernel) {  // (no two-team form of this width and layout)
       teams = 1;
-      kernel = shuffled_kernel_for(m, wide, 1);
+      kernel = shuffled_kernel_for(m, layout, 1);
     }
     if (lds > 64 * 1024) {
       ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
@@ -1412,8 +1488,8 @@ namespace {
 
 using ShuffledBatchKernel = void (*)(const ShuffledArgs *, const ShuffledSlot *);
 
-ShuffledBatchKernel shuffled_batch_kernel_for(int m, bool wide) {
-  if (wide) {
+ShuffledBatchKernel shuffled_batch_kernel_for(int m, int layout) {
+  if (layout == kWide) {
     switch (m) {
       case 1: return k_sa_sweep_shuffled_batch<1, kWide>;
       case 2: return k_sa_sweep_shuffled_batch<2, kWide>;
@@ -1421,6 +1497,15 @@ ShuffledBatchKernel shuffled_batch_kernel_for(int m, bool wide) {
       default: return nullptr;
     }
   }
+  if (layout == kNibbles) {
+    switch (m) {
+      case 1: return k_sa_sweep_shuffled_batch<1, kNibbles>;
+      case 2: return k_sa_sweep_shuffled_batch<2, kNibbles>;
+      case 4: return k_sa_sweep_shuffled_batch<4, kNibbles>;
+      default: return nullptr;
+    }
+  }
+  if (layout == kBits) return m == 1 ? k_sa_sweep_shuffled_batch<1, kBits> : nullptr;
   switch (m) {
     case 1: return k_sa_sweep_shuffled_batch<1, kBytes>;
     case 2: return k_sa_sweep_shuffled_batch<2, kBytes>;
@@ -1466,7 +1551,7 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
   for (auto &o : order_stream) ASP_TRY(o.acquire());
   // classes of workgroup shape: (layout, wavefronts)
   struct Class {
-    bool wide;
+    int layout;
     uint32_t waves;
     std::vector<uint32_t> members;
     DeviceBuffer<ShuffledSlot> slots;  // (before the stream: released after it has been waited for)
@@ -1502,12 +1587,12 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
       ShuffledRun *r = runs[i];
       Class *c = nullptr;
       for (auto &k : classes) {
-        if (k->wide == r->wide && k->waves == r->waves) c = k.get();
+        if (k->layout == r->layout && k->waves == r->waves) c = k.get();
       }
       if (!c) {
         classes.emplace_back(new Class());
         c = classes.back().get();
-        c->wide = r->wide;
+        c->layout = r->layout;
         c->waves = r->waves;
         ASP_TRY(c->stream.acquire());
         for (auto &e : c->swept) ASP_TRY(events.make(&e));
@@ -1525,7 +1610,7 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
       ASP_TRY(c->slots.alloc(slots.size()));
       ASP_TRY(c->slots.upload(slots.data(), slots.size(), c->stream.stream));
       ASP_HIP_TRY(hipStreamSynchronize(c->stream.stream));  // `slots` dies with this scope
-      ShuffledBatchKernel kernel = shuffled_batch_kernel_for(m, c->wide);
+      ShuffledBatchKernel kernel = shuffled_batch_kernel_for(m, c->layout);
       if (!kernel) return asp::set_error(ASP_ERR_INVALID, "no batched shuffled kernel for %d chains per group", m);
       if (c->lds > 64 * 1024) {
         ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
@@ -1570,7 +1655,7 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
       for (auto &c : classes) {
         hipStream_t cs = c->stream.stream;
         if (now) ASP_HIP_TRY(hipStreamWaitEvent(cs, ordered[which], 0));
-        ShuffledBatchKernel kernel = shuffled_batch_kernel_for(m, c->wide);
+        ShuffledBatchKernel kernel = shuffled_batch_kernel_for(m, c->layout);
         hipLaunchKernelGGL(kernel, dim3(c->num_slots), dim3(c->waves * 64), c->lds, cs,
                            d_sargs.ptr + static_cast<size_t>(turn) * P, c->slots.ptr);
         ASP_HIP_TRY(hipGetLastError());
@@ -1681,7 +1766,7 @@ extern "C" {
 
 int asp_sa_set_shuffled_launch(asp_sa_plan *p, int chains_per_group, int wavefronts) {
   if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
-  if (chains_per_group != 0 && !shuffled_kernel_for(chains_per_group, false)) {
+  if (chains_per_group != 0 && !shuffled_kernel_for(chains_per_group, kBytes)) {
     return asp::set_error(ASP_ERR_INVALID, "chains_per_group must be 0, 1, 2, 4 or 8");
   }
   if (wavefronts < 0 || wavefronts > 8) return asp::set_error(ASP_ERR_INVALID, "wavefronts must be 0..8");

@@ -236,3 +236,34 @@ def test_pipeline_from_yaml_and_hdf5_inputs(tmp_path, models):
     assert a.read_text() == b.read_text() == c.read_text()
     with pytest.raises(SystemExit):
         sampled_components.main(["--output", str(tmp_path / "none.csv")] + args)
+
+
+def test_fresh_process_grows_clusters_in_a_child_and_writes_the_same_file(tmp_path):
+    """A fresh process (no GPU call made yet) forks a child that grows the clusters while the
+    parent solves them (sampled_components.clusters_from_child): the same file as with the growth
+    kept in the parent (ASP_GROW_IN_PLACE=1), greedy with host threads and annealed in pipelined
+    rounds, also with the blocking wait policy (ASP_HIP_WAIT=block)."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    def run(name, extra_args, **env):
+        out = tmp_path / name
+        command = [sys.executable, "-m", "annealing_sign_problem_amd.sampled_components", "--model",
+                   "heisenberg_kagome_16", "--output", str(out), "--order", "1", "--number-samples", "24",
+                   "--seed", "91", "--noise", "0.2", "--max-cluster-size", "300"] + extra_args
+        done = subprocess.run(command, cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True,
+                              timeout=600)
+        assert done.returncode == 0, done.stderr[-2000:]
+        return out.read_text()
+
+    greedy = ["--no-annealing", "--jobs", "4"]
+    reference = run("in_place.csv", greedy, ASP_GROW_IN_PLACE="1")
+    assert len([l for l in reference.splitlines() if not l.startswith("#")]) == 24
+    assert run("child.csv", greedy) == reference
+    assert run("child_block.csv", greedy, ASP_HIP_WAIT="block") == reference
+    annealed = ["--annealing", "--jobs", "2", "--batch", "7"]  # four rounds, the next built while one anneals
+    reference = run("annealed_in_place.csv", annealed + ["--batch", "1"], ASP_GROW_IN_PLACE="1")
+    assert run("annealed_child.csv", annealed) == reference

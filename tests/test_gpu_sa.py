@@ -1094,6 +1094,49 @@ def test_shuffled_sweep_byte_layout_of_large_clusters():
     assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
 
 
+@pytest.mark.parametrize("k,forced,expect_m", [(170000, 4, 4), (170000, 0, 1), (300000, 4, 1)])
+def test_shuffled_sweep_beyond_a_byte_per_spin(k, forced, expect_m):
+    """Clusters that do not fit the LDS with a byte per spin — the largest order-2 models of the
+    sampled-cluster pipeline — keep four bits per spin (up to four chains per workgroup, 170 000
+    spins) or one bit (one chain, 300 000 spins); a request for more chains per workgroup than fit
+    is cut down.  Flips are LDS atomics there.  Chains as the oracle's."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    J, h, ham, info, betas = _shuffled_case(k, 6.0, 4)
+    lib = _lib.load()
+    _lib.check(lib.asp_sa_set_shuffled_launch(ham.plan(), forced, 0))
+    xs, es = sa.anneal_raw(ham, 4321, betas, 5, 2, None, shuffled=True)
+    got_m = ctypes.c_int(0)
+    _lib.check(lib.asp_sa_last_launch(ham.plan(), ctypes.byref(got_m), None, None))
+    assert got_m.value == expect_m
+    oxs, oes, _, _ = oracle.sa_anneal_shuffled(J, h, 4321, betas, 5, 2, None, info.energy_scale_exp,
+                                               num_threads=8)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+
+
+def test_shuffled_batch_with_a_cluster_beyond_a_byte_per_spin():
+    """A batch of shuffled items, one of them too large for a byte per spin: it shares the
+    launches in a class of its own layout (or runs by itself when its chains per workgroup had
+    to be cut); every item is its own single call."""
+    from annealing_sign_problem_amd import annealer as sa
+
+    cases = [_shuffled_case(k, d, 6, seed=k) for k, d in ((500, 5.0), (170000, 5.0), (2000, 8.0), (60000, 6.0))]
+    hams = [c[2] for c in cases]
+    batch = sa.anneal_batch_raw(hams, [3, 4, 5, 6], [c[4] for c in cases], [4, 4, 4, 4], shuffled=True)
+    for (J, h, ham, info, betas), seed, (bx, be) in zip(cases, (3, 4, 5, 6), batch):
+        sx, se = sa.anneal_raw(ham, seed, betas, 4, 0, None, shuffled=True)
+        assert np.array_equal(bx, sx) and be.tobytes() == se.tobytes()
+    J, h, ham, info, betas = cases[1]
+    ox, oe, _, _ = oracle.sa_anneal_shuffled(J, h, 4, betas, 4, 0, None, info.energy_scale_exp, num_threads=8)
+    assert np.array_equal(batch[1][0], ox) and batch[1][1].tobytes() == oe.tobytes()
+    # many chains: four per workgroup for the whole batch, four bits per spin for the large one
+    big = sa.anneal_batch_raw(hams[:2], [1, 2], [c[4] for c in cases[:2]], [600, 600], shuffled=True)
+    for (J, h, ham, info, betas), seed, (bx, be) in zip(cases[:2], (1, 2), big):
+        ox, oe, _, _ = oracle.sa_anneal_shuffled(J, h, seed, betas, 3, 597, None, info.energy_scale_exp, num_threads=8)
+        assert np.array_equal(bx[597:], ox) and be[597:].tobytes() == oe.tobytes()
+
+
 def test_shuffled_batch_equals_the_single_calls():
     """asp_sa_anneal_batch with ASP_SA_BATCH_SHUFFLED: every problem is its own
     asp_sa_anneal_shuffled call, chain for chain (and the oracle's), while their kernels overlap
