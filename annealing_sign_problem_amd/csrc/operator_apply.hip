@@ -19,6 +19,7 @@
 // J = (M + M^T)/2 needs no transpose pass.  Rows are sorted by column in LDS (rank by counting).
 // Compulsory HBM traffic: 16 B/state in, 16 B/non-zero out; integer/latency-bound, no MFMA.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -532,6 +533,106 @@ __global__ __launch_bounds__(kThreads) void k_symmetrise(SymmetryArgs g,
                               source_norms[lo]);
 }
 
+// k_source_norms + k_symmetrise for whole rows, through the LINEARITY of a bit permutation over
+// XOR: a target of row r is t = s ^ m with m the few bits its bond flips, so its image under group
+// element e is image_e(s) ^ image_e(m).  One wavefront per row: the images of the source state
+// under all elements once (lanes over the elements; LDS), which also gives the source's
+// stabiliser, i.e. its norm; then lanes over the row's targets, every element costing one LDS
+// broadcast read, two table bytes and an XOR instead of a number_spins-bit permutation.  The
+// elements are walked in the same order with the same comparisons as state_info, so the
+// representatives, characters and norms are the same bits.  (Measured on the 36-site kagome model,
+// 144 permutations x inversion: the two kernels it replaces were half of the device time of the
+// sampled-cluster pipeline, profiles/r03_pipeline_greedy_kernel_stats.csv.)
+// LDS: images u64[kWaves][P] | destination table, transposed, u8[number_spins][P].
+__global__ __launch_bounds__(kThreads) void k_symmetrise_rows(SymmetryArgs g,
+                                                             const uint64_t *__restrict__ keys,
+                                                             uint64_t num_rows,
+                                                             const int64_t *__restrict__ offsets,
+                                                             double *__restrict__ source_norms,
+                                                             uint64_t *__restrict__ other_keys,
+                                                             double *__restrict__ other_coeffs) {
+  extern __shared__ __align__(16) uint8_t symmetry_lds[];
+  const uint32_t P = g.num_permutations, ns = g.number_spins;
+  uint64_t *images = reinterpret_cast<uint64_t *>(symmetry_lds);
+  uint8_t *where = symmetry_lds + sizeof(uint64_t) * kWaves * P;  // where[i * P + e]: destination of site i
+  for (uint32_t idx = threadIdx.x; idx < ns * P; idx += kThreads) {
+    const uint32_t i = idx / P, e = idx - i * P;
+    where[idx] = g.table[static_cast<size_t>(e) * 64u + i];
+  }
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint64_t r = static_cast<uint64_t>(blockIdx.x) * kWaves + wave;
+  const bool row_ok = r < num_rows;
+  uint64_t *mine = images + static_cast<size_t>(wave) * P;
+  const uint64_t s = row_ok ? keys[r] : 0ull;  // (wavefront-uniform)
+  __syncthreads();
+  // ---- images of the source under every element; its stabiliser ----
+  int32_t stabiliser = 0;
+  if (row_ok) {
+    for (uint32_t e = lane; e < P; e += 64u) {
+      uint64_t y = 0;
+      for (uint64_t x = s; x != 0; x &= x - 1) {
+        y |= 1ull << where[static_cast<uint32_t>(__builtin_ctzll(x)) * P + e];
+      }
+      mine[e] = y;
+      stabiliser += y == s ? 1 : 0;
+      if (g.inversion != 0) stabiliser += (~y & g.mask) == s ? g.inversion : 0;
+    }
+  }
+  for (int step = 1; step < 64; step <<= 1) stabiliser += __shfl_xor(stabiliser, step, 64);
+  __syncthreads();  // (the images were written by other lanes of this wavefront)
+  if (!row_ok) return;
+  const double order = static_cast<double>(P) * (g.inversion != 0 ? 2.0 : 1.0);
+  // the same expression as state_info / the numpy reference: sqrt(max(stabiliser, 0) / |G|)
+  const double source_norm = sqrt(static_cast<double>(stabiliser > 0 ? stabiliser : 0) / order);
+  if (lane == 0) source_norms[r] = source_norm;
+  // ---- the row's targets, 64 at a time ----
+  const int64_t begin = offsets[r], end = offsets[r + 1];
+  for (int64_t base = begin; base < end; base += 64) {
+    const int64_t at = base + lane;
+    const bool on = at < end;
+    const uint64_t t = on ? other_keys[at] : s;
+    const uint64_t m = t ^ s;
+    const int flipped = __popcll(m);
+    // the usual case, at most two flipped bits: their sites once, outside the walk over the group
+    const uint32_t i0 = flipped ? static_cast<uint32_t>(__builtin_ctzll(m)) * P : 0u;
+    const uint32_t i1 = flipped ? static_cast<uint32_t>(63 - __builtin_clzll(m)) * P : 0u;
+    uint64_t best = t;  // the identity is element 0
+    int32_t fixed = 0;
+    bool through_flip = false;
+    for (uint32_t e = 0; e < P; ++e) {
+      uint64_t image_m = 0;
+      if (flipped > 2) {
+        for (uint64_t x = m; x != 0; x &= x - 1) {
+          image_m |= 1ull << where[static_cast<uint32_t>(__builtin_ctzll(x)) * P + e];
+        }
+      } else if (flipped != 0) {
+        image_m = (1ull << where[i0 + e]) | (1ull << where[i1 + e]);
+      }
+      const uint64_t y = mine[e] ^ image_m;
+      fixed += y == t ? 1 : 0;
+      if (y < best) {
+        best = y;
+        through_flip = false;
+      }
+      if (g.inversion != 0) {
+        const uint64_t z = ~y & g.mask;
+        fixed += z == t ? g.inversion : 0;
+        if (z < best) {
+          best = z;
+          through_flip = true;
+        }
+      }
+    }
+    if (on) {
+      const double character = (through_flip && g.inversion < 0) ? -1.0 : 1.0;
+      const double norm = sqrt(static_cast<double>(fixed > 0 ? fixed : 0) / order);
+      other_keys[at] = best;
+      // numpy: values * character * norm / source_norm, left to right (as k_symmetrise)
+      other_coeffs[at] = __ddiv_rn(__dmul_rn(__dmul_rn(other_coeffs[at], character), norm), source_norm);
+    }
+  }
+}
+
 thread_local float g_last_ms = 0.0f;
 
 struct Timer {
@@ -601,10 +702,25 @@ int symmetrise_batch(const asp_operator *op, uint64_t n, const ApplyBatch &w, ui
   if (op->num_permutations == 0 || n == 0) return ASP_OK;
   ASP_TRY(d_norms->alloc(n));
   const SymmetryArgs g = op->symmetry();
-  hipLaunchKernelGGL(k_source_norms, dim3(grid_for(n, kThreads)), dim3(kThreads), 0, stream, g,
-                     w.d_keys.ptr, n, d_norms->ptr);
-  hipLaunchKernelGGL(k_symmetrise, dim3(grid_for(w.total, kThreads)), dim3(kThreads), 0, stream, g,
-                     w.d_offsets.ptr, n, d_norms->ptr, w.total, d_other, d_coeffs);
+  // a wavefront per row (k_symmetrise_rows) when the group's tables fit the LDS; the entry-wise
+  // kernels otherwise (ASP_SYMMETRISE_ROWS=0: always; tests compare the two)
+  const size_t lds = sizeof(uint64_t) * kWaves * static_cast<size_t>(g.num_permutations) +
+                     static_cast<size_t>(g.number_spins) * g.num_permutations;
+  bool by_rows = lds <= 160u * 1024u;
+  if (const char *env = std::getenv("ASP_SYMMETRISE_ROWS")) by_rows = by_rows && std::atoi(env) != 0;
+  if (by_rows) {
+    if (lds > 64u * 1024u) {
+      ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_symmetrise_rows),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    }
+    hipLaunchKernelGGL(k_symmetrise_rows, dim3(grid_for(n, kWaves)), dim3(kThreads), lds, stream, g,
+                       w.d_keys.ptr, n, w.d_offsets.ptr, d_norms->ptr, d_other, d_coeffs);
+  } else {
+    hipLaunchKernelGGL(k_source_norms, dim3(grid_for(n, kThreads)), dim3(kThreads), 0, stream, g,
+                       w.d_keys.ptr, n, d_norms->ptr);
+    hipLaunchKernelGGL(k_symmetrise, dim3(grid_for(w.total, kThreads)), dim3(kThreads), 0, stream, g,
+                       w.d_offsets.ptr, n, d_norms->ptr, w.total, d_other, d_coeffs);
+  }
   ASP_HIP_TRY(hipGetLastError());
   return ASP_OK;
 }

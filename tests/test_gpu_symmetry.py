@@ -101,3 +101,33 @@ def test_kagome_18_full_sector_energy_identity_and_chains(models):
     oxs, oes, _, _ = oracle.sa_anneal(h.exchange, h.field, 435834, betas, 8, 0, None,
                                       info.energy_scale_exp, num_threads=8)
     assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+
+
+@pytest.mark.parametrize("name", ["heisenberg_kagome_36", "heisenberg_pyrochlore_2x2x2"])
+def test_row_wise_symmetric_action_equals_the_entry_wise_kernels(models, name, monkeypatch):
+    """k_symmetrise_rows (a wavefront per row: the images of the source state once, an XOR per
+    target and group element) against k_source_norms + k_symmetrise (a full bit permutation per
+    target and element), on the two production models (144 and 384 permutations, with inversion):
+    same representatives, same coefficients, same extension, bit for bit; rows of every length
+    incl. single states."""
+    import time
+
+    from annealing_sign_problem_amd import operators
+
+    op = operators.Operator.from_config(models[name])
+    dev = op.device()
+    keys = _random_representatives(op, 6000, 3)
+    results = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ASP_SYMMETRISE_ROWS", mode)
+        dev.apply(keys[:64])  # warm-up
+        t0 = time.perf_counter()
+        results[mode] = dev.apply(keys)
+        seconds = time.perf_counter() - t0
+        print("%s ASP_SYMMETRISE_ROWS=%s: apply(%d states, %d connections) %.1f ms (device %.2f ms)" % (
+            name, mode, keys.shape[0], results[mode][0].shape[0], seconds * 1e3, dev.last_ms))
+        results[mode] += (dev.extend(keys), dev.apply(keys[:1]), dev.apply(keys[17:20]))
+    for a, b in zip(results["1"][:4], results["0"][:4]):
+        assert a.dtype == b.dtype and a.tobytes() == b.tobytes()
+    for a, b in zip(results["1"][4] + results["1"][5], results["0"][4] + results["0"][5]):
+        assert a.tobytes() == b.tobytes()
