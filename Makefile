@@ -56,7 +56,7 @@ sk_32_1: LARGE = sk_32_1
 # RANKS > 1: that many processes (clusters c mod RANKS, rank 0 writes the CSV; identical output):
 # for a node with RANKS GPUs — drop the two environment variables and every rank binds its own
 # GPU (RCCL).  On ONE GPU one process with JOBS threads is as fast (4096 clusters of kagome_36 in
-# 38 s); as written the ranks share device 0 over gloo, a rehearsal.
+# 27 s); as written the ranks share device 0 over gloo, a rehearsal.
 RANKS ?= 1
 ifeq ($(RANKS),1)
   LAUNCH = $(PYTHON) -m
