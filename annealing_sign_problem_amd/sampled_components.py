@@ -312,7 +312,7 @@ def parse_command_line(argv=None):
     parser.add_argument("--sampled-power", type=float, default=0.1)
     parser.add_argument("--keep-probability", type=float, default=0.5)
     parser.add_argument("--seed", type=int, default=12345)
-    parser.add_argument("--batch", type=int, default=128,
+    parser.add_argument("--batch", type=int, default=256,
                         help="clusters whose annealing chains share one batched device call "
                              "(asp_sa_anneal_batch); 1 = one call per model, as the reference's "
                              "loop.  The output does not depend on it")
