@@ -8,25 +8,33 @@
 //   slots   u64[2^s]        open-addressing hash of table0: {fingerprint:32 | index+1:32}
 //   needles ls_bits512[N]   flat, row-major by row
 //   counts i64[K], psi f64[K], coeffs f64[N], other_psi f64[N], other_counts i64[K]
-//   offsets i64[K+1] (scan of other_counts), found i32[N] (table index or -1),
-//   row_hits u32[K], row_start i64[K+1] (scan of row_hits)
+//   offsets i64[K+1] (prefix sums of other_counts, formed on the host while the upload checks
+//   them), found i32[N] (table index or -1), row_hits u32[K],
+//   block_total u32[row blocks], tile_total u64[2][row blocks / 64] (hits of 64 row blocks)
 //   out: row u32[N], col u32[N], elements f64[N], field f64[K]
 //
-// Launch sequence of one build (one stream, no host round trip except nnz):
-//   k_split_word0   table -> table0, and a flag "some table key has a non-zero word 1..7"
-//   k_hash_insert   table0 -> slots (load factor <= 1/2, linear probing, atomicCAS)
-//   scan            other_counts -> offsets
+// One build = THREE launches on one stream, no host round trip except nnz (round 2: twelve —
+// two memsets, two three-kernel scans, four kernels):
+//   k_insert_keys   table -> table0 (words[0]), a flag "some table key has a non-zero word
+//                   1..7", and table0 -> slots (load factor <= 1/2, linear probing, atomicCAS)
 //   k_search_rows   32 lanes per row: each lane resolves one connection through the hash
 //                   (the reference bsearches, cbits/build_matrix.c:37-38; on a unique table
-//                   any exact lookup returns the same element), row hit count by ballot
-//   scan            row_hits -> row_start
-//   k_emit_rows     32 lanes per row: COO triples in input order at ballot-prefix positions
-//                   (coalesced), and the row's field as a LEFT-TO-RIGHT sum over its misses
-//                   (the reference's rounding, cbits/build_matrix.c:49)
+//                   any exact lookup returns the same element), row hit count by ballot; the
+//                   block's total goes to block_total and, atomically, to its tile's total
+//   k_emit_rows     first the block's output position WITHOUT a scan kernel: the totals of the
+//                   tiles before its own (<= K / 512 numbers) plus the totals of the blocks
+//                   before it inside its tile (<= 63) — integer sums, so the order does not
+//                   matter; then 32 lanes per row: COO triples in input order at ballot-prefix
+//                   positions (coalesced), and the row's field as a LEFT-TO-RIGHT sum over its
+//                   misses (the reference's rounding, cbits/build_matrix.c:49); last, every block
+//                   zeroes its share of the hash slots and block 0 the flag and the OTHER parity's
+//                   tile totals: the next run finds them clean (the slots are zeroed at creation)
 //
 // Arithmetic: __dmul_rn / __dadd_rn keep every product and the field add
 // separately rounded (no FMA contraction), matching the reference binary.
 // Memory-bound integer/f64 streaming: no MFMA, no LDS tiling of the payload.
+#include <vector>
+
 #include "asp_common.hpp"
 
 namespace {
@@ -46,10 +54,12 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
   return x;
 }
 
-__global__ __launch_bounds__(kThreads) void k_split_word0(const ls_bits512 *__restrict__ table,
+__global__ __launch_bounds__(kThreads) void k_insert_keys(const ls_bits512 *__restrict__ table,
                                                          uint64_t n,
                                                          uint64_t *__restrict__ table0,
-                                                         uint32_t *__restrict__ tail_flag) {
+                                                         uint32_t *__restrict__ tail_flag,
+                                                         unsigned long long *__restrict__ slots,
+                                                         uint64_t mask) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x;
   if (i >= n) return;
   const ls_bits512 key = table[i];
@@ -58,15 +68,7 @@ __global__ __launch_bounds__(kThreads) void k_split_word0(const ls_bits512 *__re
 #pragma unroll
   for (int w = 1; w < 8; ++w) tail |= key.words[w];
   if (tail != 0) atomicOr(tail_flag, 1u);
-}
-
-__global__ __launch_bounds__(kThreads) void k_hash_insert(const uint64_t *__restrict__ table0,
-                                                         uint64_t n,
-                                                         unsigned long long *__restrict__ slots,
-                                                         uint64_t mask) {
-  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t h = mix64(table0[i]);
+  const uint64_t h = mix64(key.words[0]);
   const unsigned long long entry = (h & 0xFFFFFFFF00000000ull) | (i + 1);
   uint64_t at = h & mask;
   while (atomicCAS(&slots[at], 0ull, entry) != 0ull) at = (at + 1) & mask;
@@ -114,7 +116,8 @@ __global__ __launch_bounds__(kThreads) void k_search_rows(
     const uint64_t *__restrict__ table0, const ls_bits512 *__restrict__ table,
     const uint32_t *__restrict__ tail_flag, uint64_t num_spins,
     const ls_bits512 *__restrict__ needles, const int64_t *__restrict__ offsets,
-    int32_t *__restrict__ found, uint32_t *__restrict__ row_hits) {
+    int32_t *__restrict__ found, uint32_t *__restrict__ row_hits,
+    uint32_t *__restrict__ block_total, unsigned long long *__restrict__ tile_total) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t sub = threadIdx.x & (kRowLanes - 1);
   const uint64_t r = static_cast<uint64_t>(blockIdx.x) * kRowsPerBlock + threadIdx.x / kRowLanes;
@@ -161,10 +164,34 @@ __global__ __launch_bounds__(kThreads) void k_search_rows(
     __builtin_amdgcn_wave_barrier();  // the next trip overwrites the staging area
   }
   if (row_ok && sub == 0) row_hits[r] = hits;
+  // hits of the block's rows: to the block's total and to the total of its tile of 64 blocks
+  __shared__ uint32_t hits_of_row[kRowsPerBlock];
+  if (sub == 0) hits_of_row[threadIdx.x / kRowLanes] = row_ok ? hits : 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < kRowsPerBlock; ++k) total += hits_of_row[k];
+    block_total[blockIdx.x] = total;
+    if (total) atomicAdd(&tile_total[blockIdx.x >> 6], static_cast<unsigned long long>(total));
+  }
 }
 
+struct EmitTotals {
+  const uint32_t *row_hits;                // [K]
+  const uint32_t *block_total;             // [row blocks]
+  const unsigned long long *tile_total;    // [tiles] of this run
+  unsigned long long *nnz;                 // the build's number of couplings
+  // left clean for the next run:
+  unsigned long long *slots;
+  uint64_t slot_count;
+  uint32_t *tail_flag;
+  unsigned long long *next_tile_total;     // the other parity's tiles
+  uint32_t num_tiles;
+};
+
 __global__ __launch_bounds__(kThreads) void k_emit_rows(
-    const int64_t *__restrict__ offsets, const int64_t *__restrict__ row_start,
+    const int64_t *__restrict__ offsets, EmitTotals totals,
     const int32_t *__restrict__ found, const int64_t *__restrict__ counts,
     const double *__restrict__ psi, const double *__restrict__ coeffs,
     const double *__restrict__ other_psi, uint64_t num_spins, uint32_t *__restrict__ out_row,
@@ -173,13 +200,35 @@ __global__ __launch_bounds__(kThreads) void k_emit_rows(
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t sub = threadIdx.x & (kRowLanes - 1);
   const uint32_t half_base = lane & 32u;
-  const uint64_t r = static_cast<uint64_t>(blockIdx.x) * kRowsPerBlock + threadIdx.x / kRowLanes;
+  const uint32_t row_in_block = threadIdx.x / kRowLanes;
+  const uint64_t r = static_cast<uint64_t>(blockIdx.x) * kRowsPerBlock + row_in_block;
   const bool row_ok = r < num_spins;
+  // ---- where this block's couplings start: tiles before its tile + blocks before it in the tile
+  __shared__ unsigned long long block_base;
+  __shared__ uint32_t hits_of_row[kRowsPerBlock];
+  if (threadIdx.x == 0) block_base = 0ull;
+  if (sub == 0) hits_of_row[row_in_block] = row_ok ? totals.row_hits[r] : 0u;
+  __syncthreads();
+  {
+    const uint32_t tile = blockIdx.x >> 6, first_of_tile = blockIdx.x & ~63u;
+    unsigned long long mine = 0;
+    for (uint32_t t = threadIdx.x; t < tile; t += kThreads) mine += totals.tile_total[t];
+    if (threadIdx.x < blockIdx.x - first_of_tile) mine += totals.block_total[first_of_tile + threadIdx.x];
+    for (int step = 1; step < 64; step <<= 1) mine += __shfl_xor(mine, step, 64);
+    if (lane == 0 && mine) atomicAdd(&block_base, mine);
+  }
+  __syncthreads();
+  int64_t w = static_cast<int64_t>(block_base);
+  for (uint32_t k = 0; k < row_in_block; ++k) w += hits_of_row[k];
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    unsigned long long all = block_base;
+    for (int k = 0; k < kRowsPerBlock; ++k) all += hits_of_row[k];
+    *totals.nnz = all;
+  }
   const int64_t begin = row_ok ? offsets[r] : 0;
   const int64_t end = row_ok ? offsets[r + 1] : 0;
   const double c = row_ok ? static_cast<double>(counts[r]) : 0.0;  // exact i64 -> f64 as in C
   const double a = row_ok ? fabs(psi[r]) : 0.0;
-  int64_t w = row_ok ? row_start[r] : 0;
   double f = 0.0;
   const int64_t other_len = __shfl_xor(end - begin, 32, 64);
   const int64_t trips = ((end - begin > other_len ? end - begin : other_len) + kRowLanes - 1) / kRowLanes;
@@ -215,6 +264,17 @@ __global__ __launch_bounds__(kThreads) void k_emit_rows(
     }
   }
   if (row_ok && sub == 0) out_field[r] = f;
+  // ---- leave the tables clean for the next run (nobody reads the slots or the flag any more) ----
+  {
+    const uint64_t share = (totals.slot_count + gridDim.x - 1) / gridDim.x;
+    const uint64_t first = static_cast<uint64_t>(blockIdx.x) * share;
+    const uint64_t last = first + share < totals.slot_count ? first + share : totals.slot_count;
+    for (uint64_t k = first + threadIdx.x; k < last; k += kThreads) totals.slots[k] = 0ull;
+    if (blockIdx.x == 0) {
+      if (threadIdx.x == 0) *totals.tail_flag = 0u;
+      for (uint32_t t = threadIdx.x; t < totals.num_tiles; t += kThreads) totals.next_tile_total[t] = 0ull;
+    }
+  }
 }
 
 // extract_signs: one wavefront builds one 64-bit word with a ballot.
@@ -247,10 +307,14 @@ struct asp_build {
   DeviceBuffer<unsigned long long> slots;
   DeviceBuffer<uint32_t> tail_flag;
   uint64_t slot_mask = 0;
-  DeviceBuffer<int64_t> counts, other_counts, offsets, row_start, scratch;
+  DeviceBuffer<int64_t> counts, offsets;
   DeviceBuffer<double> psi, coeffs, other_psi, elements, field;
   DeviceBuffer<int32_t> found;
-  DeviceBuffer<uint32_t> row_hits, out_row, out_col;
+  DeviceBuffer<uint32_t> row_hits, block_total, out_row, out_col;
+  DeviceBuffer<unsigned long long> tile_total, nnz;  // tile_total: [2][num_tiles], one parity per run
+  uint32_t num_tiles = 0;
+  uint32_t parity = 0;
+  bool clean = false;  // slots, flag and this parity's tile totals are zero (k_emit_rows leaves them so)
 };
 
 extern "C" {
@@ -276,17 +340,18 @@ asp_build *asp_build_create(uint64_t num_spins, uint64_t num_other) {
   uint64_t slot_count = 64;
   while (slot_count < 2 * K) slot_count <<= 1;  // load factor <= 1/2
   b->slot_mask = slot_count - 1;
-  const size_t scratch = asp::scan_scratch_elems(K > N ? K : N);
+  const uint64_t row_blocks = row_blocks_for(K);
+  b->num_tiles = static_cast<uint32_t>((row_blocks + 63) / 64);
   ok = ok && b->table.alloc(K) == ASP_OK && b->needles.alloc(N) == ASP_OK &&
        b->table0.alloc(K) == ASP_OK && b->slots.alloc(b->slot_mask + 1) == ASP_OK &&
        b->tail_flag.alloc(1) == ASP_OK && b->counts.alloc(K) == ASP_OK &&
-       b->other_counts.alloc(K) == ASP_OK && b->offsets.alloc(K + 1) == ASP_OK &&
-       b->row_start.alloc(K + 1) == ASP_OK && b->scratch.alloc(scratch) == ASP_OK &&
+       b->offsets.alloc(K + 1) == ASP_OK &&
        b->psi.alloc(K) == ASP_OK && b->coeffs.alloc(N) == ASP_OK &&
        b->other_psi.alloc(N) == ASP_OK && b->elements.alloc(N) == ASP_OK &&
        b->field.alloc(K) == ASP_OK && b->found.alloc(N) == ASP_OK &&
-       b->row_hits.alloc(K) == ASP_OK && b->out_row.alloc(N) == ASP_OK &&
-       b->out_col.alloc(N) == ASP_OK;
+       b->row_hits.alloc(K) == ASP_OK && b->block_total.alloc(row_blocks) == ASP_OK &&
+       b->tile_total.alloc(2ull * b->num_tiles) == ASP_OK && b->nnz.alloc(1) == ASP_OK &&
+       b->out_row.alloc(N) == ASP_OK && b->out_col.alloc(N) == ASP_OK;
   if (!ok) {
     asp_build_destroy(b);
     return nullptr;
@@ -330,12 +395,16 @@ int asp_build_upload(asp_build *b, ls_bits512 const *spins, int64_t const *count
     return asp::set_error(ASP_ERR_INVALID, "sum(other_counts) = %llu but num_other = %llu",
                           (unsigned long long)total, (unsigned long long)N);
   }
+  // offsets of the rows in the flat arrays: the prefix sums of the counts just walked
+  std::vector<int64_t> offsets(K + 1);
+  offsets[0] = 0;
+  for (uint64_t r = 0; r < K; ++r) offsets[r + 1] = offsets[r] + other_counts[r];
   ASP_TRY(b->table.upload(spins, K, b->stream));
   ASP_TRY(b->counts.upload(counts, K, b->stream));
   ASP_TRY(b->psi.upload(psi, K, b->stream));
   ASP_TRY(b->needles.upload(other_spins, N, b->stream));
   ASP_TRY(b->coeffs.upload(other_coeffs, N, b->stream));
-  ASP_TRY(b->other_counts.upload(other_counts, K, b->stream));
+  ASP_TRY(b->offsets.upload(offsets.data(), K + 1, b->stream));
   ASP_TRY(b->other_psi.upload(other_psi, N, b->stream));
   ASP_HIP_TRY(hipStreamSynchronize(b->stream));
   b->uploaded = true;
@@ -348,34 +417,39 @@ int asp_build_run(asp_build *b, uint64_t *nnz) {
   ASP_TRY(asp::bind_device());
   const uint64_t K = b->num_spins;
   hipStream_t s = b->stream;
-  ASP_HIP_TRY(hipEventRecord(b->ev_start, s));
-  ASP_HIP_TRY(hipMemsetAsync(b->slots.ptr, 0, (b->slot_mask + 1) * sizeof(unsigned long long), s));
-  ASP_HIP_TRY(hipMemsetAsync(b->tail_flag.ptr, 0, sizeof(uint32_t), s));
-  if (K > 0) {
-    hipLaunchKernelGGL(k_split_word0, dim3(blocks_for(K)), dim3(kThreads), 0, s, b->table.ptr, K,
-                       b->table0.ptr, b->tail_flag.ptr);
-    hipLaunchKernelGGL(k_hash_insert, dim3(blocks_for(K)), dim3(kThreads), 0, s, b->table0.ptr, K,
-                       b->slots.ptr, b->slot_mask);
+  if (!b->clean) {
+    // first run of the handle, or the one before it failed half-way: k_emit_rows leaves these zero
+    ASP_HIP_TRY(hipMemsetAsync(b->slots.ptr, 0, (b->slot_mask + 1) * sizeof(unsigned long long), s));
+    ASP_HIP_TRY(hipMemsetAsync(b->tail_flag.ptr, 0, sizeof(uint32_t), s));
+    ASP_HIP_TRY(hipMemsetAsync(b->tile_total.ptr, 0, 2ull * b->num_tiles * sizeof(unsigned long long), s));
   }
-  ASP_TRY(asp::exclusive_scan_i64(b->other_counts.ptr, K, b->offsets.ptr, b->scratch.ptr, s));
+  b->clean = false;
+  ASP_HIP_TRY(hipEventRecord(b->ev_start, s));
   if (K > 0) {
+    unsigned long long *tiles = b->tile_total.ptr + static_cast<size_t>(b->parity) * b->num_tiles;
+    unsigned long long *other_tiles = b->tile_total.ptr + static_cast<size_t>(b->parity ^ 1u) * b->num_tiles;
+    hipLaunchKernelGGL(k_insert_keys, dim3(blocks_for(K)), dim3(kThreads), 0, s, b->table.ptr, K,
+                       b->table0.ptr, b->tail_flag.ptr, b->slots.ptr, b->slot_mask);
     hipLaunchKernelGGL(k_search_rows, dim3(row_blocks_for(K)), dim3(kThreads), 0, s, b->slots.ptr,
                        b->slot_mask, b->table0.ptr, b->table.ptr, b->tail_flag.ptr, K,
-                       b->needles.ptr, b->offsets.ptr, b->found.ptr, b->row_hits.ptr);
-  }
-  ASP_TRY(asp::exclusive_scan_u32(b->row_hits.ptr, K, b->row_start.ptr, b->scratch.ptr, s));
-  if (K > 0) {
+                       b->needles.ptr, b->offsets.ptr, b->found.ptr, b->row_hits.ptr,
+                       b->block_total.ptr, tiles);
+    EmitTotals totals{b->row_hits.ptr, b->block_total.ptr, tiles, b->nnz.ptr, b->slots.ptr,
+                      b->slot_mask + 1, b->tail_flag.ptr, other_tiles, b->num_tiles};
     hipLaunchKernelGGL(k_emit_rows, dim3(row_blocks_for(K)), dim3(kThreads), 0, s, b->offsets.ptr,
-                       b->row_start.ptr, b->found.ptr, b->counts.ptr, b->psi.ptr, b->coeffs.ptr,
+                       totals, b->found.ptr, b->counts.ptr, b->psi.ptr, b->coeffs.ptr,
                        b->other_psi.ptr, K, b->out_row.ptr, b->out_col.ptr, b->elements.ptr,
                        b->field.ptr);
   }
   ASP_HIP_TRY(hipGetLastError());
   ASP_HIP_TRY(hipEventRecord(b->ev_stop, s));
-  int64_t total = 0;
-  ASP_HIP_TRY(hipMemcpyAsync(&total, b->row_start.ptr + K, sizeof total, hipMemcpyDeviceToHost, s));
+  unsigned long long total = 0;  // (K = 0: no kernel ran)
+  if (K > 0) ASP_HIP_TRY(hipMemcpyAsync(&total, b->nnz.ptr, sizeof total, hipMemcpyDeviceToHost, s));
   ASP_HIP_TRY(hipStreamSynchronize(s));
   ASP_HIP_TRY(hipEventElapsedTime(&b->last_ms, b->ev_start, b->ev_stop));
+  // this run's tile totals were read by its last kernel; the other parity's are zero again
+  b->parity ^= 1u;
+  b->clean = K > 0;
   b->last_nnz = static_cast<uint64_t>(total);
   if (nnz) *nnz = b->last_nnz;
   return ASP_OK;

@@ -80,6 +80,54 @@ def test_build_matrix_matches_oracle_random(seed, n, mean, multi, miss):
     _same(g_field, field)
 
 
+def test_build_handle_is_reusable_run_after_run():
+    """The device-resident form (asp_build_create / upload / run / download: what bench.py times):
+    one build is three launches and leaves its hash slots, flag and tile totals clean for the next
+    one — three runs on one upload, then other data of the same shape through the same handle,
+    are each the oracle's result (sizes that span several tiles of row blocks)."""
+    import ctypes
+
+    from annealing_sign_problem_amd import _build_matrix, _lib
+
+    from helpers import random_build_case
+
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    first = random_build_case(rng, 5000, 9.0, False, 0.4, True)
+    k, n = first["spins"].shape[0], first["other_spins"].shape[0]
+    # the same shape with other keys, amplitudes and hit pattern (same counts per row)
+    second = dict(first)
+    second["psi"] = rng.normal(size=k)
+    second["other_psi"] = rng.normal(size=n)
+    second["other_coeffs"] = rng.normal(size=n)
+    second["other_spins"] = first["other_spins"][::-1].copy()
+    handle = lib.asp_build_create(ctypes.c_uint64(k), ctypes.c_uint64(n))
+    assert handle
+    try:
+        for case, runs in ((first, 3), (second, 2), (first, 1)):
+            arrays = [np.ascontiguousarray(case[key]) for key in INPUTS]
+            spins512 = _build_matrix.as_bits512(arrays[0])
+            others512 = _build_matrix.as_bits512(arrays[3])
+            _lib.check(lib.asp_build_upload(handle, _lib.ptr(spins512), _lib.ptr(arrays[1]), _lib.ptr(arrays[2]),
+                                            _lib.ptr(others512), _lib.ptr(arrays[4]), _lib.ptr(arrays[5]),
+                                            _lib.ptr(arrays[6])))
+            want_nnz, row, col, elements, field = oracle.build_matrix(*arrays)
+            for _ in range(runs):
+                nnz = ctypes.c_uint64(0)
+                _lib.check(lib.asp_build_run(handle, ctypes.byref(nnz)))
+                assert nnz.value == want_nnz
+                g_row, g_col = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+                g_el, g_field = np.zeros(n), np.zeros(k)
+                _lib.check(lib.asp_build_download(handle, _lib.ptr(g_row), _lib.ptr(g_col), _lib.ptr(g_el),
+                                                  _lib.ptr(g_field)))
+                _same(g_row[:want_nnz], row)
+                _same(g_col[:want_nnz], col)
+                _same(g_el[:want_nnz], elements)
+                _same(g_field, field)
+    finally:
+        lib.asp_build_destroy(handle)
+
+
 def test_build_matrix_empty():
     from annealing_sign_problem_amd import _build_matrix
 
