@@ -467,8 +467,6 @@ def _worker_chunk(indices):
         w["log_coeff_fn"] = common.ground_state_to_log_coeff_fn(w["noisy_ground_state"], w["hamiltonian"].basis)
     args = w["args"]
     if os.environ.get("ASP_WORKER_TIMING"):  # development aid
-        import atexit  # noqa: F401
-
         def report(lines, t0=started, first=indices[0]):
             sys.stderr.write("worker %d: clusters %d..%d in %.2f s\n" % (
                 os.getpid(), first, indices[-1], time.perf_counter() - t0))
