@@ -595,8 +595,12 @@ def main(argv=None):
         clusters = asp_dist.broadcast_object(clusters)
         phase("clusters grown")
     else:
-        # one process: a forked child grows the clusters while this one solves them
+        # one process: a forked child grows the clusters while this one solves them.  The first
+        # cluster is pulled here, so that the fork happens in this thread, before any other exists
+        import itertools
+
         clusters = clusters_from_child(hamiltonian, ground_state, args)
+        clusters = itertools.chain(list(itertools.islice(clusters, 1)), clusters)
     if args.jobs > 1:
         # several plans are built at once: one host thread each (csrc/sa_plan.cpp starts four for
         # a large model, which pays for one model at a time only)
