@@ -428,7 +428,7 @@ def bench_batched_clusters(num_problems=128, serial_every=8):
 
 
 def bench_real_kagome_36(replicas, sweeps, targets=(10_000, 30_000, 100_000), seeds=24, calls=5,
-                         warmup=2):
+                         warmup=2, pipeline=True):
     """The headline step on REAL clusters of the 36-site kagome model, not planted ones: the
     ground state of heisenberg_kagome_36.yaml's symmetry sector is computed here (31.5 M
     representatives; enumeration, resident Hamiltonian and Lanczos on this GPU, sector_ed.py —
@@ -490,6 +490,8 @@ def bench_real_kagome_36(replicas, sweeps, targets=(10_000, 30_000, 100_000), se
                        "call_ms": [round(c[0] * 1e3, 2) for c in timed],
                        "sweep_kernel_ms": [round(c[1], 2) for c in timed]})
     return {
+        # (not under the profiler's counter passes: its descent sweeps are k_sa_sweep launches too)
+        "pipeline": bench_pipeline(op, psi, log_psi) if pipeline else None,
         "workload": "real heisenberg_kagome_36 clusters (order-2 extension, cutoff 1e-6) closest to "
                     "K = %s, %d chains x %d sweeps per call (median of %d calls each)" % (
                         "/".join(str(t) for t in targets), replicas, sweeps, calls),
@@ -506,6 +508,57 @@ def bench_real_kagome_36(replicas, sweeps, targets=(10_000, 30_000, 100_000), se
         "cluster_build_s": build_s,
         "clusters_built": len(models),
         "sizes_built": sorted(int(m.size) for m in models),
+    }
+
+
+def bench_pipeline(op, psi, log_psi, greedy_clusters=128, annealed_clusters=32, threads=16):
+    """`make kagome_36`'s per-cluster pipeline on the real model (the caller's operator and ground
+    state): clusters of 50-1000 seed states, orders 0-2, cutoff 1e-6 — coupling build, extension,
+    cutoff, plan, greedy solver and metrics per order — with host threads, then the same with every
+    model annealed (64 chains x 5120 sweeps, the reference's defaults) in one batched call."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from annealing_sign_problem_amd import sampled_components
+
+    os.environ.setdefault("ASP_HOST_THREADS", "1")  # (as sampled_components.main does with --jobs > 1)
+    state = np.random.get_state()
+    np.random.seed(435834)
+    try:
+        t0 = time.perf_counter()
+        clusters = sampled_components.generate_clusters(op, psi, greedy_clusters, 0.1, 50, 1000, 0.5)
+        growth_s = time.perf_counter() - t0
+    finally:
+        np.random.set_state(state)
+
+    def work(cluster):
+        return sampled_components.process_cluster(cluster, op, psi, psi, log_psi, 2, 1e-6, False)
+
+    work(clusters[0])  # warm-up
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        results = list(pool.map(work, clusters))
+    greedy_s = time.perf_counter() - t0
+    some = clusters[:annealed_clusters]
+    t0 = time.perf_counter()
+    staged = sampled_components.stage_clusters(some, op, psi, psi, log_psi, 2, 1e-6, threads)
+    staged_s = time.perf_counter() - t0
+    spins = sum(m.size for _, m, _, _, _ in staged)
+    t0 = time.perf_counter()
+    annealed = sampled_components.anneal_staged(staged, some, True)
+    anneal_s = time.perf_counter() - t0
+    return {
+        "workload": "%d real kagome_36 clusters x orders 0-2 (cutoff 1e-6), greedy, %d host threads; "
+                    "%d of them with 64 chains x 5120 sweeps per model" % (greedy_clusters, threads, annealed_clusters),
+        "growth_ms_per_cluster": growth_s / greedy_clusters * 1e3,
+        "greedy_ms_per_cluster": greedy_s / greedy_clusters * 1e3,
+        "greedy_clusters_per_s": greedy_clusters / greedy_s,
+        "median_order2_greedy_accuracy": float(np.median([r[2].greedy_accuracy for r in results])),
+        "annealed_models": len(staged),
+        "annealed_spins": int(spins),
+        "annealed_build_s": staged_s,
+        "annealed_anneal_s": anneal_s,
+        "annealed_flips_per_s": spins * 64 * 5120 / anneal_s,
+        "median_order2_sa_accuracy": float(np.median([r[2].sa_accuracy for r in annealed])),
     }
 
 

@@ -76,7 +76,7 @@ def main():
     elif kind == "real":
         import bench
 
-        out = bench.bench_real_kagome_36(a.chains, a.sweeps, calls=a.runs, warmup=0)
+        out = bench.bench_real_kagome_36(a.chains, a.sweeps, calls=a.runs, warmup=0, pipeline=False)
         flips = int(out["flips_profiled"])
         sweep_ms = [c["sweep_kernel_ms"] for c in out["clusters"]]
         record.update(kernel="k_sa_sweep<", clusters=out["clusters"])
