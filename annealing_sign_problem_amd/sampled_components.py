@@ -643,11 +643,39 @@ def main(argv=None):
         # a round of --batch clusters per rank at a time; rank 0 appends every round's lines, so a
         # job that is killed keeps what it has finished (driver :828-830 appends per cluster).
         # The round size is a multiple of the world size: cluster c stays on rank c mod world.
-        step = max(args.batch, 1) * asp_dist.world_size()
-        for start in range(0, len(clusters), step):
-            lines = asp_dist.map_sharded_many(clusters[start:start + step], work_many)
-            if writer:
-                append(lines)
+        world, me = asp_dist.world_size(), asp_dist.rank()
+        step = max(args.batch, 1) * world
+        rounds = [clusters[start:start + step] for start in range(0, len(clusters), step)]
+        if args.batch > 1 and args.annealing:
+            # as in the single process: while a rank's chains of one round anneal, a second
+            # thread builds the models of its share of the next round
+            from concurrent.futures import ThreadPoolExecutor
+
+            def my_share(r):
+                return [rounds[r][c] for c in range(len(rounds[r])) if c % world == me]
+
+            def stage(some):
+                return stage_clusters(some, hamiltonian, ground_state, noisy_ground_state,
+                                      noisy_log_coeff_fn, args.order, args.global_cutoff, args.jobs)
+
+            with ThreadPoolExecutor(max_workers=1) as builder:
+                upcoming = builder.submit(stage, my_share(0)) if rounds else None
+                for r in range(len(rounds)):
+                    staged = upcoming.result()
+                    upcoming = builder.submit(stage, my_share(r + 1)) if r + 1 < len(rounds) else None
+
+                    def solve(some, staged=staged):  # (`some` is this rank's share of the round)
+                        return [",".join(x.to_csv_str() for x in columns)
+                                for columns in anneal_staged(staged, some, True, args.sweep_order)]
+
+                    lines = asp_dist.map_sharded_many(rounds[r], solve)
+                    if writer:
+                        append(lines)
+        else:
+            for some in rounds:
+                lines = asp_dist.map_sharded_many(some, work_many)
+                if writer:
+                    append(lines)
         if created_group:
             import torch.distributed as dist
 

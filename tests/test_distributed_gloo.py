@@ -223,6 +223,70 @@ def test_pipeline_main_initialises_ranks_from_env(tmp_path):
     mp.spawn(_main_worker, args=(2, _free_port(), out, True), nprocs=2, join=True)
 
 
+def _pipelined_worker(rank, world, port, out_path):
+    """sampled_components.main() with --batch 2 and annealing under two ranks: the branch that
+    builds a rank's share of the next round while the current one anneals.  Stand-in stages."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import threading
+
+    from annealing_sign_problem_amd import distributed, sampled_components as sc
+
+    def fake_clusters(hamiltonian, ground_state, number_samples, *args):
+        states = hamiltonian.basis.states
+        return [states[11 * c: 11 * c + 4 + c].copy() for c in range(number_samples)]
+
+    main_thread = threading.get_ident()
+    log = []
+
+    def fake_stage(clusters, hamiltonian, ground_state, noisy, fn, order, cutoff, jobs=1):
+        log.append(("stage", [int(c.size) - 4 for c in clusters], threading.get_ident() != main_thread))
+        return [(i, ("model", int(c.size), o), None, None,
+                 sc.OptimizationResult(int(c.size) + o, 0.5, 0.25, float("nan"), float("nan"), 1.0))
+                for i, c in enumerate(clusters) for o in range(order + 1)]
+
+    def fake_anneal(staged, clusters, annealing, sweep_order=None):
+        assert annealing and sweep_order == "colour" and not distributed.shards_chains()
+        log.append(("anneal", [int(c.size) - 4 for c in clusters]))
+        results = [[] for _ in clusters]
+        for index, model, _, _, r in staged:
+            assert model[1] == int(clusters[index].size)  # the models ARE those of these clusters
+            r.sa_accuracy, r.sa_overlap = float(model[1] % 7) / 7.0, float(distributed.rank())
+            results[index].append(r)
+        return results
+
+    sc.generate_clusters = lambda *args: fake_clusters(*args)
+    sc.iter_clusters = lambda *args: iter(fake_clusters(*args))
+    sc.stage_clusters = fake_stage
+    sc.anneal_staged = fake_anneal
+    sc.main(["--model", "heisenberg_kagome_16", "--output", out_path, "--order", "1", "--number-samples", "9",
+             "--seed", "3", "--batch", "2", "--annealing"])
+    if world > 1:
+        # rounds of 2 x 2 clusters: this rank's shares, each staged on the builder thread (the
+        # next one is submitted before the current one is annealed) and annealed in order
+        shares = [[c for c in range(start, min(start + 4, 9)) if (c - start) % 2 == rank] for start in (0, 4, 8)]
+        staged = [e[1] for e in log if e[0] == "stage"]
+        annealed = [e[1] for e in log if e[0] == "anneal"]
+        assert staged == shares and annealed == shares
+        assert all(e[2] for e in log if e[0] == "stage")
+
+
+def test_pipeline_rounds_are_pipelined_under_ranks(tmp_path):
+    """--batch > 1 with annealing under two ranks: every rank stages its share of the next round
+    on a second thread while it anneals the current one; the file is the single process's."""
+    import torch.multiprocessing as mp
+
+    out, single = str(tmp_path / "two.csv"), str(tmp_path / "one.csv")
+    mp.spawn(_pipelined_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_pipelined_worker, args=(1, _free_port(), single), nprocs=1, join=True)
+    rows = [l for l in open(out).read().splitlines() if not l.startswith("#")]
+    assert len(rows) == 9 and [int(l.split(",")[0]) for l in rows] == [4 + c for c in range(9)]
+    strip = lambda path: [",".join(c for i, c in enumerate(l.split(",")) if i % 6 != 4)  # (sa_overlap = the rank)
+                          for l in open(path).read().splitlines()]
+    assert strip(out) == strip(single)
+
+
 def test_pipeline_worker_processes_write_the_single_process_file(tmp_path, monkeypatch):
     """--workers N: the parent loads the inputs without touching the GPU, a child grows the
     clusters, N forked workers share the inputs and take rounds of clusters from a queue, the

@@ -84,6 +84,17 @@ def test_pipeline_two_ranks_on_one_gpu_gloo(tmp_path):
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert proc.returncode == 0, proc.stdout + proc.stderr
     assert two.read_text() == single.read_text()
+    # annealed, rounds of 2 clusters per rank: every rank builds its share of the next round while
+    # the current one anneals (round 3); the per-model loop of a single process is the reference
+    annealed = [a for a in args if a != "--no-annealing"] + ["--annealing", "--number-sweeps", "5000"]
+    one = tmp_path / "annealed_single.csv"
+    sampled_components.main(annealed + ["--batch", "1", "--output", str(one)])
+    both = tmp_path / "annealed_two.csv"
+    cmd = cmd[:cmd.index("annealing_sign_problem_amd.sampled_components") + 1] + annealed + [
+        "--batch", "2", "--output", str(both)]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    assert both.read_text() == one.read_text()
 
 
 def test_bench_multi_rank_path_at_world_size_one():
