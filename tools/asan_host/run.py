@@ -13,6 +13,12 @@ cases.append(synthetic.sk_cluster(700,degree=300,seed=3))
 import scipy.sparse
 cases.append((scipy.sparse.csr_matrix((5,5)),np.zeros(5)))
 cases.append((scipy.sparse.identity(7,format='csr'),np.ones(7)))
+# round 3: the symmetric-J short cut and the general merge on the same couplings (upper triangle),
+# and a matrix that is symmetric but for one missing mirror element
+J,h=synthetic.planted_cluster(3000,seed=9,mean_degree=12.0)[:2]
+cases.append((scipy.sparse.triu(2.0*J,1).tocsr(),h))
+lil=scipy.sparse.lil_matrix(J); i,j=(int(v[0]) for v in J.nonzero()); lil[j,i]=0.0
+cases.append((scipy.sparse.csr_matrix(lil),h))
 for J,h in cases:
     J=scipy.sparse.csr_matrix(J); J.sort_indices(); n=J.shape[0]
     ip=J.indptr.astype(np.int64); ix=J.indices.astype(np.int32); d=J.data.astype(np.float64); h=np.ascontiguousarray(h,dtype=np.float64)
