@@ -287,6 +287,30 @@ def test_pipeline_rounds_are_pipelined_under_ranks(tmp_path):
     assert strip(out) == strip(single)
 
 
+def test_growth_child_failure_stops_the_parent_with_its_message(tmp_path, monkeypatch):
+    """The forked child that grows the clusters (sampled_components.clusters_from_child) fails:
+    the parent stops with the child's error instead of waiting or writing a partial file body;
+    with ASP_GROW_IN_PLACE=1 the same error surfaces directly."""
+    sys.path.insert(0, ROOT)
+    from annealing_sign_problem_amd import sampled_components as sc
+
+    def broken(hamiltonian, ground_state, number_samples, *args):
+        yield hamiltonian.basis.states[:5].copy()
+        raise RuntimeError("no such lattice")
+
+    monkeypatch.setattr(sc, "iter_clusters", broken)
+    monkeypatch.setattr(sc, "process_cluster", lambda cluster, *rest: [
+        sc.OptimizationResult(int(cluster.size), 0.5, 0.5, float("nan"), float("nan"), 1.0)])
+    argv = ["--model", "heisenberg_kagome_16", "--order", "0", "--number-samples", "3", "--seed", "1",
+            "--no-annealing"]
+    with pytest.raises(SystemExit) as stop:
+        sc.main(argv + ["--output", str(tmp_path / "child.csv")])
+    assert "cluster generation failed" in str(stop.value) and "no such lattice" in str(stop.value)
+    monkeypatch.setenv("ASP_GROW_IN_PLACE", "1")
+    with pytest.raises(RuntimeError, match="no such lattice"):
+        sc.main(argv + ["--output", str(tmp_path / "in_place.csv")])
+
+
 def test_pipeline_worker_processes_write_the_single_process_file(tmp_path, monkeypatch):
     """--workers N: the parent loads the inputs without touching the GPU, a child grows the
     clusters, N forked workers share the inputs and take rounds of clusters from a queue, the
