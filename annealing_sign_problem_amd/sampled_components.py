@@ -575,6 +575,13 @@ def main(argv=None):
     # rank 0 looks at the file and tells the others, so that all ranks stop together
     refuse = asp_dist.broadcast_object(writer and os.path.exists(args.output))
     if refuse:
+        if created_group:
+            # leave no process group behind: its background threads have been seen to abort a rank
+            # that exits with the group still up ("terminate called without an active exception")
+            import torch.distributed as dist
+
+            dist.barrier()
+            dist.destroy_process_group()
         raise SystemExit("Output file '{}' already exists: refusing to overwrite".format(args.output))
     hamiltonian, ground_state = load_input(args)
     phase("inputs loaded")
