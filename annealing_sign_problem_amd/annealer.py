@@ -203,9 +203,14 @@ class Hamiltonian:
 
 
 def resolve_sweep_order(sweep_order: Optional[str]) -> str:
-    """``"colour"`` or ``"shuffled"``; ``None`` reads ``$ASP_SWEEP_ORDER`` (default colour)."""
+    """``"shuffled"`` or ``"colour"``; ``None`` reads ``$ASP_SWEEP_ORDER`` and falls back to
+    ``"shuffled"`` — the visiting order of the reference's annealer, so
+    that every drop-in entry point (``sa.anneal``, ``common.solve_ising_model``, `make small`,
+    ``sampled_components --annealing``) runs the chain with the reference's law unless told
+    otherwise.  ``"colour"`` (ASP-SA-1's fixed order: faster here, a different Markov chain) is
+    one keyword / flag / environment variable away."""
     if sweep_order is None:
-        sweep_order = os.environ.get("ASP_SWEEP_ORDER") or "colour"
+        sweep_order = os.environ.get("ASP_SWEEP_ORDER") or "shuffled"
     if sweep_order not in ("colour", "shuffled"):
         raise ValueError("'sweep_order' must be 'colour' or 'shuffled'")
     return sweep_order
@@ -267,12 +272,13 @@ def anneal(hamiltonian: Hamiltonian, x0=None, seed=None, number_sweeps: int = 51
     ``only_best=False`` the per-repetition arrays ``(xs[R, words], es[R])``
     (zip-able, experiments/full_hilbert_space.py:176).
 
-    ``sweep_order="colour"`` (default): the fixed colour order of specification ASP-SA-1.
-    ``sweep_order="shuffled"``: a fresh random visiting order every sweep — what the reference's
-    ``ising_glass_annealer`` does as far as its published success probabilities can tell
-    (DESIGN.md §6.1); statistically the library's behaviour, a third to a quarter of the colour
-    order's rate here and with a LOWER success probability per sweep.  ``None``: the value of
-    ``$ASP_SWEEP_ORDER`` if set, else ``"colour"``.
+    ``sweep_order="shuffled"`` (default): a fresh random visiting order every sweep — what the
+    reference's ``ising_glass_annealer`` does as far as its published success probabilities can
+    tell: statistically the library's behaviour.
+    ``sweep_order="colour"``: the fixed colour order of specification ASP-SA-1 — a different
+    Markov chain (a HIGHER success probability per sweep than the published curves) and several
+    times the rate on this hardware; the headline kernel of ``bench.py``.  ``None``: the value of
+    ``$ASP_SWEEP_ORDER`` if set, else ``"shuffled"``.
 
     When ``torch.distributed`` is initialised with more than one rank (and
     ``distributed`` is true) the repetitions are sharded over the ranks and

@@ -276,9 +276,10 @@ def solve_ising_model(
     sweep_order: Optional[str] = None,
 ) -> np.ndarray:
     """Optimise the signs of ``model`` and project them onto ``frozen_spins``
-    (common.py:232-261).  ``sweep_order`` (not in the reference): ``"colour"``, the fixed order
-    of this package's default annealer, or ``"shuffled"``, a fresh random order every sweep as
-    in the reference's annealer (``sa.anneal``); ``None`` = ``$ASP_SWEEP_ORDER`` or colour."""
+    (common.py:232-261).  ``sweep_order`` (not in the reference): ``"shuffled"``, a fresh random
+    order every sweep as in the reference's annealer — the default, so that the drop-in call has
+    the reference's law —, or ``"colour"``, this package's fixed colour order (faster, a different
+    chain; ``sa.anneal``); ``None`` = ``$ASP_SWEEP_ORDER`` or shuffled."""
     if mode == "sa":
         x, _ = sa.anneal(model.ising_hamiltonian, seed=seed, number_sweeps=number_sweeps,
                          repetitions=repetitions, only_best=only_best, sweep_order=sweep_order)

@@ -150,11 +150,53 @@ int build_sa_layout(uint64_t num_spins, const int64_t *indptr, const int32_t *in
       }
     }
     symmetric = sum_a == 0 && sum_b == 0;
+    // test hook: pretend the hashes collided, so that the exact confirmation below decides alone
+    if (std::getenv("ASP_PLAN_HASHES_SAY_SYMMETRIC")) symmetric = true;
+  }
+  const unsigned parts = host_threads(n);
+  if (symmetric) {
+    // The hashes are the fast NEGATIVE test; a yes is confirmed exactly before the short cut is
+    // taken (a false yes would silently build A = 2 J from the upper rows): every entry above the
+    // diagonal finds its mirror with the same bits by a binary search in the mirror's row, and
+    // there are as many entries below the diagonal as above (rows are duplicate-free, so the map
+    // entry -> mirror is injective and the counts make it onto).  O(nnz log d), rows in parallel.
+    std::vector<uint8_t> part_ok(parts, 1);
+    std::vector<int64_t> part_upper(parts, 0), part_lower(parts, 0);
+    parallel_ranges(n, parts, [&](uint64_t begin, uint64_t end, unsigned part) {
+      int64_t upper = 0, lower = 0;
+      bool ok = true;
+      for (uint64_t i = begin; i < end && ok; ++i) {
+        for (int64_t k = indptr[i]; k < indptr[i + 1]; ++k) {
+          const uint64_t j = static_cast<uint64_t>(indices[k]);
+          if (j < i) {
+            ++lower;
+          } else if (j > i) {
+            ++upper;
+            const int32_t *row = indices + indptr[j], *row_end = indices + indptr[j + 1];
+            const int32_t *at = std::lower_bound(row, row_end, static_cast<int32_t>(i));
+            if (at == row_end || static_cast<uint64_t>(*at) != i ||
+                std::memcmp(&data[indptr[j] + (at - row)], &data[k], sizeof(double)) != 0) {
+              ok = false;
+              break;
+            }
+          }
+        }
+      }
+      part_ok[part] = ok ? 1 : 0;
+      part_upper[part] = upper;
+      part_lower[part] = lower;
+    });
+    int64_t upper = 0, lower = 0;
+    for (unsigned part = 0; part < parts; ++part) {
+      symmetric = symmetric && part_ok[part];
+      upper += part_upper[part];
+      lower += part_lower[part];
+    }
+    symmetric = symmetric && upper == lower;
   }
   stage("symmetry");
   // ---- J^T by rows (bucket the entries by column; rows are visited in order so
   //      every bucket ends up sorted by original row) --------------------------
-  const unsigned parts = host_threads(n);
   std::vector<int64_t> t_ptr(symmetric ? 0 : n + 1, 0);
   std::vector<Entry> t_entries(symmetric ? 0 : static_cast<size_t>(nnz));
   if (!symmetric) {

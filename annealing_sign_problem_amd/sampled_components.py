@@ -316,10 +316,10 @@ def parse_command_line(argv=None):
                         help="clusters whose annealing chains share one batched device call "
                              "(asp_sa_anneal_batch); 1 = one call per model, as the reference's "
                              "loop.  The output does not depend on it")
-    parser.add_argument("--sweep-order", type=str, default="colour", choices=["colour", "shuffled"],
-                        help="visiting order of the annealing sweeps: 'colour' (this package's "
-                             "default, fixed) or 'shuffled' (a fresh random order every sweep: the "
-                             "reference annealer's statistics)")
+    parser.add_argument("--sweep-order", type=str, default="shuffled", choices=["colour", "shuffled"],
+                        help="visiting order of the annealing sweeps: 'shuffled' (default: a fresh "
+                             "random order every sweep, the reference annealer's statistics) or "
+                             "'colour' (this package's fixed colour order: faster, a different chain)")
     parser.add_argument("--workers", type=int, default=0,
                         help="worker PROCESSES (forked after the inputs are loaded, so the ground state "
                              "is shared, not read once per rank); worker k computes on GPU k mod "
@@ -365,6 +365,31 @@ def load_input(args):
 _WORKER = {}
 
 
+def gpu_maybe_initialised() -> bool:
+    """True when this process may already hold HIP state, which a forked child must not inherit.
+    ``asp_device_touched()`` only knows about calls made THROUGH libasp_hip; the GPU may also have
+    been initialised by a profiler's preloaded tool library (rocprofv3 sets ``ROCP_TOOL_LIBRARIES``
+    / ``HSA_TOOLS_LIB`` / ``LD_PRELOAD`` and initialises HSA before the program starts) or by a host
+    that used ``torch.cuda``."""
+    from . import _lib
+
+    if _lib.gpu_touched():
+        return True
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or os.environ.get("HSA_TOOLS_LIB"):
+        return True
+    preload = os.environ.get("LD_PRELOAD", "")
+    if any(name in preload for name in ("rocprof", "roctracer", "roctx")):
+        return True
+    torch = sys.modules.get("torch")
+    if torch is not None:
+        try:
+            if torch.cuda.is_initialized():
+                return True
+        except Exception:  # noqa: BLE001 - a torch without a usable cuda module has not touched a GPU
+            pass
+    return False
+
+
 def _generate_in_child(conn, hamiltonian, ground_state, args):
     """Cluster growth uses the GPU action; done in a child so that the parent stays free of
     any HIP state and can fork its workers afterwards."""
@@ -408,10 +433,9 @@ def clusters_from_child(hamiltonian, ground_state, args):
     not fork): otherwise, and where there is no fork, the clusters are grown in place."""
     import multiprocessing
 
-    from . import _lib
-
-    # (under torch.distributed.run the rank has bound its GPU through torch already)
-    in_place = (_lib.gpu_touched() or "RANK" in os.environ
+    # (under torch.distributed.run the rank has bound its GPU through torch already; under
+    # rocprofv3 the profiler's tool library has initialised it before main() runs)
+    in_place = (gpu_maybe_initialised() or "RANK" in os.environ
                 or "fork" not in multiprocessing.get_all_start_methods()
                 or os.environ.get("ASP_GROW_IN_PLACE") == "1")
     if in_place:
@@ -517,9 +541,7 @@ def _main_with_workers(args):
         raise SystemExit("Output file '{}' already exists: refusing to overwrite".format(args.output))
     np.random.seed(args.seed)
     hamiltonian, ground_state = load_input(args)
-    from . import _lib
-
-    if _lib.gpu_touched():
+    if gpu_maybe_initialised():
         # (a ground state computed on the GPU on the spot: --model of a 32-/36-site system without --hdf5)
         raise SystemExit("--workers forks after the inputs are loaded and needs them loaded WITHOUT the "
                          "GPU: write the ground state first (python -m annealing_sign_problem_amd.sector_ed) "
@@ -540,8 +562,22 @@ def _main_with_workers(args):
                    noisy_ground_state=noisy_ground_state, args=args, clusters=clusters)
     step = max(args.batch, 1) if args.annealing else max(1, min(16, args.batch))
     rounds = [list(range(start, min(start + step, len(clusters)))) for start in range(0, len(clusters), step)]
-    with ctx.Pool(processes=args.workers, initializer=_worker_init) as pool:
-        for lines in pool.imap(_worker_chunk, rounds):  # (in order: the file grows round by round)
+    # (an executor, not multiprocessing.Pool: a Pool silently replaces a worker that died — a GPU
+    # fault, an out-of-memory kill — and never completes its task, so the parent would wait forever)
+    from concurrent.futures import ProcessPoolExecutor
+    from concurrent.futures.process import BrokenProcessPool
+
+    with ProcessPoolExecutor(max_workers=args.workers, mp_context=ctx, initializer=_worker_init) as pool:
+        futures = [pool.submit(_worker_chunk, indices) for indices in rounds]
+        for indices, future in zip(rounds, futures):  # (in order: the file grows round by round)
+            try:
+                lines = future.result()
+            except BrokenProcessPool:
+                for other in futures:
+                    other.cancel()
+                raise SystemExit("a worker process died while clusters %d..%d were being solved (a GPU fault "
+                                 "or an out-of-memory kill?); the output holds the rounds before them"
+                                 % (indices[0], indices[-1]))
             with open(args.output, "a") as f:
                 for line in lines:
                     f.write(line + "\n")
@@ -558,30 +594,51 @@ def main(argv=None):
             sys.stderr.write("[pipeline] %-28s at %7.2f s\n" % (name, time.perf_counter() - started))
 
     if args.workers > 1 and "RANK" not in os.environ:
-        from . import _lib
-
-        if _lib.gpu_touched():
+        if gpu_maybe_initialised():
             import warnings
 
-            warnings.warn("--workers needs a process that has not used the GPU yet: running with "
-                          "--jobs threads instead")
+            warnings.warn("--workers needs a process that has not used the GPU yet (this one has, or "
+                          "runs under a profiler that has): running with --jobs threads instead")
         else:
             return _main_with_workers(args)
     # under `python -m torch.distributed.run -m ...sampled_components`: bind this rank's GPU for
     # torch and for libasp_hip and join the process group before anything touches a device
     created_group = asp_dist.init_from_env()
+    # Whatever way the rest of main() ends — normally, a SystemExit from the inputs, an exception
+    # of a stage, of a worker thread or of a collective whose peer has died — the group this
+    # call created is destroyed before the interpreter exits: torch's background threads of a
+    # group that is still up have been seen to abort the process at exit ("terminate called
+    # without an active exception", commit 1f46a71).  Only the normal end waits for the other
+    # ranks (a barrier); a failing rank must not wait for ranks that may be dead or blocked.
+    failed = True
+    try:
+        _main_in_group(args, asp_dist, created_group, phase)
+        failed = False
+    finally:
+        if created_group:
+            import torch.distributed as dist
+
+            try:
+                if not failed:
+                    dist.barrier()
+            finally:
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001 - nothing more to do for a group that is half gone
+                    pass
+
+
+def _main_in_group(args, asp_dist, created_group, phase):
     np.random.seed(args.seed)
     writer = asp_dist.rank() == 0  # under torch.distributed only rank 0 touches the file
     # rank 0 looks at the file and tells the others, so that all ranks stop together
     refuse = asp_dist.broadcast_object(writer and os.path.exists(args.output))
     if refuse:
         if created_group:
-            # leave no process group behind: its background threads have been seen to abort a rank
-            # that exits with the group still up ("terminate called without an active exception")
+            # (every rank is here: wait for the others, then main() tears the group down)
             import torch.distributed as dist
 
             dist.barrier()
-            dist.destroy_process_group()
         raise SystemExit("Output file '{}' already exists: refusing to overwrite".format(args.output))
     hamiltonian, ground_state = load_input(args)
     phase("inputs loaded")
@@ -683,11 +740,6 @@ def main(argv=None):
                 lines = asp_dist.map_sharded_many(some, work_many)
                 if writer:
                     append(lines)
-        if created_group:
-            import torch.distributed as dist
-
-            dist.barrier()
-            dist.destroy_process_group()
         return
     # With --jobs > 1 several clusters are in flight on one GPU at once — the C calls release
     # the GIL and every Hamiltonian owns its stream.  All randomness was consumed above, so the

@@ -322,13 +322,13 @@ def bench_default_call():
     lib = _lib.load()
     J, h, _ = synthetic.planted_cluster(100000, seed=1, mean_degree=8.0)
     ham = sa.Hamiltonian(J, h)
-    sa.anneal(ham, seed=1, number_sweeps=16, repetitions=64)  # warm-up
+    sa.anneal(ham, seed=1, number_sweeps=16, repetitions=64, sweep_order="colour")  # warm-up
     out = {"workload": "anneal(number_sweeps=5120, repetitions=64), K=100000, dbar=8"}
     energies = []
     for name, team in (("team", -1), ("one_workgroup_per_chain", 0)):
         _lib.check(lib.asp_sa_set_team(ham.plan(), team))
         t0 = time.perf_counter()
-        x, e = sa.anneal(ham, seed=12345, number_sweeps=5120, repetitions=64)
+        x, e = sa.anneal(ham, seed=12345, number_sweeps=5120, repetitions=64, sweep_order="colour")
         out[name + "_s"] = time.perf_counter() - t0
         out[name + "_flips_per_s"] = 100000 * 64 * 5120 / (lib.asp_sa_last_sweep_ms(ham.plan()) * 1e-3)
         energies.append(e)
@@ -382,15 +382,16 @@ def bench_batched_clusters(num_problems=128, serial_every=8):
         ham.info()  # plan resident before the timed region
         hams.append(ham)
     sweeps, reps = 5120, 64
-    sa.anneal_batch(hams[:4], seed=1, number_sweeps=8, repetitions=reps)  # warm-up
+    sa.anneal_batch(hams[:4], seed=1, number_sweeps=8, repetitions=reps, sweep_order="colour")  # warm-up
     t0 = time.perf_counter()
-    batched = sa.anneal_batch(hams, seed=12345, number_sweeps=sweeps, repetitions=reps)
+    batched = sa.anneal_batch(hams, seed=12345, number_sweeps=sweeps, repetitions=reps, sweep_order="colour")
     t_batched = time.perf_counter() - t0
     batched_kernel_ms = float(lib.asp_sa_batch_last_ms())
     subset = list(range(0, num_problems, serial_every))
-    sa.anneal(hams[subset[0]], seed=1, number_sweeps=8, repetitions=reps)  # warm-up
+    sa.anneal(hams[subset[0]], seed=1, number_sweeps=8, repetitions=reps, sweep_order="colour")  # warm-up
     t0 = time.perf_counter()
-    serial = [sa.anneal(hams[i], seed=12345, number_sweeps=sweeps, repetitions=reps) for i in subset]
+    serial = [sa.anneal(hams[i], seed=12345, number_sweeps=sweeps, repetitions=reps, sweep_order="colour")
+              for i in subset]
     t_serial = time.perf_counter() - t0
     for i, (x, e) in zip(subset, serial):
         if not (np.array_equal(x, batched[i][0]) and e == batched[i][1]):

@@ -41,9 +41,11 @@ void asp_clear_error(void);
 
 /* Number of HIP devices (>= 0) or a negative asp_status. */
 int asp_device_count(void);
-/* 1 once this process has made a HIP call through the library (any entry point that needs the
- * device), 0 before: a process that has not may still fork workers that each open the device
- * (sampled_components --workers). */
+/* 1 once this process has made a HIP call THROUGH THIS LIBRARY (any entry point that needs the
+ * device), 0 before.  It knows nothing of HIP state created elsewhere in the process (a
+ * profiler's preloaded tool library, the host's own HIP or torch.cuda calls): 0 means "not by
+ * this library", and only a process whose GPU is untouched by anybody may fork workers that each
+ * open the device (sampled_components --workers checks both). */
 int asp_device_touched(void);
 /* Select the device used by this library in the whole process (every entry point binds
  * its calling thread to it). */

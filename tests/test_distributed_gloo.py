@@ -44,13 +44,13 @@ def _worker(rank, world, port, repetitions, out_dir):
     # the public entry point picks the sharded path by itself
     annealer_info = type("I", (), {"beta0_auto": 0.5, "beta1_auto": 100.0})()
     ham.info = lambda: annealer_info
-    x, e = annealer.anneal(ham, seed=999, number_sweeps=15, repetitions=repetitions)
+    x, e = annealer.anneal(ham, seed=999, number_sweeps=15, repetitions=repetitions, sweep_order="colour")
     np.savez(os.path.join(out_dir, "best%d.npz" % rank), x=x, e=e)
     xs_all, es_all = annealer.anneal(ham, seed=999, number_sweeps=15, repetitions=repetitions,
-                                     only_best=False)
+                                     only_best=False, sweep_order="colour")
     assert np.array_equal(xs_all, xs) and es_all.tobytes() == es.tobytes()
     # seed=None: rank 0 draws, every rank must run the same stream
-    xr, er = annealer.anneal(ham, seed=None, number_sweeps=15, repetitions=repetitions)
+    xr, er = annealer.anneal(ham, seed=None, number_sweeps=15, repetitions=repetitions, sweep_order="colour")
     np.savez(os.path.join(out_dir, "drawn%d.npz" % rank), x=xr, e=er)
     # the shuffled visiting order shards the same way (global replica ids key its random words too)
     xs_s, es_s = annealer.anneal(ham, seed=999, number_sweeps=15, repetitions=repetitions,
@@ -117,7 +117,7 @@ def _cluster_worker(rank, world, port, out_dir):
         J, h, _ = synthetic.planted_cluster(100 + 10 * k, seed=k, mean_degree=6.0)
         ham = annealer.Hamiltonian(J, h)
         ham.info = lambda: info
-        x, e = annealer.anneal(ham, seed=7 + k, number_sweeps=10, repetitions=3)
+        x, e = annealer.anneal(ham, seed=7 + k, number_sweeps=10, repetitions=3, sweep_order="colour")
         return (k, float(e), x.tobytes())
 
     results = distributed.map_sharded(list(range(7)), solve)   # 4 items on rank 0, 3 on rank 1
@@ -247,7 +247,7 @@ def _pipelined_worker(rank, world, port, out_path):
                 for i, c in enumerate(clusters) for o in range(order + 1)]
 
     def fake_anneal(staged, clusters, annealing, sweep_order=None):
-        assert annealing and sweep_order == "colour" and not distributed.shards_chains()
+        assert annealing and sweep_order == "shuffled" and not distributed.shards_chains()  # (the default)
         log.append(("anneal", [int(c.size) - 4 for c in clusters]))
         results = [[] for _ in clusters]
         for index, model, _, _, r in staged:
@@ -347,3 +347,146 @@ def test_pipeline_worker_processes_write_the_single_process_file(tmp_path, monke
     assert len([l for l in open(forked) if not l.startswith("#")]) == 9
     with pytest.raises(SystemExit):
         sc.main(common + ["--output", forked, "--workers", "3"])  # refuses to overwrite
+
+
+def test_fork_guard_sees_gpu_state_made_outside_the_library(tmp_path, monkeypatch):
+    """asp_device_touched() only knows HIP calls made through libasp_hip.  Under a
+    profiler's preloaded tool library (or a host that used torch.cuda) the GPU is initialised
+    before main() runs: the clusters must then be grown in place and --workers refused, not
+    forked into children that would call HIP in a copy of the runtime."""
+    sys.path.insert(0, ROOT)
+    import multiprocessing
+
+    from annealing_sign_problem_amd import sampled_components as sc
+
+    for name in ("ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "LD_PRELOAD", "RANK", "ASP_GROW_IN_PLACE"):
+        monkeypatch.delenv(name, raising=False)
+    assert not sc.gpu_maybe_initialised()
+    for name, value in (("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so"),
+                        ("HSA_TOOLS_LIB", "librocprofiler64.so.1"),
+                        ("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")):
+        monkeypatch.setenv(name, value)
+        assert sc.gpu_maybe_initialised()
+        monkeypatch.delenv(name)
+    monkeypatch.setenv("LD_PRELOAD", "/usr/lib/libjemalloc.so")
+    assert not sc.gpu_maybe_initialised()
+    monkeypatch.delenv("LD_PRELOAD")
+
+    forks = []
+    real_context = multiprocessing.get_context
+
+    def watched(method=None):
+        forks.append(method)
+        return real_context(method)
+
+    monkeypatch.setattr(multiprocessing, "get_context", watched)
+    monkeypatch.setattr(sc, "iter_clusters", lambda hamiltonian, *rest: iter(
+        [hamiltonian.basis.states[:5].copy(), hamiltonian.basis.states[9:16].copy()]))
+    monkeypatch.setattr(sc, "process_cluster", lambda cluster, *rest: [
+        sc.OptimizationResult(int(cluster.size), 0.5, 0.5, float("nan"), float("nan"), 1.0)])
+    argv = ["--model", "heisenberg_kagome_16", "--order", "0", "--number-samples", "2", "--seed", "1",
+            "--no-annealing"]
+    sc.main(argv + ["--output", str(tmp_path / "child.csv")])
+    assert forks == ["fork"]  # an untouched process grows its clusters in a forked child
+    del forks[:]
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "librocprofiler-sdk-tool.so")
+    sc.main(argv + ["--output", str(tmp_path / "in_place.csv")])
+    with pytest.warns(UserWarning, match="--workers"):
+        sc.main(argv + ["--output", str(tmp_path / "workers.csv"), "--workers", "2"])
+    assert forks == []  # under the profiler: in place, and threads instead of worker processes
+    assert (open(tmp_path / "child.csv").read() == open(tmp_path / "in_place.csv").read()
+            == open(tmp_path / "workers.csv").read())
+
+
+def _dying_chunk(indices):
+    if 2 in indices:
+        os._exit(9)  # what a GPU fault or an out-of-memory kill looks like from the parent
+    return ["%d" % i for i in indices]
+
+
+def test_a_dying_worker_process_stops_the_run(tmp_path, monkeypatch):
+    """multiprocessing.Pool replaces a dead worker and never completes its task — the
+    parent waited forever.  The executor reports the broken pool; the parent names the round."""
+    sys.path.insert(0, ROOT)
+    from annealing_sign_problem_amd import sampled_components as sc
+
+    monkeypatch.setattr(sc, "generate_clusters", lambda hamiltonian, *rest: [
+        hamiltonian.basis.states[5 * c: 5 * c + 4].copy() for c in range(6)])
+    monkeypatch.setattr(sc, "_worker_chunk", _dying_chunk)
+    monkeypatch.setattr(sc, "_worker_init", lambda: None)
+    out = tmp_path / "dying.csv"
+    with pytest.raises(SystemExit) as stop:
+        sc.main(["--model", "heisenberg_kagome_16", "--order", "0", "--number-samples", "6", "--seed", "1",
+                 "--no-annealing", "--workers", "2", "--batch", "1", "--output", str(out)])
+    assert "worker process died" in str(stop.value) and "clusters 2..2" in str(stop.value)
+    assert [l for l in open(out).read().splitlines() if not l.startswith("#")] == ["0", "1"]
+
+
+_FAILING_RANK = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+from annealing_sign_problem_amd import distributed, sampled_components as sc
+rank = int(os.environ["RANK"])
+
+def fake_clusters(hamiltonian, ground_state, number_samples, *args):
+    states = hamiltonian.basis.states
+    return [states[11 * c: 11 * c + 4 + c].copy() for c in range(number_samples)]
+
+def fake_stage(clusters, *rest, **kw):
+    if rank == 1 and {where!r} == "stage":
+        raise RuntimeError("stage failed on rank 1")
+    return [(i, ("model", int(c.size), 0), None, None,
+             sc.OptimizationResult(int(c.size), 0.5, 0.25, float("nan"), float("nan"), 1.0))
+            for i, c in enumerate(clusters)]
+
+def fake_anneal(staged, clusters, annealing, sweep_order=None):
+    results = [[] for _ in clusters]
+    for index, model, _, _, r in staged:
+        results[index].append(r)
+    return results
+
+def fake_load(args):
+    if rank == 1 and {where!r} == "load":
+        raise SystemExit("rank 1 cannot read its input")
+    return real_load(args)
+
+real_load = sc.load_input
+sc.load_input = fake_load
+sc.generate_clusters = fake_clusters
+sc.stage_clusters = fake_stage
+sc.anneal_staged = fake_anneal
+sc.main(["--model", "heisenberg_kagome_16", "--output", {out!r}, "--order", "0", "--number-samples", "6",
+         "--seed", "3", "--batch", "2", "--annealing"])
+"""
+
+
+@pytest.mark.parametrize("where", ["stage", "load"])
+def test_a_failing_rank_ends_every_rank_without_abort(tmp_path, where):
+    """main() tears its process group down on EVERY way out.  Rank 1 fails — an
+    exception inside stage_clusters on the builder thread, or a SystemExit while loading the
+    inputs —: both ranks end with a non-zero status, rank 1 with its message, neither with
+    torch's 'terminate called without an active exception' (the abort of commit 1f46a71)."""
+    import subprocess
+
+    port = _free_port()
+    script = _FAILING_RANK.format(root=ROOT, where=where, out=str(tmp_path / "out.csv"))
+    ranks = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), ASP_DIST_BACKEND="gloo", ASP_SINGLE_DEVICE="1")
+        ranks.append(subprocess.Popen([sys.executable, "-c", script], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outputs = []
+    for process in ranks:
+        try:
+            _, err = process.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for other in ranks:
+                other.kill()
+            pytest.fail("a rank kept waiting for a rank that had failed")
+        outputs.append((process.returncode, err))
+    (rc0, err0), (rc1, err1) = outputs
+    assert rc0 != 0 and rc1 != 0, outputs
+    assert ("stage failed on rank 1" if where == "stage" else "rank 1 cannot read its input") in err1
+    assert "terminate called" not in err0 and "terminate called" not in err1
+    assert rc0 > 0 and rc1 > 0, "a rank was killed by a signal: %r" % ((rc0, rc1),)

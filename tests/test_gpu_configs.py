@@ -103,8 +103,9 @@ def test_config1_j1j2_full_space_one_and_few_replicas(models):
     # the public entry point with only_best: the first minimum of the chains
     from annealing_sign_problem_amd import annealer as sa
 
-    x, e = sa.anneal(h, seed=435834, number_sweeps=150, repetitions=5)
-    xs5, es5 = sa.anneal(h, seed=435834, number_sweeps=150, repetitions=5, only_best=False)
+    x, e = sa.anneal(h, seed=435834, number_sweeps=150, repetitions=5, sweep_order="colour")
+    xs5, es5 = sa.anneal(h, seed=435834, number_sweeps=150, repetitions=5, only_best=False,
+                       sweep_order="colour")
     k = int(np.argmin(es5))
     assert np.array_equal(x, xs5[k]) and e == es5[k]
 

@@ -54,7 +54,7 @@ def test_plan_rejects_bad_matrices_and_oversized_problems():
     # more spins than one workgroup's LDS can hold even bit-packed: the sign words move to HBM
     n = 1500000
     big = sa.Hamiltonian(scipy.sparse.identity(n, format="csr"), np.zeros(n))
-    x, e = sa.anneal(big, seed=1, number_sweeps=1, repetitions=1)
+    x, e = sa.anneal(big, seed=1, number_sweeps=1, repetitions=1, sweep_order="colour")
     assert e == float(n) and _lib.load().asp_sa_last_layout(big.plan()) == 3
     # arguments of anneal
     ok = sa.Hamiltonian(scipy.sparse.identity(5, format="csr"), np.zeros(5))

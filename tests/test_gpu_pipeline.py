@@ -198,8 +198,13 @@ def test_pipeline_with_the_shuffled_visiting_order(tmp_path):
     a, b, c = tmp_path / "loop.csv", tmp_path / "batch.csv", tmp_path / "colour.csv"
     sampled_components.main(common_args + ["--output", str(a), "--batch", "1", "--sweep-order", "shuffled"])
     sampled_components.main(common_args + ["--output", str(b), "--sweep-order", "shuffled"])
-    sampled_components.main(common_args + ["--output", str(c)])
+    sampled_components.main(common_args + ["--output", str(c), "--sweep-order", "colour"])
     assert a.read_text() == b.read_text()
+    # the reference's law is the DEFAULT of --annealing: no flag = shuffled
+    d = tmp_path / "default.csv"
+    sampled_components.main(common_args + ["--output", str(d)])
+    data = lambda path: [l for l in path.read_text().splitlines() if not l.startswith("#")]
+    assert data(d) == data(b)
     rows = lambda path: np.array([[float(t) for t in l.split(",")] for l in path.read_text().splitlines()
                                   if not l.startswith("#")])
     shuffled, colour = rows(a), rows(c)

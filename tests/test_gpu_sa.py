@@ -164,16 +164,17 @@ def test_anneal_api_and_quality_on_planted_ferromagnet():
 
     J, h, planted = _planted(2000, 16, frustrated_fraction=0.0, diagonal_range=0)
     ham = sa.Hamiltonian(J, h)
-    x, e = sa.anneal(ham, seed=12345, number_sweeps=400, repetitions=16, only_best=True)
+    x, e = sa.anneal(ham, seed=12345, number_sweeps=400, repetitions=16, only_best=True, sweep_order="colour")
     assert x.dtype == np.uint64 and x.shape == ((2000 + 63) // 64,)
     s = sa.bits_to_signs(x, 2000)
     e_planted = planted @ (J @ planted)
     assert e <= e_planted + 1e-12 * abs(e_planted)
-    xs, es = sa.anneal(ham, seed=12345, number_sweeps=400, repetitions=16, only_best=False)
+    xs, es = sa.anneal(ham, seed=12345, number_sweeps=400, repetitions=16, only_best=False,
+                     sweep_order="colour")
     assert xs.shape == (16, 32) and es.shape == (16,)
     assert float(es.min()) == e and np.array_equal(xs[int(np.argmin(es))], x)
     # determinism
-    x2, e2 = sa.anneal(ham, seed=12345, number_sweeps=400, repetitions=16)
+    x2, e2 = sa.anneal(ham, seed=12345, number_sweeps=400, repetitions=16, sweep_order="colour")
     assert np.array_equal(x, x2) and e == e2
     assert abs(ham.energy(x) - s @ (J @ s)) <= 1e-12 * abs(e)
 
@@ -758,9 +759,10 @@ def test_batch_many_small_clusters_fill_the_chip_and_match():
                                           num_threads=16)
         assert np.array_equal(results[i][0], oxs) and results[i][1].tobytes() == oes.tobytes()
     # the public form: one (x, e) per problem = the first minimum of its chains
-    best = sa.anneal_batch([p["ham"] for p in problems[:5]], seed=7, number_sweeps=30, repetitions=8)
+    best = sa.anneal_batch([p["ham"] for p in problems[:5]], seed=7, number_sweeps=30, repetitions=8,
+                           sweep_order="colour")
     for p, (x, e) in zip(problems[:5], best):
-        x1, e1 = sa.anneal(p["ham"], seed=7, number_sweeps=30, repetitions=8)
+        x1, e1 = sa.anneal(p["ham"], seed=7, number_sweeps=30, repetitions=8, sweep_order="colour")
         assert np.array_equal(x, x1) and e == e1
 
 
@@ -1170,7 +1172,7 @@ def test_shuffled_batch_equals_the_single_calls():
     for ham, (x, e) in zip(hams[:3], best):
         sx, se = sa.anneal(ham, seed=12345, number_sweeps=30, repetitions=5, sweep_order="shuffled")
         assert np.array_equal(x, sx) and e == se
-    colour = sa.anneal_batch(hams[:3], seed=12345, number_sweeps=30, repetitions=5)
+    colour = sa.anneal_batch(hams[:3], seed=12345, number_sweeps=30, repetitions=5, sweep_order="colour")
     assert any(not np.array_equal(x, cx) for (x, _), (cx, _) in zip(best, colour))
 
 
@@ -1181,13 +1183,19 @@ def test_sweep_order_reaches_the_solver_entry_points(monkeypatch):
 
     J, h, ham, info, betas = _shuffled_case(600, 7.0, 8)
     model = common.IsingModel(np.arange(600, dtype=np.uint64), None, ham, sa.signs_to_bits(np.ones(600)))
-    x_colour = common.solve_ising_model(model, seed=3, number_sweeps=50, repetitions=4)
+    x_colour = common.solve_ising_model(model, seed=3, number_sweeps=50, repetitions=4,
+                                        sweep_order="colour")
     x_shuffled = common.solve_ising_model(model, seed=3, number_sweeps=50, repetitions=4,
                                           sweep_order="shuffled")
+    # the drop-in default is the reference's law
+    monkeypatch.delenv("ASP_SWEEP_ORDER", raising=False)
+    assert np.array_equal(common.solve_ising_model(model, seed=3, number_sweeps=50, repetitions=4), x_shuffled)
     expected, _ = sa.anneal(ham, seed=3, number_sweeps=50, repetitions=4, sweep_order="shuffled")
     assert np.array_equal(x_shuffled, expected) and not np.array_equal(x_shuffled, x_colour)
     assert np.array_equal(common.solve_ising_models([model], seed=3, number_sweeps=50, repetitions=4,
                                                     sweep_order="shuffled")[0], expected)
+    monkeypatch.setenv("ASP_SWEEP_ORDER", "colour")
+    assert np.array_equal(common.solve_ising_model(model, seed=3, number_sweeps=50, repetitions=4), x_colour)
     monkeypatch.setenv("ASP_SWEEP_ORDER", "shuffled")
     assert np.array_equal(common.solve_ising_model(model, seed=3, number_sweeps=50, repetitions=4), expected)
     with pytest.raises(ValueError):

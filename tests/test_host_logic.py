@@ -197,6 +197,30 @@ def test_plan_layout_matches_oracle_layout():
         results.append((colors, pos, x, info.beta0_auto, info.beta1_auto, info.energy_scale_exp))
     for a, b in zip(results[0], results[1]):
         assert np.array_equal(a, b)
+    # the two 64-bit hashes are only the fast negative test.  With the hashes forced to
+    # say "symmetric" (a collision), the exact mirror search must still send the upper triangle,
+    # the nudged matrix and a matrix whose lower half misses one element through the general merge
+    holed = J.tolil()
+    i, j = [(i, j) for i, j in zip(*J.nonzero()) if i > j][7]
+    holed[i, j] = 0.0
+    holed = holed.tocsr()
+    holed.eliminate_zeros()
+    holed.sort_indices()
+    os.environ["ASP_PLAN_HASHES_SAY_SYMMETRIC"] = "1"
+    try:
+        for m, expected in ((J, results[0]), (upper, results[1]), (nudged, results[2]), (holed, None)):
+            info = _lib.SaInfo()
+            colors, pos = np.zeros(3000, np.int32), np.zeros(3000, np.uint32)
+            _lib.check(lib.asp_sa_layout_host(3000, _lib.ptr(m.indptr.astype(np.int64)),
+                                              _lib.ptr(m.indices.astype(np.int32)), _lib.ptr(m.data), _lib.ptr(h),
+                                              ctypes.byref(info), _lib.ptr(colors), _lib.ptr(pos)))
+            ocolors, _, ncol, nnz, diag = oracle.sa_layout(m)
+            assert np.array_equal(colors, ocolors) and info.nnz_offdiag == nnz and info.diag_sum == diag
+            if expected is not None:
+                assert np.array_equal(colors, expected[0]) and np.array_equal(pos, expected[1])
+                assert (info.beta0_auto, info.beta1_auto, info.energy_scale_exp) == expected[3:]
+    finally:
+        del os.environ["ASP_PLAN_HASHES_SAY_SYMMETRIC"]
     # rejects non-canonical input loudly
     bad_indices = np.array([1, 0], np.int32)
     rc = lib.asp_sa_layout_host(2, _lib.ptr(np.array([0, 2, 2], np.int64)), _lib.ptr(bad_indices),

@@ -69,7 +69,7 @@ def main():
         J, h, _ = synthetic.planted_cluster(100000, seed=1, mean_degree=8.0)
         ham = sa.Hamiltonian(J, h)
         for _ in range(a.runs):
-            sa.anneal(ham, seed=12345, number_sweeps=1024, repetitions=64)
+            sa.anneal(ham, seed=12345, number_sweeps=1024, repetitions=64, sweep_order="colour")
             sweep_ms.append(lib.asp_sa_last_sweep_ms(ham.plan()))
             flips += 100000 * 64 * 1024
         record.update(kernel="k_sa_sweep_team", K=100000, chains=64, sweeps=1024)

@@ -11,11 +11,11 @@ from annealing_sign_problem_amd import annealer as sa  # noqa: E402
 lib = _lib.load()
 J, h, _ = synthetic.planted_cluster(100000, seed=1, mean_degree=8.0)
 ham = sa.Hamiltonian(J, h)
-sa.anneal(ham, seed=1, number_sweeps=16, repetitions=64)  # warm-up
+sa.anneal(ham, seed=1, number_sweeps=16, repetitions=64, sweep_order="colour")  # warm-up
 for team in (-1, 0):
     _lib.check(lib.asp_sa_set_team(ham.plan(), team))
     t0 = time.time()
-    x, e = sa.anneal(ham, seed=12345, number_sweeps=5120, repetitions=64)
+    x, e = sa.anneal(ham, seed=12345, number_sweeps=5120, repetitions=64, sweep_order="colour")
     print("team=%2d: %.3f s wall, sweep kernel %.1f ms, E = %.12g" % (
         team, time.time() - t0, lib.asp_sa_last_sweep_ms(ham.plan()), e), flush=True)
 ham.release()  # handles are destroyed before the interpreter (and the profiler) wind down

@@ -39,5 +39,5 @@ ham = sa.Hamiltonian(J, h)
 for team in (0, -1):
     _lib.check(lib.asp_sa_set_team(ham.plan(), team))
     t0 = time.time()
-    x, e = sa.anneal(ham, seed=12345, number_sweeps=5120, repetitions=64)
+    x, e = sa.anneal(ham, seed=12345, number_sweeps=5120, repetitions=64, sweep_order="colour")
     print("anneal(5120 sweeps x 64) team=%d: %.3f s, E = %.12g" % (team, time.time() - t0, e), flush=True)
