@@ -55,6 +55,8 @@ constexpr uint64_t kQuadLimit = 0x100000;           // quads of one sweep: 3 KiB
 // status words shared by the kernels of a call (device memory, zeroed per attempt)
 enum : uint32_t { kStatBad = 0, kStatLevels = 1, kStatBlocks = 2, kStatQuads = 3, kStatWords = 4 };
 constexpr uint32_t kTimingSlots = 6, kTimingWaves = 8;  // u64[waves][slots] behind the status words (ASP_SHUF_TIMING)
+constexpr uint32_t kOrderTimingSlots = 8;               // u64[slots] behind those: wavefront 0 of the order kernel
+constexpr uint32_t kStatusWords = 4 + 2 * kTimingSlots * kTimingWaves + 2 * kOrderTimingSlots;
 
 // ---------------------------------------------------------------------------
 // Order kernel
@@ -70,31 +72,36 @@ struct OrderArgs {
   uint32_t num_spins, first_sweep, count;
   uint32_t level_cap, block_cap, quad_cap;  // capacities per sweep of the outputs below
   uint32_t stream_kib;                      // KiB between the coupling streams of consecutive sweeps
+  uint32_t log_s;                           // a block is S = 1 << log_s spins of one level (S = 4 .. 64)
   uint32_t lanes_per_row;                   // power of two <= 64: lanes sharing a row in the graph passes
+  uint32_t threads;                         // threads of this problem's order workgroups (a multiple of 64)
+  uint32_t lds_arrays;                      // 1: priorities, counters and the order in LDS (PeelArrays)
   uint32_t col_shift;                       // columns are written as (neighbour << col_shift): LDS addresses
   // scratch, [count][K] each
   uint32_t *prio, *indeg, *order;
   // outputs, per sweep of the chunk
   uint32_t *level_block;  // [count][level_cap + 1] first block of level l; entry [levels] = blocks
   uint32_t *num_levels;   // [count]
-  uint2 *block_meta;      // [count][block_cap] {KiB offset of the block in the sweep's stream, quads}
-  uint32_t *spin_of_pos;  // [count][block_cap * 64] scratch: kDummySpin = padding lane
-  // The sweep's couplings as ONE stream per sweep, block after block in level-major order.  A
-  // block is a 1 KiB header — spin of the lane u32[64] (kDummySpin = padding lane), 256 B unused,
-  // field of that spin f64[64] — followed by 3 KiB per quad of couplings: columns uint4[64],
-  // values double2[64] (entries 0, 1), values double2[64] (entries 2, 3); the quad layout of
-  // csrc/sa_plan.cpp.  One buffer resource and one scalar offset address all of a block.
+  uint2 *block_meta;      // [count][block_cap] {offset of the block in the sweep's stream in slabs, quads}
+  uint32_t *spin_of_pos;  // [count][block_cap * S] scratch: kDummySpin = padding lane
+  // The sweep's couplings as ONE stream per sweep, block after block in level-major order, in
+  // SLABS of 16 S bytes (1 KiB for S = 64).  A block is one header slab — per spin of the block 16
+  // bytes: its index u32 (kDummySpin = padding lane), 4 bytes unused, its field f64 — followed by
+  // three slabs per quad of couplings: columns uint4[S], values double2[S] (entries 0, 1), values
+  // double2[S] (entries 2, 3); the quad layout of csrc/sa_plan.cpp.  One buffer resource and one
+  // scalar offset address all of a block; a lane's part of a slab is ONE 16-byte load.
   uint8_t *stream;        // [count][stream_kib KiB]
   uint32_t *status;
 };
 
 // Exclusive prefix sum of a[0..n) in LDS, in place; returns the total.  All threads call it;
 // `carry` is one LDS word of scratch, `wave_tot` 16.
-__device__ uint32_t block_exclusive_scan(uint32_t *a, uint32_t n, uint32_t *wave_tot, uint32_t *carry) {
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, waves = blockDim.x >> 6;
+__device__ uint32_t block_exclusive_scan(uint32_t *a, uint32_t n, uint32_t *wave_tot, uint32_t *carry,
+                                         uint32_t nthreads) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, waves = nthreads >> 6;
   if (tid == 0) *carry = 0;
   __syncthreads();
-  for (uint32_t base = 0; base < n; base += blockDim.x) {
+  for (uint32_t base = 0; base < n; base += nthreads) {
     const uint32_t i = base + tid;
     const uint32_t v = i < n ? a[i] : 0u;
     uint32_t inc = v;
@@ -123,15 +130,68 @@ __device__ __forceinline__ bool comes_before(uint32_t pa, uint32_t a, uint32_t p
   return pa < pb || (pa == pb && a < b);
 }
 
+// The three per-spin arrays of the peel — priority, number of earlier neighbours still unvisited,
+// visiting order — in HBM scratch (clusters of any size), or IN LDS (LDSA; a.lds_arrays): 4 + 1 + 2
+// bytes per spin, counters packed four to a word (rows of at most 255 couplings), the order as
+// 16-bit indices (K < 65 536).  With the arrays in HBM every level of the peel is a chain of L2
+// round trips — read the level's spins, gather their neighbours' priorities, a device-scope
+// atomic per later neighbour —, about 4 us per level and 0.97 s of device time for the 128-problem
+// production batch (orders alone; the sweeps alone took 1.7 s): LDS atomics and gathers cut a
+// level to a fraction of a microsecond.
+template <bool LDSA>
+struct PeelArrays {
+  uint32_t *prio;
+  uint32_t *indeg;  // LDSA: bytes packed in words
+  void *order;      // LDSA: uint16_t
+  __device__ __forceinline__ uint32_t order_at(uint32_t m) const {
+    if constexpr (LDSA) return static_cast<const uint16_t *>(order)[m];
+    return static_cast<const uint32_t *>(order)[m];
+  }
+  __device__ __forceinline__ void append(uint32_t *tail, uint32_t i) const {
+    const uint32_t at = atomicAdd(tail, 1u);
+    if constexpr (LDSA) {
+      static_cast<uint16_t *>(order)[at] = static_cast<uint16_t>(i);
+    } else {
+      static_cast<uint32_t *>(order)[at] = i;
+    }
+  }
+  // (called once per spin, on zeroed words in the LDS form)
+  __device__ __forceinline__ void set_count(uint32_t i, uint32_t count) const {
+    if constexpr (LDSA) {
+      if (count) atomicAdd(indeg + (i >> 2), count << (8u * (i & 3u)));
+    } else {
+      // (relaxed device-scope store: the decrements are device-scope atomics)
+      __hip_atomic_store(indeg + i, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // one earlier neighbour of spin n has been visited: true when it was the last one
+  __device__ __forceinline__ bool visited_one(uint32_t n) const {
+    if constexpr (LDSA) {
+      const uint32_t shift = 8u * (n & 3u);
+      return ((atomicSub(indeg + (n >> 2), 1u << shift) >> shift) & 0xFFu) == 1u;
+    } else {
+      return atomicSub(indeg + n, 1u) == 1u;
+    }
+  }
+};
+
 // (`Args` is OrderArgs, or OrderArgs in the constant address space: the batched kernel reads its
 // problem's descriptor from a table, like k_sa_sweep_batch does; `s` = sweep of the chunk)
-template <typename Args>
-__device__ __forceinline__ void shuffled_orders_body(const Args &a, const uint32_t s) {
+template <bool LDSA, typename Args>
+__device__ __forceinline__ void shuffled_orders_impl(const Args &a, const uint32_t s) {
   extern __shared__ __align__(16) uint8_t lds[];
   const uint32_t K = a.num_spins;
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), waves = blockDim.x >> 6;
+  // The problem's own number of threads: in a shared launch (k_shuffled_orders_batch) the workgroups
+  // have the threads of the LARGEST problem; the wavefronts a small problem has no use for end here
+  // (a barrier waits for the surviving wavefronts of its workgroup only).
+  const uint32_t nthreads = a.threads;
+  if (tid >= nthreads) return;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), waves = nthreads >> 6;
   const uint32_t t = a.first_sweep + s;
+  // blocks of S spins: a wavefront handles 64 / S of them per pass, lane = (block of the pass, slot)
+  const uint32_t S = 1u << a.log_s, per_pass = 64u >> a.log_s;
+  const uint32_t slot = lane & (S - 1u), pass_block = lane >> a.log_s;
   // ctl: [0] tail of the order, [1..2] level ends (ping-pong), [3] carry of the scans
   uint32_t *ctl = reinterpret_cast<uint32_t *>(lds);
   uint32_t *wave_tot = ctl + 8;                         // 16
@@ -141,22 +201,44 @@ __device__ __forceinline__ void shuffled_orders_body(const Args &a, const uint32
   uint32_t *block_first = block_quads + a.block_cap + 1;  // block_cap + 1
   uint32_t *hist = block_first + a.block_cap + 1;         // waves * 64
   uint32_t *cursor = hist + waves * 64u;                  // waves * 64
-  uint32_t *prio = a.prio + static_cast<uint64_t>(s) * K;
-  uint32_t *indeg = a.indeg + static_cast<uint64_t>(s) * K;
-  uint32_t *order = a.order + static_cast<uint64_t>(s) * K;
+  PeelArrays<LDSA> peel;
+  if constexpr (LDSA) {
+    peel.prio = cursor + waves * 64u;            // K
+    peel.indeg = peel.prio + K;                  // ceil(K / 4) words of four counters
+    peel.order = peel.indeg + ((K + 3u) >> 2);   // K uint16_t
+    for (uint32_t w = tid; w < ((K + 3u) >> 2); w += nthreads) peel.indeg[w] = 0u;
+  } else {
+    peel.prio = a.prio + static_cast<uint64_t>(s) * K;
+    peel.indeg = a.indeg + static_cast<uint64_t>(s) * K;
+    peel.order = a.order + static_cast<uint64_t>(s) * K;
+  }
+  uint32_t *prio = peel.prio;
   const uint32_t key0 = static_cast<uint32_t>(a.seed), key1 = static_cast<uint32_t>(a.seed >> 32);
+#if ASP_SHUF_TIMING
+  unsigned long long oticks[kOrderTimingSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long otick_last = __builtin_readcyclecounter();
+#define ASP_OTICK(slot)                                             \
+  do {                                                              \
+    const unsigned long long now_ = __builtin_readcyclecounter();   \
+    oticks[slot] += now_ - otick_last;                              \
+    otick_last = now_;                                              \
+  } while (0)
+#else
+#define ASP_OTICK(slot) do {} while (0)
+#endif
 
   // ---- 1. priorities ----
-  for (uint32_t i = tid; i < K; i += blockDim.x) {
+  for (uint32_t i = tid; i < K; i += nthreads) {
     prio[i] = philox4x32_10(i, t, kPriorityCounter, 0u, key0, key1).w[0];
   }
   if (tid == 0) ctl[0] = 0;
   __syncthreads();
+  ASP_OTICK(0);
 
   // ---- 2. number of earlier neighbours; spins without any open level 0 ----
   // G lanes share a row: one quad of four neighbours per lane and trip
   const uint32_t G = a.lanes_per_row;
-  const uint32_t sub = tid & (G - 1u), gid = tid / G, groups = blockDim.x / G;
+  const uint32_t sub = tid & (G - 1u), gid = tid / G, groups = nthreads / G;
   for (uint32_t i = gid; i < K; i += groups) {
     const uint32_t pi = prio[i];
     const uint32_t q1 = a.rq_ptr[i + 1];
@@ -171,9 +253,8 @@ __device__ __forceinline__ void shuffled_orders_body(const Args &a, const uint32
     }
     for (uint32_t step = G >> 1; step > 0; step >>= 1) count += __shfl_xor(count, step, 64);
     if (sub == 0) {
-      // (relaxed device-scope store: the decrements below are device-scope atomics)
-      __hip_atomic_store(indeg + i, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (count == 0) order[atomicAdd(&ctl[0], 1u)] = i;
+      peel.set_count(i, count);
+      if (count == 0) peel.append(&ctl[0], i);
     }
   }
   __syncthreads();
@@ -184,12 +265,13 @@ __device__ __forceinline__ void shuffled_orders_body(const Args &a, const uint32
   }
   __syncthreads();
 
+  ASP_OTICK(1);
   // ---- 3. peel the levels ----
   uint32_t begin = 0, end = ctl[1], levels = 0;
   while (begin < end) {
     ++levels;
     for (uint32_t m = begin + gid; m < end; m += groups) {
-      const uint32_t i = order[m];
+      const uint32_t i = peel.order_at(m);
       const uint32_t pi = prio[i];
       const uint32_t q1 = a.rq_ptr[i + 1];
       for (uint32_t q = a.rq_ptr[i] + sub; q < q1; q += G) {
@@ -199,7 +281,7 @@ __device__ __forceinline__ void shuffled_orders_body(const Args &a, const uint32
         for (int j = 0; j < 4; ++j) {
           const uint32_t n = cs[j];
           if (n != i && comes_before(pi, i, prio[n], n)) {
-            if (atomicSub(indeg + n, 1u) == 1u) order[atomicAdd(&ctl[0], 1u)] = n;
+            if (peel.visited_one(n)) peel.append(&ctl[0], n);
           }
         }
       }
@@ -217,16 +299,17 @@ __device__ __forceinline__ void shuffled_orders_body(const Args &a, const uint32
   const uint32_t L = levels;
   bool bad = L > a.level_cap;
 
+  ASP_OTICK(2);
   // ---- 4. blocks of the levels ----
   if (!bad) {
-    for (uint32_t l = tid; l < L; l += blockDim.x) {
-      level_block[l] = (level_start[l + 1] - level_start[l] + 63u) >> 6;
+    for (uint32_t l = tid; l < L; l += nthreads) {
+      level_block[l] = (level_start[l + 1] - level_start[l] + S - 1u) >> a.log_s;
     }
     __syncthreads();
   }
   uint32_t B = 0;
   if (!bad) {
-    B = block_exclusive_scan(level_block, L, wave_tot, ctl + 3);
+    B = block_exclusive_scan(level_block, L, wave_tot, ctl + 3, nthreads);
     if (tid == 0) level_block[L] = B;
     __syncthreads();
     bad = B > a.block_cap;
@@ -241,20 +324,21 @@ __device__ __forceinline__ void shuffled_orders_body(const Args &a, const uint32
     return;
   }
 
+  ASP_OTICK(3);
   // ---- 5. every level sorted by descending row length (counting sort, a wavefront per level) ----
-  uint32_t *sop = a.spin_of_pos + static_cast<uint64_t>(s) * a.block_cap * 64u;
+  uint32_t *sop = a.spin_of_pos + (static_cast<uint64_t>(s) * a.block_cap << a.log_s);
   for (uint32_t base = 0; base < L; base += waves) {
     const uint32_t l = base + wave;
     uint32_t lo = 0, n = 0, pos0 = 0;
     if (l < L) {
       lo = level_start[l];
       n = level_start[l + 1] - lo;
-      pos0 = level_block[l] * 64u;
+      pos0 = level_block[l] << a.log_s;
     }
     hist[wave * 64u + lane] = 0;
     __syncthreads();
     for (uint32_t m = lane; m < n; m += 64u) {
-      const uint32_t i = order[lo + m];
+      const uint32_t i = peel.order_at(lo + m);
       const uint32_t cls = min(a.rq_ptr[i + 1] - a.rq_ptr[i], kClassCap);
       atomicAdd(&hist[wave * 64u + cls], 1u);
     }
@@ -271,28 +355,33 @@ __device__ __forceinline__ void shuffled_orders_body(const Args &a, const uint32
     }
     __syncthreads();
     for (uint32_t m = lane; m < n; m += 64u) {
-      const uint32_t i = order[lo + m];
+      const uint32_t i = peel.order_at(lo + m);
       const uint32_t cls = min(a.rq_ptr[i + 1] - a.rq_ptr[i], kClassCap);
       sop[pos0 + atomicAdd(&cursor[wave * 64u + cls], 1u)] = i;
     }
-    for (uint32_t m = n + lane; m < ((n + 63u) & ~63u); m += 64u) sop[pos0 + m] = kDummySpin;
+    for (uint32_t m = n + lane; m < ((n + S - 1u) & ~(S - 1u)); m += 64u) sop[pos0 + m] = kDummySpin;
     __syncthreads();
   }
 
+  ASP_OTICK(4);
   // ---- 6. block widths and their prefix sum ----
-  for (uint32_t b = wave; b < B; b += waves) {
-    const uint32_t i = sop[b * 64u + lane];
+  for (uint32_t b0 = wave * per_pass; b0 < B; b0 += waves * per_pass) {
+    const uint32_t b = b0 + pass_block;
+    const uint32_t i = b < B ? sop[(b << a.log_s) + slot] : kDummySpin;
     uint32_t w = i == kDummySpin ? 0u : a.rq_ptr[i + 1] - a.rq_ptr[i];
 #pragma unroll
-    for (int step = 1; step < 64; step <<= 1) w = max(w, static_cast<uint32_t>(__shfl_xor(w, step, 64)));
-    if (lane == 0) {
+    for (int step = 1; step < 64; step <<= 1) {  // maximum over the S lanes of the block
+      const uint32_t o = static_cast<uint32_t>(__shfl_xor(w, step, 64));
+      if (static_cast<uint32_t>(step) < S) w = max(w, o);
+    }
+    if (slot == 0 && b < B) {
       block_quads[b] = w;
-      block_first[b] = 1u + 3u * w;  // KiB of the block: header + quads
+      block_first[b] = 1u + 3u * w;  // slabs of the block: header + quads
     }
   }
   __syncthreads();
-  const uint32_t kib = block_exclusive_scan(block_first, B, wave_tot, ctl + 3);
-  const uint32_t Q = (kib - B) / 3u;
+  const uint32_t slabs = block_exclusive_scan(block_first, B, wave_tot, ctl + 3, nthreads);
+  const uint32_t Q = (slabs - B) / 3u;
   if (Q > a.quad_cap) {
     if (tid == 0) {
       atomicMax(a.status + kStatQuads, Q);
@@ -302,19 +391,31 @@ __device__ __forceinline__ void shuffled_orders_body(const Args &a, const uint32
     return;
   }
 
+  ASP_OTICK(5);
   // ---- 7. the sweep's coupling stream ----
   uint8_t *stream = a.stream + static_cast<uint64_t>(s) * a.stream_kib * 1024u;
-  for (uint32_t b = wave; b < B; b += waves) {
-    const uint32_t i = sop[b * 64u + lane];
+  const uint32_t slab_bytes = 16u << a.log_s;
+  for (uint32_t b0 = wave * per_pass; b0 < B; b0 += waves * per_pass) {
+    const uint32_t b = b0 + pass_block;
+    const bool live = b < B;
+    const uint32_t i = live ? sop[(b << a.log_s) + slot] : kDummySpin;
     const bool real = i != kDummySpin;
     const uint32_t row = real ? a.rq_ptr[i] : 0u;
     const uint32_t mine = real ? a.rq_ptr[i + 1] - row : 0u;
     const uint32_t own = real ? i << a.col_shift : 0u;  // padding reads the lane's own spin (x +0.0)
-    const uint32_t quads = block_quads[b];
-    uint8_t *block = stream + static_cast<uint64_t>(block_first[b]) * 1024u;
-    reinterpret_cast<uint32_t *>(block)[lane] = i;
-    reinterpret_cast<double *>(block + 512)[lane] = real ? a.field[i] : 0.0;
-    for (uint32_t q = 0; q < quads; ++q) {
+    const uint32_t quads = live ? block_quads[b] : 0u;
+    uint32_t most = quads;  // the widest block of the pass
+#pragma unroll
+    for (int step = 1; step < 64; step <<= 1) most = max(most, static_cast<uint32_t>(__shfl_xor(most, step, 64)));
+    uint8_t *block = stream + static_cast<uint64_t>(live ? block_first[b] : 0u) * slab_bytes;
+    if (live) {
+      const double h = real ? a.field[i] : 0.0;
+      const unsigned long long hb = static_cast<unsigned long long>(__double_as_longlong(h));
+      reinterpret_cast<uint4 *>(block)[slot] =
+          make_uint4(i, 0u, static_cast<uint32_t>(hb), static_cast<uint32_t>(hb >> 32));
+    }
+    for (uint32_t q = 0; q < most; ++q) {
+      if (!live || q >= quads) continue;
       uint4 c = make_uint4(own, own, own, own);
       double2 v01 = make_double2(0.0, 0.0), v23 = make_double2(0.0, 0.0);
       if (q < mine) {
@@ -327,23 +428,40 @@ __device__ __forceinline__ void shuffled_orders_body(const Args &a, const uint32
         v01 = a.rq_val[static_cast<uint64_t>(row + q) * 2u];
         v23 = a.rq_val[static_cast<uint64_t>(row + q) * 2u + 1u];
       }
-      uint8_t *quad = block + 1024u + static_cast<uint64_t>(q) * 3072u;
-      reinterpret_cast<uint4 *>(quad)[lane] = c;
-      reinterpret_cast<double2 *>(quad + 1024)[lane] = v01;
-      reinterpret_cast<double2 *>(quad + 2048)[lane] = v23;
+      uint8_t *quad = block + static_cast<uint64_t>(1u + 3u * q) * slab_bytes;
+      reinterpret_cast<uint4 *>(quad)[slot] = c;
+      reinterpret_cast<double2 *>(quad + slab_bytes)[slot] = v01;
+      reinterpret_cast<double2 *>(quad + 2u * slab_bytes)[slot] = v23;
     }
   }
 
+  ASP_OTICK(6);
   // ---- 8. the sweep's tables ----
   uint32_t *out_lb = a.level_block + static_cast<uint64_t>(s) * (a.level_cap + 1u);
-  for (uint32_t l = tid; l <= L; l += blockDim.x) out_lb[l] = level_block[l];
+  for (uint32_t l = tid; l <= L; l += nthreads) out_lb[l] = level_block[l];
   uint2 *out_meta = a.block_meta + static_cast<uint64_t>(s) * a.block_cap;
-  for (uint32_t b = tid; b < B; b += blockDim.x) out_meta[b] = make_uint2(block_first[b], block_quads[b]);
+  for (uint32_t b = tid; b < B; b += nthreads) out_meta[b] = make_uint2(block_first[b], block_quads[b]);
   if (tid == 0) {
     a.num_levels[s] = L;
     atomicMax(a.status + kStatLevels, L);
     atomicMax(a.status + kStatBlocks, B);
     atomicMax(a.status + kStatQuads, Q);
+  }
+  ASP_OTICK(7);
+#if ASP_SHUF_TIMING
+  if (tid == 0) {
+    unsigned long long *out = reinterpret_cast<unsigned long long *>(a.status + kStatWords) + kTimingSlots * kTimingWaves;
+    for (uint32_t k = 0; k < kOrderTimingSlots; ++k) atomicAdd(out + k, oticks[k]);
+  }
+#endif
+}
+
+template <typename Args>
+__device__ __forceinline__ void shuffled_orders_body(const Args &a, const uint32_t s) {
+  if (a.lds_arrays) {
+    shuffled_orders_impl<true>(a, s);
+  } else {
+    shuffled_orders_impl<false>(a, s);
   }
 }
 
@@ -380,6 +498,11 @@ struct ShuffledArgs {
   double scale;
   uint32_t num_spins, words, level_cap, block_cap, stream_kib;
   uint32_t first_sweep, chunk_sweeps, replica_first, initialise;
+  // lane packing (kernels with PK = true): a block is S = 1 << log_s spins and a wavefront visits
+  // it for G = 64 / S groups of M chains at once, lane = (group, spin); a workgroup holds the spins
+  // of its G groups.  groups_total: groups of the whole call (the last workgroup may have fewer).
+  uint32_t log_s, groups_total;
+  uint32_t waves;  // wavefronts (per team) of this problem's workgroups
 };
 
 // Spins stay in LDS in ORIGINAL order, in one of four layouts: a 32-bit word per spin (kWide: byte
@@ -421,9 +544,9 @@ __device__ __forceinline__ uint32_t from_lds(uint32_t v) {
 
 template <int M, int LAYOUT, typename Args>
 __device__ __forceinline__ void snapshot_original(const uint8_t *spins, const Args &a,
-                                                  uint32_t group, uint32_t mask) {
+                                                  uint32_t group, uint32_t mask, uint32_t nthreads) {
   const uint32_t lane = threadIdx.x & 63u;
-  for (uint32_t w = threadIdx.x >> 6; w < a.words; w += blockDim.x >> 6) {
+  for (uint32_t w = threadIdx.x >> 6; w < a.words; w += nthreads >> 6) {
     const uint32_t i = w * 64u + lane;
     uint32_t neg = (1u << M) - 1u;
     if (i < a.num_spins) {
@@ -469,14 +592,25 @@ __device__ __forceinline__ void load_quad_buffer(HeldQuad &q, BufferRsrc stream,
   q.v01 = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(stream, lane16 + 1024u, at, 0));
   q.v23 = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(stream, lane16 + 2048u, at, 0));
 }
+// Blocks of S < 64 spins (lane packing): the three slabs of a quad are `slab` = 16 S bytes apart —
+// scalar offsets, one vector offset (slot * 16); the groups of a wavefront read the same bytes
+__device__ __forceinline__ void load_quad_slabs(HeldQuad &q, BufferRsrc stream, uint32_t at, uint32_t lane16,
+                                                uint32_t slab) {
+  q.c = __builtin_amdgcn_raw_buffer_load_b128(stream, lane16, at, 0);
+  q.v01 = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(stream, lane16, at + slab, 0));
+  q.v23 = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(stream, lane16, at + 2u * slab, 0));
+}
 
-template <int LAYOUT>
-__device__ __forceinline__ void gather_quad(const HeldQuad &q, uint32_t (&s)[4]) {
+// (`gbase`, lane packing only: LDS byte address of the spins of the lane's group)
+template <int LAYOUT, bool PK = false>
+__device__ __forceinline__ void gather_quad(const HeldQuad &q, uint32_t (&s)[4], uint32_t gbase = 0) {
   const uint32_t cs[4] = {q.c.x, q.c.y, q.c.z, q.c.w};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     // columns are LDS byte addresses (sa_device.hpp: the spins start at LDS address 0)
-    if constexpr (LAYOUT == kWide) {
+    if constexpr (LAYOUT == kWide && PK) {
+      s[j] = *reinterpret_cast<LdsWord *>(static_cast<uintptr_t>(cs[j] + gbase));
+    } else if constexpr (LAYOUT == kWide) {
       s[j] = *reinterpret_cast<LdsWord *>(static_cast<uintptr_t>(cs[j]));
     } else if constexpr (LAYOUT == kNibbles) {  // (packed layouts: the column is the spin's index)
       s[j] = static_cast<uint32_t>(*reinterpret_cast<LdsByte *>(static_cast<uintptr_t>(cs[j] >> 1))) >>
@@ -567,7 +701,21 @@ __device__ __forceinline__ void apply_quad(const HeldQuad &q, const uint32_t (&s
 #endif
 
 constexpr uint32_t kNoBlock = 0xFFFFFFFFu;
-constexpr int kHeldQuads = 12;  // quads of a block kept in registers (wider blocks stream the rest)
+#ifndef ASP_SHUF_HELD_QUADS
+#define ASP_SHUF_HELD_QUADS 12
+#endif
+// quads of a block kept in registers (wider blocks stream the rest).  Scanned in round 4 on the
+// production batch and on K = 1e4 x 1024 chains (-DASP_SHUF_HELD_QUADS=6/8/10/12): fewer held quads
+// free registers (10: the order kernel fits beside two sweep wavefronts per SIMD; 6: three sweep
+// wavefronts per SIMD) but every step down lengthens a visit, 22.3 / 25.1 / 27.8 / 31.6 ms for
+// 12 / 10 / 8 / 6 on the single cluster.
+constexpr int kHeldQuads = ASP_SHUF_HELD_QUADS;
+#ifndef ASP_SHUF_FIRST_QUADS
+#define ASP_SHUF_FIRST_QUADS 6
+#endif
+// quads of the next block requested BEFORE the accept phase (the rest after it: what is requested
+// late must land during the level barrier, so as much as the miss queue takes goes out early)
+constexpr int kFirstQuads = ASP_SHUF_FIRST_QUADS < kHeldQuads ? ASP_SHUF_FIRST_QUADS : kHeldQuads;
 
 // The loads of a block do not depend on the spins, so a wavefront fetches its NEXT block — of this
 // level or of the next one — while it finishes the current one: the quads of the next block are
@@ -581,16 +729,27 @@ constexpr int kHeldQuads = 12;  // quads of a block kept in registers (wider blo
 // level on half the instructions per visit.  Built to test whether a visit is bound by the issue
 // rate of its lone wavefront; it is not (the fill rate from L2 binds: DESIGN.md §4.9), and this
 // form is slower.  Kept because it is cheap and its parity is tested.
-template <int M, int LAYOUT, int TEAMS, typename Args>
-__device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_t group) {
+// PK = true (lane packing, wide layout only): a block of the order kernel is S = 1 << log_s < 64
+// spins and a wavefront visits it for G = 64 / S groups of M chains at once — lane = (group,
+// spin) —, so that a level of a handful of spins (clusters of 1e2 .. 3e3 spins: 3 .. 40 spins
+// per level) fills its wavefront with CHAINS instead of padding lanes.  The workgroup holds the
+// spins of its G groups (group g at LDS byte address g K 4); the G groups of a wavefront read
+// the same bytes of the coupling stream (one request per address), a neighbour's LDS address is
+// column + base of the lane's group (one VALU add per gather), the energy bookkeeping is
+// reduced over the S lanes of a group.  Everything else — arithmetic, random words, the order
+// of the terms — is the lane = spin kernel's; every chain is bit for bit the same.
+template <int M, int LAYOUT, int TEAMS, bool PK, typename Args>
+__device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_t wg) {
   constexpr bool WIDE = LAYOUT == kWide;
-  constexpr int MT = M * TEAMS;  // chains of the workgroup
+  constexpr int MT = M * TEAMS;  // chains of a group
   constexpr bool PACKED = kPackedLayout<LAYOUT>;
   static_assert(LAYOUT == kWide || LAYOUT == kBytes || PACKED, "spins are LDS words, bytes, nibbles or bits");
   static_assert(!WIDE || MT <= 4, "the wide layout holds up to four chains");
   static_assert(!PACKED || (TEAMS == 1 && M <= static_cast<int>(kSpinBits<LAYOUT>)),
                 "a packed layout holds as many chains as it has bits per spin, in one team");
   static_assert(MT <= 8 && (TEAMS == 1 || TEAMS == 2), "a byte holds eight chains");
+  static_assert(!PK || (WIDE && TEAMS == 1), "lane packing: wide layout, one team");
+  constexpr uint32_t CH = PK ? 64u : 8u;  // chains of a workgroup the bookkeeping arrays hold
   extern __shared__ __align__(16) uint8_t lds[];
   if (a.status[kStatBad] != 0u) return;  // an order kernel ran out of room: the host repeats the call
 #if ASP_ABS_LDS
@@ -599,78 +758,100 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
   }
 #endif
   const uint32_t K = a.num_spins;
-  uint8_t *spins = lds;  // original order: K words (byte m = 0x80 * chain m is -1) or K bytes
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  // The problem's own wavefronts: in a shared launch (k_sa_sweep_shuffled_batch) the workgroups have
+  // the wavefronts of the problem that wants the most; the ones this problem has no use for end
+  // here (a barrier waits for the surviving wavefronts of its workgroup only).
+  const uint32_t nthreads = a.waves * 64u * TEAMS;
+  if (tid >= nthreads) return;
+  const uint32_t log_s = PK ? a.log_s : 6u;
+  const uint32_t G = 64u >> log_s;                         // groups of the workgroup
+  const uint32_t slot = lane & ((1u << log_s) - 1u);       // the lane's spin slot inside a block
+  const uint32_t lg = PK ? lane >> log_s : 0u;             // the lane's group inside the workgroup
+  const uint32_t group = wg * G + lg;                      // ... and inside the call
+  const bool group_live = !PK || group < a.groups_total;   // (the last workgroup may have idle groups)
+  const uint32_t gbase = PK ? lg * K * 4u : 0u;            // LDS byte address of the group's spins
+  uint8_t *spins = lds;  // original order: K words (byte m = 0x80 * chain m is -1) or K bytes, per group
   uint32_t *wide = reinterpret_cast<uint32_t *>(lds);
-  const uint32_t P = ((WIDE ? K * 4u : (PACKED ? (K * kSpinBits<LAYOUT> + 7u) / 8u : K)) + 15u) & ~15u;
-  long long *delta = reinterpret_cast<long long *>(lds + P);  // [8] energy change of the running sweep
-  long long *book = delta + 8;  // [m] current tracked energy, [8 + m] best, [16 + m] accepted flips
-  uint32_t *improved_flag = reinterpret_cast<uint32_t *>(book + 24);
+  const uint32_t P = ((WIDE ? G * K * 4u : (PACKED ? (K * kSpinBits<LAYOUT> + 7u) / 8u : K)) + 15u) & ~15u;
+  long long *delta = reinterpret_cast<long long *>(lds + P);  // [CH] energy change of the running sweep
+  long long *book = delta + CH;  // [c] current tracked energy, [CH + c] best, [2 CH + c] accepted flips
+  uint32_t *improved_flag = reinterpret_cast<uint32_t *>(book + 3 * CH);  // [2] bit c: chain c improved
   // the running sweep's tables, copied from HBM once per sweep (they were written by another
   // kernel, possibly on another XCD: a scalar load of one entry is a full memory round trip,
   // and the level loop would pay two of them per level)
   uint2 *meta = reinterpret_cast<uint2 *>(improved_flag + 4);             // [block_cap]
   uint32_t *level_block = reinterpret_cast<uint32_t *>(meta + a.block_cap);  // [level_cap + 2]
-  const uint32_t tid = threadIdx.x, lane = tid & 63u;
   // (`wave` / `waves`: this wavefront's index inside its team and the team's size)
-  const uint32_t all_waves = blockDim.x >> 6, waves = all_waves / TEAMS;
+  const uint32_t waves = a.waves;
   const uint32_t team = TEAMS == 1 ? 0u : __builtin_amdgcn_readfirstlane(tid >> 6) / waves;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6) - team * waves;
-  const uint32_t r0 = a.replica_first + group * MT;  // first chain of the group
+  const uint32_t r0 = a.replica_first + group * MT;  // first chain of the (lane's) group
   const uint32_t c0 = team * M;                      // first chain of this wavefront's team
   // this team's chains inside a spin's LDS word (byte per chain) or byte (bit per chain)
   const uint32_t team_shift = team * (WIDE ? 8u * M : static_cast<uint32_t>(M));
   const uint32_t key0 = static_cast<uint32_t>(a.seed), key1 = static_cast<uint32_t>(a.seed >> 32);
-  uint8_t *state = a.state + static_cast<uint64_t>(group) * K;
+  const uint64_t first_chain = static_cast<uint64_t>(wg) * G * MT;  // of the workgroup, in the call's arrays
+  const uint64_t chains_total = PK ? static_cast<uint64_t>(a.groups_total) * MT : ~0ull;
 
   // ---- chain state: fresh, or where the previous chunk left it ----
   if constexpr (PACKED) {  // spins of different threads share a word: OR them into zeroed words
-    for (uint32_t w = tid; w < P / 4u; w += blockDim.x) wide[w] = 0u;
+    for (uint32_t w = tid; w < P / 4u; w += nthreads) wide[w] = 0u;
     __syncthreads();
   }
-  for (uint32_t i = tid; i < K; i += blockDim.x) {
-    uint32_t mask;
-    if (!a.initialise) {
-      mask = state[i];
-    } else if (a.x0 != nullptr) {
-      mask = ((a.x0[i >> 6] >> (i & 63u)) & 1ull) ? 0u : ((1u << MT) - 1u);
-    } else {
-      mask = 0;
-      Philox4 rnd{};
-      uint32_t have = 0xFFFFFFFFu;
+  for (uint32_t g = 0; g < G; ++g) {
+    const uint32_t gg = wg * G + g;
+    const bool live = !PK || gg < a.groups_total;  // (workgroup-uniform)
+    const uint8_t *state_g = a.state + static_cast<uint64_t>(gg) * K;
+    const uint32_t r0g = a.replica_first + gg * MT;
+    for (uint32_t i = tid; i < K; i += nthreads) {
+      uint32_t mask;
+      if (!live) {
+        mask = 0;
+      } else if (!a.initialise) {
+        mask = state_g[i];
+      } else if (a.x0 != nullptr) {
+        mask = ((a.x0[i >> 6] >> (i & 63u)) & 1ull) ? 0u : ((1u << MT) - 1u);
+      } else {
+        mask = 0;
+        Philox4 rnd{};
+        uint32_t have = 0xFFFFFFFFu;
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const uint32_t r = r0 + m;
-        if (m == 0 || (r >> 2) != have) {
-          have = r >> 2;
-          rnd = philox4x32_10(i, 0xFFFFFFFFu, have, 0u, key0, key1);
+        for (int m = 0; m < MT; ++m) {
+          const uint32_t r = r0g + m;
+          if (m == 0 || (r >> 2) != have) {
+            have = r >> 2;
+            rnd = philox4x32_10(i, 0xFFFFFFFFu, have, 0u, key0, key1);
+          }
+          mask |= ((pick_word(rnd, r & 3u) & 1u) ^ 1u) << m;  // bit 0 of the word: 1 -> s = +1
         }
-        mask |= ((pick_word(rnd, r & 3u) & 1u) ^ 1u) << m;  // bit 0 of the word: 1 -> s = +1
+      }
+      if constexpr (WIDE) {
+        wide[g * K + i] = spread_mask(mask);
+      } else if constexpr (PACKED) {
+        constexpr uint32_t B = kSpinBits<LAYOUT>;
+        if (mask) atomicOr(wide + ((i * B) >> 5), mask << ((i * B) & 31u));
+      } else {
+        spins[i] = static_cast<uint8_t>(mask);
       }
     }
-    if constexpr (WIDE) {
-      wide[i] = spread_mask(mask);
-    } else if constexpr (PACKED) {
-      constexpr uint32_t B = kSpinBits<LAYOUT>;
-      if (mask) atomicOr(wide + ((i * B) >> 5), mask << ((i * B) & 31u));
-    } else {
-      spins[i] = static_cast<uint8_t>(mask);
-    }
   }
-  if (tid < 32) {
+  for (uint32_t x = tid; x < 4u * CH; x += nthreads) {  // delta[CH] | book[3 CH]
     long long v = 0;
-    if (!a.initialise && tid >= 8) {
-      const uint32_t m = tid & 7u;
-      if (m < MT) {
-        const uint64_t at = static_cast<uint64_t>(group) * MT + m;
-        v = tid < 16 ? a.e_cur[at] : (tid < 24 ? a.e_best[at] : static_cast<long long>(a.accepted[at]));
-      }
+    const uint32_t c = x & (CH - 1u), which = x / CH;
+    const uint64_t at = first_chain + c;
+    if (!a.initialise && which >= 1u && c < G * MT && at < chains_total) {
+      v = which == 1u ? a.e_cur[at] : (which == 2u ? a.e_best[at] : static_cast<long long>(a.accepted[at]));
     }
-    delta[tid] = v;  // delta[8] | book[24]
+    delta[x] = v;
   }
-  if (tid == 0) *improved_flag = 0;
+  if (tid < 2) improved_flag[tid] = 0;
   __syncthreads();
   if (a.initialise) {
-    snapshot_original<MT, LAYOUT>(spins, a, group, (1u << MT) - 1u);
+    for (uint32_t g = 0; g < G; ++g) {
+      if (PK && wg * G + g >= a.groups_total) break;
+      snapshot_original<MT, LAYOUT>(spins + (PK ? g * K * 4u : 0u), a, wg * G + g, (1u << MT) - 1u, nthreads);
+    }
     __syncthreads();
   }
 
@@ -679,6 +860,9 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
   unsigned long long ticks[kTimingSlots] = {0, 0, 0, 0, 0, 0};
   unsigned long long tick_last = __builtin_readcyclecounter();
 #endif
+  // byte offsets of a lane inside the three slabs of a quad (lane packing: slabs of 16 S bytes)
+  const uint32_t lane16 = slot * 16u;
+  const uint32_t slab_bytes = 16u << log_s;
   for (uint32_t tt = 0; tt < a.chunk_sweeps; ++tt) {
     const uint32_t t = a.first_sweep + tt;
     const double beta = a.betas[t];
@@ -686,9 +870,9 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
     {
       const uint32_t *g_level_block = a.level_block + static_cast<uint64_t>(tt) * (a.level_cap + 1u);
       const uint2 *g_meta = a.block_meta + static_cast<uint64_t>(tt) * a.block_cap;
-      for (uint32_t l = tid; l <= levels; l += blockDim.x) level_block[l] = g_level_block[l];
+      for (uint32_t l = tid; l <= levels; l += nthreads) level_block[l] = g_level_block[l];
       const uint32_t blocks = g_level_block[levels];
-      for (uint32_t b = tid; b < blocks; b += blockDim.x) meta[b] = g_meta[b];
+      for (uint32_t b = tid; b < blocks; b += nthreads) meta[b] = g_meta[b];
       __syncthreads();  // (the previous sweep's last use of the tables is behind its final barriers)
     }
     const BufferRsrc stream = make_rsrc(a.stream + static_cast<uint64_t>(tt) * a.stream_kib * 1024u);
@@ -704,7 +888,6 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
     uint32_t held_quads = 0, held_spin = kDummySpin, held_first = 0;
     double held_h = 0.0;
     HeldQuad hq[kHeldQuads];
-    const uint32_t lane16 = lane * 16u;
     // Requests block `nb`: what does not depend on other loads, in two instalments — a compute
     // unit keeps only so many cache misses in flight (a burst of 36 KiB per wavefront stalls the
     // issuing wavefront until the queue drains), so the header and the first half of the quads go
@@ -712,11 +895,18 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
     // (re)defined by every request — those beyond the block's width with "any value" — so that
     // nothing of the previous block stays live across the visit; ONE call site each inside the
     // loops, so that the registers of the quads are not duplicated.
+    auto load_quad_at = [&](HeldQuad &q, uint32_t j) {  // quad j of the held block
+      if constexpr (PK) {
+        load_quad_slabs(q, stream, held_first + (1u + 3u * j) * slab_bytes, lane16, slab_bytes);
+      } else {
+        load_quad_buffer(q, stream, held_first + 1024u + j * 3072u, lane16);
+      }
+    };
     auto request_quads = [&](int lo, int hi) {
 #pragma unroll
       for (int j = lo; j < hi; ++j) {
         if (ASP_SHUF_ABL != 3 && static_cast<uint32_t>(j) < held_quads) {
-          load_quad_buffer(hq[j], stream, held_first + 1024u + static_cast<uint32_t>(j) * 3072u, lane16);
+          load_quad_at(hq[j], static_cast<uint32_t>(j));
         } else {
           hq[j].c = __builtin_nondeterministic_value(hq[j].c);
           hq[j].v01 = __builtin_nondeterministic_value(hq[j].v01);
@@ -731,13 +921,15 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
       } else {
         const uint2 info = meta[nb];
         held_quads = __builtin_amdgcn_readfirstlane(info.y);
-        held_first = __builtin_amdgcn_readfirstlane(info.x) << 10;  // byte offset of the block
-        held_spin = __builtin_amdgcn_raw_buffer_load_b32(stream, lane * 4u, held_first, 0);
-        held_h = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(stream, 512u + lane * 8u, held_first, 0));
+        held_first = __builtin_amdgcn_readfirstlane(info.x) << (4u + log_s);  // byte offset of the block
+        // the header slab: {spin of the lane, -, field of that spin} in one 16-byte load
+        const u32x4 head = __builtin_amdgcn_raw_buffer_load_b128(stream, lane16, held_first, 0);
+        held_spin = head.x;
+        held_h = __hiloint2double(static_cast<int>(head.w), static_cast<int>(head.z));
       }
-      request_quads(0, kHeldQuads / 2);
+      request_quads(0, kFirstQuads);
     };
-    auto request_rest = [&]() { request_quads(kHeldQuads / 2, kHeldQuads); };
+    auto request_rest = [&]() { request_quads(kFirstQuads, kHeldQuads); };
     uint32_t lb_begin = level_block[0];
     uint32_t lb_end = level_block[levels ? 1u : 0u];
     {
@@ -761,7 +953,7 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
           if (nb >= lb_after) nb = kNoBlock;
         }
         const uint32_t spin = held_spin;
-        const bool valid = spin != kDummySpin;
+        const bool valid = spin != kDummySpin && group_live;
         const uint32_t me = valid ? spin : 0u;
         const double h = held_h;
         double acc[M];
@@ -773,11 +965,11 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
           // oracle's); the LDS gather of quad j + 1 is issued before the FMAs of quad j (past the
           // block's last quad it reads whatever the registers held: harmless, never applied)
           uint32_t sa[4], sb[4];
-          gather_quad<LAYOUT>(hq[0], sa);
+          gather_quad<LAYOUT, PK>(hq[0], sa, gbase);
 #pragma unroll
           for (int j = 0; j < kHeldQuads; ++j) {
             if (static_cast<uint32_t>(j) < quads) {
-              if (j + 1 < kHeldQuads) gather_quad<LAYOUT>(hq[j + 1], (j & 1) ? sa : sb);
+              if (j + 1 < kHeldQuads) gather_quad<LAYOUT, PK>(hq[j + 1], (j & 1) ? sa : sb, gbase);
               __builtin_amdgcn_sched_barrier(0);
               if constexpr (TEAMS > 1) {  // this team's chains to the low end (a plain VOP2 shift)
 #pragma unroll
@@ -790,12 +982,12 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
             // a block wider than the registers hold (rows of more than 4 kHeldQuads couplings):
             // the rest streams with one quad in flight
             HeldQuad qa, qb;
-            load_quad_buffer(qa, stream, held_first + 1024u + kHeldQuads * 3072u, lane16);
+            load_quad_at(qa, kHeldQuads);
             for (uint32_t j = kHeldQuads; j < quads; ++j) {
               // (one quad past the block at the end: never used)
-              load_quad_buffer(qb, stream, held_first + 1024u + (j + 1u) * 3072u, lane16);
+              load_quad_at(qb, j + 1u);
               __builtin_amdgcn_sched_barrier(0);
-              gather_quad<LAYOUT>(qa, sa);
+              gather_quad<LAYOUT, PK>(qa, sa, gbase);
               if constexpr (TEAMS > 1) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) sa[k] >>= team_shift;
@@ -815,7 +1007,7 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
         ASP_TICK(1);
         if (busy && ASP_SHUF_ABL != 2) {
           // (this team's chains only: the partner team owns the other half of the word / byte)
-          const uint32_t own = read_spin<LAYOUT>(spins, me) >> team_shift;
+          const uint32_t own = PK ? wide[(gbase >> 2) + me] : read_spin<LAYOUT>(spins, me) >> team_shift;
           bool need = false;  // some proposal of this lane needs a random number
           double de[M];
 #pragma unroll
@@ -872,7 +1064,7 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
                 reinterpret_cast<uint8_t *>(wide + me)[team] = static_cast<uint8_t>(own ^ spread_mask(flip));
               }
             } else if constexpr (WIDE) {
-              wide[me] = own ^ spread_mask(flip);
+              wide[(gbase >> 2) + me] = own ^ spread_mask(flip);
             } else if constexpr (PACKED) {
               // other lanes own the other spins of the word and may flip in the same instruction
               constexpr uint32_t B = kSpinBits<LAYOUT>;
@@ -901,75 +1093,105 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
     }
 
     // ---- exact (integer) reduction of the sweep's energy change ----
+    // (lane packing: over the S lanes of the lane's group; else over the wavefront)
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-      const long long v = wave_sum_i64(q_acc[m]);
-      const long long n = wave_sum_i64(static_cast<long long>(n_acc[m]));
-      if (lane == 0 && n != 0) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(&delta[c0 + m]), static_cast<unsigned long long>(v));
-        atomicAdd(reinterpret_cast<unsigned long long *>(&book[16 + c0 + m]), static_cast<unsigned long long>(n));
+      long long v = q_acc[m], n = static_cast<long long>(n_acc[m]);
+#pragma unroll
+      for (int step = 1; step < 64; step <<= 1) {
+        const long long ov = __shfl_xor(v, step, 64), on = __shfl_xor(n, step, 64);
+        if (!PK || static_cast<uint32_t>(step) < (1u << log_s)) {
+          v += ov;
+          n += on;
+        }
+      }
+      if (slot == 0 && n != 0) {
+        const uint32_t c = (PK ? lg * M : c0) + m;
+        atomicAdd(reinterpret_cast<unsigned long long *>(&delta[c]), static_cast<unsigned long long>(v));
+        atomicAdd(reinterpret_cast<unsigned long long *>(&book[2 * CH + c]), static_cast<unsigned long long>(n));
       }
     }
     __syncthreads();
-    if (tid < MT) {
+    if (tid < G * MT) {
       const long long e = book[tid] + delta[tid];
       book[tid] = e;
       delta[tid] = 0;
-      if (e < book[8 + tid]) {
-        book[8 + tid] = e;
-        atomicOr(improved_flag, 1u << tid);
+      if (e < book[CH + tid]) {
+        book[CH + tid] = e;
+        atomicOr(improved_flag + (tid >> 5), 1u << (tid & 31u));
       }
     }
     __syncthreads();
-    const uint32_t improved = *improved_flag;
-    if (improved) snapshot_original<MT, LAYOUT>(spins, a, group, improved);
+    const uint64_t improved = static_cast<uint64_t>(improved_flag[0]) | (static_cast<uint64_t>(improved_flag[1]) << 32);
+    if (improved) {
+      for (uint32_t g = 0; g < G; ++g) {
+        const uint32_t mask = static_cast<uint32_t>(improved >> (g * MT)) & ((1u << MT) - 1u);
+        if (mask) snapshot_original<MT, LAYOUT>(spins + (PK ? g * K * 4u : 0u), a, wg * G + g, mask, nthreads);
+      }
+    }
     __syncthreads();
-    if (tid == 0) *improved_flag = 0;  // next write to it is two barriers away
+    if (tid < 2) improved_flag[tid] = 0;  // next write to it is two barriers away
     ASP_TICK(4);
   }
 #if ASP_SHUF_TIMING
-  if (group == 0 && lane == 0 && wave < kTimingWaves) {
+  if (wg == 0 && lane == 0 && wave < kTimingWaves) {
     unsigned long long *out = reinterpret_cast<unsigned long long *>(const_cast<uint32_t *>(a.status) + kStatWords) +
                               wave * kTimingSlots;
     for (uint32_t k = 0; k < kTimingSlots; ++k) atomicAdd(out + k, ticks[k]);
   }
 #endif
 
-  for (uint32_t i = tid; i < K; i += blockDim.x) {
-    state[i] = static_cast<uint8_t>(from_lds<LAYOUT>(read_spin<LAYOUT>(spins, i)));
+  for (uint32_t g = 0; g < G; ++g) {
+    const uint32_t gg = wg * G + g;
+    if (PK && gg >= a.groups_total) break;
+    uint8_t *state_g = a.state + static_cast<uint64_t>(gg) * K;
+    const uint8_t *spins_g = spins + (PK ? g * K * 4u : 0u);
+    for (uint32_t i = tid; i < K; i += nthreads) {
+      state_g[i] = static_cast<uint8_t>(from_lds<LAYOUT>(read_spin<LAYOUT>(spins_g, i)));
+    }
   }
-  if (tid < MT) {
-    const uint64_t at = static_cast<uint64_t>(group) * MT + tid;
+  if (tid < G * MT && first_chain + tid < chains_total) {
+    const uint64_t at = first_chain + tid;
     a.e_cur[at] = book[tid];
-    a.e_best[at] = book[8 + tid];
-    a.accepted[at] = static_cast<unsigned long long>(book[16 + tid]);
+    a.e_best[at] = book[CH + tid];
+    a.accepted[at] = static_cast<unsigned long long>(book[2 * CH + tid]);
   }
 }
 
 using ShuffledKernel = void (*)(ShuffledArgs);
 
-template <int M, int LAYOUT, int TEAMS>
+template <int M, int LAYOUT, int TEAMS, bool PK = false>
 __global__ __launch_bounds__(512) void k_sa_sweep_shuffled(ShuffledArgs a) {
-  shuffled_sweep_body<M, LAYOUT, TEAMS>(a, blockIdx.x);
+  shuffled_sweep_body<M, LAYOUT, TEAMS, PK>(a, blockIdx.x);
 }
 
-// Many problems in one launch: workgroup -> (problem, group of M chains) through a slot table,
-// the problem's arguments through a descriptor table (csrc/sa_sweep.hip: k_sa_sweep_batch).
+// Many problems in one launch: workgroup -> (problem, workgroup of the problem) through a slot
+// table, the problem's arguments through a descriptor table (csrc/sa_sweep.hip: k_sa_sweep_batch).
 struct ShuffledSlot {
   uint32_t problem, group;
 };
-template <int M, int LAYOUT>
+template <int M, int LAYOUT, bool PK = false>
 __global__ __launch_bounds__(512) void k_sa_sweep_shuffled_batch(const ShuffledArgs *problems,
                                                                  const ShuffledSlot *slots) {
   using ConstArgs = const ShuffledArgs __attribute__((address_space(4)));
   const ShuffledSlot slot = slots[blockIdx.x];
   ConstArgs *a = reinterpret_cast<ConstArgs *>(
       reinterpret_cast<uintptr_t>(problems + __builtin_amdgcn_readfirstlane(slot.problem)));
-  shuffled_sweep_body<M, LAYOUT, 1>(*a, __builtin_amdgcn_readfirstlane(slot.group));
+  shuffled_sweep_body<M, LAYOUT, 1, PK>(*a, __builtin_amdgcn_readfirstlane(slot.group));
 }
 
-// m = chains per workgroup; teams = 2: two teams of m / 2 chains (wide: m = 4 or 2; bytes: m = 8 or 4)
-ShuffledKernel shuffled_kernel_for(int m, int layout, int teams = 1) {
+// m = chains per group; teams = 2: two teams of m / 2 chains (wide: m = 4 or 2; bytes: m = 8 or 4);
+// packed_lanes: blocks of fewer than 64 spins, several groups per wavefront (wide layout, one team)
+ShuffledKernel shuffled_kernel_for(int m, int layout, int teams = 1, bool packed_lanes = false) {
+  if (packed_lanes) {
+    if (layout != kWide || teams != 1) return nullptr;
+    switch (m) {
+      case 1: return k_sa_sweep_shuffled<1, kWide, 1, true>;
+      case 2: return k_sa_sweep_shuffled<2, kWide, 1, true>;
+      case 4: return k_sa_sweep_shuffled<4, kWide, 1, true>;
+      default: return nullptr;
+    }
+  }
   if (teams == 2) {
     if (layout == kWide) {
       switch (m) {
@@ -1011,10 +1233,12 @@ ShuffledKernel shuffled_kernel_for(int m, int layout, int teams = 1) {
   }
 }
 
-// spins | delta[8] book[24] | flag (16 B) | meta[block_cap] | level_block[level_cap + 2]
-size_t sweep_lds_bytes(uint64_t K, int layout, uint32_t level_cap, uint32_t block_cap) {
-  const uint64_t spin_bytes = layout == kWide ? K * 4 : (layout == kNibbles ? (K + 1) / 2 : (layout == kBits ? (K + 7) / 8 : K));
-  return ((spin_bytes + 15) & ~size_t{15}) + 32 * sizeof(long long) + 16 +
+// spins (of `groups` groups: lane packing) | delta[CH] book[3 CH] | flags (16 B) | meta[block_cap] |
+// level_block[level_cap + 2]; CH = 8 chains, 64 with lane packing (groups > 0)
+size_t sweep_lds_bytes(uint64_t K, int layout, uint32_t level_cap, uint32_t block_cap, uint32_t groups = 0) {
+  uint64_t spin_bytes = layout == kWide ? K * 4 : (layout == kNibbles ? (K + 1) / 2 : (layout == kBits ? (K + 7) / 8 : K));
+  if (groups) spin_bytes *= groups;
+  return ((spin_bytes + 15) & ~size_t{15}) + (groups ? 256 : 32) * sizeof(long long) + 16 +
          static_cast<size_t>(block_cap) * sizeof(uint2) + (static_cast<size_t>(level_cap) + 2) * sizeof(uint32_t);
 }
 
@@ -1027,9 +1251,11 @@ int shuffled_layout_for(uint64_t K, int m, uint32_t level_cap, uint32_t block_ca
   return -1;
 }
 
-size_t order_lds_bytes(uint32_t level_cap, uint32_t block_cap, uint32_t waves) {
+// (`arrays_of`: K when the peel's per-spin arrays live in LDS — PeelArrays<true> —, else 0)
+size_t order_lds_bytes(uint32_t level_cap, uint32_t block_cap, uint32_t waves, uint64_t arrays_of = 0) {
   return sizeof(uint32_t) * (8 + 16 + 2 * (static_cast<size_t>(level_cap) + 2) +
-                             2 * (static_cast<size_t>(block_cap) + 1) + 2 * static_cast<size_t>(waves) * 64);
+                             2 * (static_cast<size_t>(block_cap) + 1) + 2 * static_cast<size_t>(waves) * 64 +
+                             arrays_of + (arrays_of + 3) / 4 + (arrays_of + 1) / 2);
 }
 
 uint32_t next_pow2(uint32_t v) {
@@ -1077,9 +1303,15 @@ struct ShuffledRun {
 
   uint64_t K = 0;
   uint32_t words = 0, groups = 0, waves = 1, level_cap = 0, quad_cap = 0, order_threads = 64, lanes_per_row = 1;
+  // lane packing: blocks of 1 << log_s spins, 64 >> log_s groups per workgroup, `wgs` workgroups
+  uint32_t log_s = 6, wgs = 0;
+  bool packed_lanes = false;
+  uint32_t blocks_of_spins() const { return static_cast<uint32_t>((K + (1u << log_s) - 1) >> log_s); }
   uint64_t padded = 0;
   int m = 1, teams = 1, attempt = 0;
   int forced_m = 0;      // chains per workgroup chosen by the batched driver (0: by this run)
+  uint32_t order_threads_cap = 0;  // set by the batched driver: threads of an order workgroup at most
+  bool batch_saturates = false;    // set by the batched driver: the batch has more workgroups than the chip holds
   bool batched = false;  // launched by the batched driver: no timing events of its own
   bool trivial = false;  // nothing to launch (no spins or no chains)
   uint32_t status[kStatWords] = {0, 0, 0, 0};
@@ -1161,10 +1393,16 @@ struct ShuffledRun {
     // call's count when there is one
     const double levels_guess = p->last_shuffled_levels > 0 ? p->last_shuffled_levels : 2.5 * mean_degree + 4.0;
     waves = static_cast<uint32_t>(p->shuffled_waves);
+    // one wavefront more than the blocks of an average level: the first levels of a sweep are its
+    // widest (K = 12 870 alone on the chip: +6 %) — but not in a batch that oversubscribes the chip,
+    // where a wavefront mostly waiting at level barriers holds 256 registers of a SIMD that another
+    // problem's workgroup could run in (128-problem production batch, sweeps alone: 1.69 -> 1.56 s)
+    uint32_t waves_extra = batch_saturates ? 0u : 1u;
+    if (const char *env = std::getenv("ASP_SHUFFLED_WAVES_EXTRA")) waves_extra = static_cast<uint32_t>(std::atoi(env));
     if (!waves) {
       // a wavefront per block of an average level, and one more: the first blocks of a level are
       // its widest (K = 12 870: 4 blocks per level, 4 -> 8 wavefronts +6 %)
-      waves = static_cast<uint32_t>(std::ceil(static_cast<double>(K) / levels_guess / 64.0)) + 1u;
+      waves = static_cast<uint32_t>(std::ceil(static_cast<double>(K) / levels_guess / 64.0)) + waves_extra;
       waves = std::max(1u, std::min(8u, waves));
     }
     // Two teams of m / 2 chains (k_sa_sweep_shuffled, TEAMS): only on request.  Measured at
@@ -1191,8 +1429,39 @@ struct ShuffledRun {
       const int fits = shuffled_layout_for(K, m, level_cap, words + level_cap, p->max_lds);
       if (fits == kNibbles || fits == kBits) teams = 1;  // (the packed layouts have one team)
     }
+    // Lane packing: a level holds about K / levels spins.  When that is well below a wavefront, the
+    // order kernel cuts the levels into blocks of S < 64 spins and a wavefront visits a block for
+    // G = 64 / S groups of chains at once (k_sa_sweep_shuffled<.., PK = true>): a production-sized
+    // cluster (1e2 .. 3e3 spins) has 3 .. 40 spins per level, so 16 workgroups of four chains with
+    // a few live lanes each become one to four workgroups with full wavefronts.  S = three quarters
+    // of the mean level rounded up to a power of two (levels run from ~2.5 x the mean down to one
+    // spin; smaller blocks waste fewer slots on the rounding), at least 4, and large enough that
+    // the call has G groups to fill the lanes with and that G x K spin words fit the LDS.
+    log_s = 6;
+    packed_lanes = false;
+    if (teams == 1 && m <= 4 && !std::getenv("ASP_SHUFFLED_NO_PACKING")) {
+      const double mean_level = static_cast<double>(K) / levels_guess;
+      uint32_t want = std::max(4u, std::min(64u, next_pow2(static_cast<uint32_t>(std::ceil(0.75 * mean_level)))));
+      if (const char *env = std::getenv("ASP_SHUFFLED_LOG_S")) {
+        want = 1u << std::max(2l, std::min(6l, std::strtol(env, nullptr, 10)));
+      }
+      while (want < 64u && 64u / want > groups) want <<= 1;
+      while (want < 64u && sweep_lds_bytes(K, kWide, level_cap, static_cast<uint32_t>((K + want - 1) / want) + level_cap,
+                                           64u / want) > p->max_lds) {
+        want <<= 1;
+      }
+      if (want < 64u) {
+        packed_lanes = true;
+        while ((1u << log_s) > want) --log_s;
+        if (!p->shuffled_waves) {
+          waves = std::max(1u, std::min(8u, static_cast<uint32_t>(std::ceil(mean_level / want)) + waves_extra));
+        }
+      }
+    }
+    wgs = (groups + (64u >> log_s) - 1) / (64u >> log_s);
     quad_cap = 0;  // 0: derive from level_cap
     order_threads = K >= 4096 ? kOrderThreads : (K >= 512 ? 256u : 64u);
+    if (order_threads_cap) order_threads = std::min(order_threads, order_threads_cap);
     lanes_per_row = std::min(64u, std::min(order_threads, next_pow2(std::max(
         1u, static_cast<uint32_t>(std::ceil(mean_degree / 4.0))))));
     if (const char *env = std::getenv("ASP_SHUFFLED_BYTES")) budget = std::strtoull(env, nullptr, 10);
@@ -1212,7 +1481,7 @@ struct ShuffledRun {
     ASP_TRY(d_perm.alloc(static_cast<uint64_t>(repetitions) * L.num_blocks));
     ASP_TRY(d_partial.alloc(static_cast<uint64_t>(repetitions) * L.num_blocks));
     ASP_TRY(d_e.alloc(repetitions));
-    ASP_TRY(d_status.alloc(kStatWords + 2 * kTimingSlots * kTimingWaves));
+    ASP_TRY(d_status.alloc(kStatusWords));
     ASP_TRY(d_betas.upload(betas, num_sweeps, s));
     if (x0) {
       ASP_TRY(d_x0.alloc(words));
@@ -1225,6 +1494,7 @@ struct ShuffledRun {
   uint32_t block_cap = 0, stream_kib = 0, chunk = 0;
   int layout = kBytes;
   size_t lds = 0, order_lds = 0;
+  bool order_in_lds = false;
   ShuffledKernel kernel = nullptr;
   int nsets = 1, nlanes = 1;
   OrderArgs oa{};
@@ -1233,32 +1503,45 @@ struct ShuffledRun {
   // Sweeps per chunk this run would choose by itself for its present capacities.
   int plan_sizes() {
     const uint32_t max_quads = p->rq_max_quads;
-    block_cap = words + level_cap;
+    const uint32_t S = 1u << log_s;
+    block_cap = blocks_of_spins() + level_cap;
+    if (packed_lanes && sweep_lds_bytes(K, kWide, level_cap, block_cap, 64u >> log_s) > p->max_lds) {
+      // (the capacities grew since setup(): back to blocks of 64 spins, one group per workgroup)
+      packed_lanes = false;
+      log_s = 6;
+      wgs = groups;
+      return plan_sizes();
+    }
     // a word per spin (the one-instruction sign) when that fits the LDS beside the sweep's tables,
     // else a byte, else four bits (m <= 4) or one (m = 1)
-    layout = shuffled_layout_for(K, m, level_cap, block_cap, p->max_lds);
+    layout = packed_lanes ? kWide : shuffled_layout_for(K, m, level_cap, block_cap, p->max_lds);
     if (layout < 0) {
       return asp::set_error(ASP_ERR_TOO_LARGE, "the shuffled sweep keeps its spins in LDS: %llu spins with %d "
                                                "chains per workgroup do not fit", (unsigned long long)K, m);
     }
-    lds = sweep_lds_bytes(K, layout, level_cap, block_cap);
+    lds = sweep_lds_bytes(K, layout, level_cap, block_cap, packed_lanes ? 64u >> log_s : 0u);
     if (!quad_cap) {
       // exact class sort (rows below 63 quads): a block is no wider than every row of the block
       // before it in its level, so the blocks hold at most (sum of the row quads) / 64 + one
       // widest block per level; otherwise every block may be as wide as the longest row
-      const uint64_t tight = (static_cast<uint64_t>(p->rq_quads) + 63) / 64 +
+      const uint64_t tight = (static_cast<uint64_t>(p->rq_quads) + S - 1) / S +
                              static_cast<uint64_t>(level_cap) * max_quads;
       const uint64_t loose = static_cast<uint64_t>(block_cap) * max_quads;
       quad_cap = static_cast<uint32_t>(std::min<uint64_t>(max_quads < kClassCap ? tight : loose, kQuadLimit));
     }
-    // KiB of one sweep's stream: a header per block, 3 KiB per quad, and slack for the sweep
-    // kernel's read of one quad past a wide block (< 4 GiB: 32-bit scalar offsets)
-    stream_kib = block_cap + 3u * (quad_cap + 2u);
-    const uint64_t per_sweep = static_cast<uint64_t>(stream_kib) * 1024 + static_cast<uint64_t>(block_cap) * (256 + 8) +
+    // KiB of one sweep's stream: slabs of 16 S bytes — a header slab per block, three per quad,
+    // and slack for the sweep kernel's read of one quad past a wide block (< 4 GiB: 32-bit
+    // scalar offsets)
+    stream_kib = static_cast<uint32_t>(((static_cast<uint64_t>(block_cap) + 3ull * (quad_cap + 2ull)) * 16 * S + 1023) / 1024);
+    const uint64_t per_sweep = static_cast<uint64_t>(stream_kib) * 1024 + static_cast<uint64_t>(block_cap) * (4 * S + 8) +
                                (level_cap + 1ull) * 4 + 12ull * K;
     chunk = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(256, budget / per_sweep)));
     chunk = std::max(1u, std::min(chunk, (num_sweeps + 3) / 4));  // at least four chunks: the pipeline needs them
-    order_lds = order_lds_bytes(level_cap, block_cap, order_threads / 64);
+    // the peel's arrays in LDS when they fit half of it (the sweep workgroups of the previous chunk
+    // are resident beside the order workgroups) and the counters fit a byte
+    order_in_lds = K < 65536 && p->rq_max_quads * 4u <= 255u && !std::getenv("ASP_SHUFFLED_ORDER_IN_HBM") &&
+                   order_lds_bytes(level_cap, block_cap, order_threads / 64, K) <= p->max_lds * 9 / 16;
+    order_lds = order_lds_bytes(level_cap, block_cap, order_threads / 64, order_in_lds ? K : 0);
     if (order_lds > p->max_lds) {
       return asp::set_error(ASP_ERR_TOO_LARGE, "%u levels x %u blocks do not fit the order kernel's LDS",
                             level_cap, block_cap);
@@ -1276,19 +1559,20 @@ struct ShuffledRun {
     nsets = static_cast<int>(std::min<uint32_t>(kSets, chunks));
     nlanes = static_cast<int>(std::min<uint32_t>(kLanes, chunks));
     for (int i = 0; i < nlanes; ++i) {
-      ASP_TRY(d_prio[i].ensure(static_cast<uint64_t>(chunk) * K));
-      ASP_TRY(d_indeg[i].ensure(static_cast<uint64_t>(chunk) * K));
-      ASP_TRY(d_order[i].ensure(static_cast<uint64_t>(chunk) * K));
+      const uint64_t scratch = order_in_lds ? 1 : static_cast<uint64_t>(chunk) * K;  // (LDS: no HBM scratch)
+      ASP_TRY(d_prio[i].ensure(scratch));
+      ASP_TRY(d_indeg[i].ensure(scratch));
+      ASP_TRY(d_order[i].ensure(scratch));
     }
     for (int i = 0; i < nsets; ++i) {
       OrderSet &o = sets[i];
       ASP_TRY(o.level_block.ensure(static_cast<uint64_t>(chunk) * (level_cap + 1)));
       ASP_TRY(o.num_levels.ensure(chunk));
       ASP_TRY(o.block_meta.ensure(static_cast<uint64_t>(chunk) * block_cap));
-      ASP_TRY(o.spin_of_pos.ensure(static_cast<uint64_t>(chunk) * block_cap * 64));
+      ASP_TRY(o.spin_of_pos.ensure((static_cast<uint64_t>(chunk) * block_cap) << log_s));
       ASP_TRY(o.stream.ensure(static_cast<uint64_t>(chunk) * stream_kib * 1024));
     }
-    ASP_HIP_TRY(hipMemsetAsync(d_status.ptr, 0, (kStatWords + 2 * kTimingSlots * kTimingWaves) * sizeof(uint32_t), s));
+    ASP_HIP_TRY(hipMemsetAsync(d_status.ptr, 0, (kStatusWords) * sizeof(uint32_t), s));
     ASP_HIP_TRY(hipEventRecord(p->ev[0], s));
     oa = OrderArgs{};
     oa.rq_ptr = p->rq_ptr.ptr;
@@ -1302,6 +1586,9 @@ struct ShuffledRun {
     oa.quad_cap = quad_cap;
     oa.stream_kib = stream_kib;
     oa.lanes_per_row = lanes_per_row;
+    oa.log_s = log_s;
+    oa.threads = order_threads;
+    oa.lds_arrays = order_in_lds ? 1u : 0u;
     oa.col_shift = layout == kWide ? 2u : 0u;
     oa.status = d_status.ptr;
     sa = ShuffledArgs{};
@@ -1321,6 +1608,9 @@ struct ShuffledRun {
     sa.block_cap = block_cap;
     sa.stream_kib = stream_kib;
     sa.replica_first = replica_offset;
+    sa.log_s = log_s;
+    sa.groups_total = groups;
+    sa.waves = waves;
     return ASP_OK;
   }
 
@@ -1358,10 +1648,10 @@ struct ShuffledRun {
     if (trivial) return ASP_OK;
     hipStream_t s = p->stream;
     ASP_TRY(plan_sizes());
-    kernel = shuffled_kernel_for(m, layout, teams);
+    kernel = shuffled_kernel_for(m, layout, teams, packed_lanes);
     if (!kernel) {  // (no two-team form of this width and layout)
       teams = 1;
-      kernel = shuffled_kernel_for(m, layout, 1);
+      kernel = shuffled_kernel_for(m, layout, 1, packed_lanes);
     }
     if (lds > 64 * 1024) {
       ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
@@ -1393,7 +1683,7 @@ struct ShuffledRun {
         ASP_HIP_TRY(hipEventRecord(ordered[which], os));
         ASP_HIP_TRY(hipStreamWaitEvent(s, ordered[which], 0));
       }
-      hipLaunchKernelGGL(kernel, dim3(groups), dim3(waves * teams * 64), lds, s, s_args);
+      hipLaunchKernelGGL(kernel, dim3(wgs), dim3(waves * teams * 64), lds, s, s_args);
       ASP_HIP_TRY(hipGetLastError());
       ASP_HIP_TRY(hipEventRecord(swept[which], s));
       first_launch = false;
@@ -1439,7 +1729,7 @@ struct ShuffledRun {
     p->last_shuffled_levels = static_cast<int>(status[kStatLevels]);
 #if ASP_SHUF_TIMING
     {
-      unsigned long long host_ticks[kTimingSlots * kTimingWaves];
+      unsigned long long host_ticks[kTimingSlots * kTimingWaves + kOrderTimingSlots];
       ASP_HIP_TRY(hipMemcpy(host_ticks, d_status.ptr + kStatWords, sizeof host_ticks, hipMemcpyDeviceToHost));
       static const char *names[kTimingSlots] = {"row sums", "request", "accept", "barrier", "sweep end", "level head"};
       for (uint32_t w = 0; w < waves && w < kTimingWaves; ++w) {
@@ -1449,6 +1739,13 @@ struct ShuffledRun {
         }
         std::fprintf(stderr, "\n");
       }
+      static const char *onames[kOrderTimingSlots] = {"priorities", "counts", "peel", "level blocks", "sort", "widths",
+                                                      "stream", "tables"};
+      std::fprintf(stderr, "order kernel, wavefront 0, all sweeps:");
+      for (uint32_t k = 0; k < kOrderTimingSlots; ++k) {
+        std::fprintf(stderr, " %s %.3f Mcyc", onames[k], static_cast<double>(host_ticks[kTimingSlots * kTimingWaves + k]) * 1e-6);
+      }
+      std::fprintf(stderr, "\n");
     }
 #endif
     ASP_TRY(asp::sa_permute_bits(p, d_best.ptr, repetitions, d_perm.ptr));
@@ -1474,6 +1771,8 @@ struct ShuffledRun {
     p->last_layout = 5;
     p->last_threads = static_cast<int>(waves * teams * 64);
     p->last_groups = static_cast<int>(groups);
+    p->last_shuffled_log_s = log_s;
+    p->last_shuffled_wgs = wgs;
     if (!batched) {
       ASP_HIP_TRY(hipEventElapsedTime(&p->last_sweep_ms, p->ev[0], p->ev[2]));
       ASP_HIP_TRY(hipEventElapsedTime(&p->last_total_ms, p->ev[0], p->ev[3]));
@@ -1488,7 +1787,16 @@ namespace {
 
 using ShuffledBatchKernel = void (*)(const ShuffledArgs *, const ShuffledSlot *);
 
-ShuffledBatchKernel shuffled_batch_kernel_for(int m, int layout) {
+ShuffledBatchKernel shuffled_batch_kernel_for(int m, int layout, bool packed_lanes) {
+  if (packed_lanes) {
+    if (layout != kWide) return nullptr;
+    switch (m) {
+      case 1: return k_sa_sweep_shuffled_batch<1, kWide, true>;
+      case 2: return k_sa_sweep_shuffled_batch<2, kWide, true>;
+      case 4: return k_sa_sweep_shuffled_batch<4, kWide, true>;
+      default: return nullptr;
+    }
+  }
   if (layout == kWide) {
     switch (m) {
       case 1: return k_sa_sweep_shuffled_batch<1, kWide>;
@@ -1535,11 +1843,11 @@ struct EventPool {
 int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
   const uint32_t P = static_cast<uint32_t>(runs.size());
   const uint32_t num_sweeps = runs[0]->num_sweeps;
-  // one block size for the shared order launch: the largest any problem wants
+  // one block size for the shared order launch: the largest any problem wants (the workgroups of
+  // a smaller problem retire the wavefronts beyond its own OrderArgs::threads at once)
   uint32_t order_threads = 64;
   for (ShuffledRun *r : runs) order_threads = std::max(order_threads, r->order_threads);
   for (ShuffledRun *r : runs) {
-    r->order_threads = order_threads;
     r->batched = true;
     r->teams = 1;
   }
@@ -1549,10 +1857,16 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
   DeviceBuffer<ShuffledArgs> d_sargs;
   asp::ScopedStream order_stream[ShuffledRun::kLanes];
   for (auto &o : order_stream) ASP_TRY(o.acquire());
-  // classes of workgroup shape: (layout, wavefronts)
+  // Classes of KERNEL: (layout, lane packing).  Wavefronts per workgroup and spins per block are
+  // per-problem arguments (a workgroup retires the wavefronts beyond its problem's own), so a
+  // chunk is one order launch and one sweep launch per class — two or three launches, each on a
+  // stream of its own: the device runs FOUR hardware queues, and with a class per (wavefronts,
+  // block size) — eleven streams on the production mix — kernels waiting for their chunk's orders
+  // blocked the queues of kernels that could have run (profiles/r04_shuffled_batch_trace.txt).
   struct Class {
     int layout;
-    uint32_t waves;
+    uint32_t waves = 0;  // of the launch: the most any member wants
+    bool packed_lanes;
     std::vector<uint32_t> members;
     DeviceBuffer<ShuffledSlot> slots;  // (before the stream: released after it has been waited for)
     asp::ScopedStream stream;
@@ -1587,34 +1901,52 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
       ShuffledRun *r = runs[i];
       Class *c = nullptr;
       for (auto &k : classes) {
-        if (k->layout == r->layout && k->waves == r->waves) c = k.get();
+        if (k->layout == r->layout && k->packed_lanes == r->packed_lanes) c = k.get();
       }
       if (!c) {
         classes.emplace_back(new Class());
         c = classes.back().get();
         c->layout = r->layout;
-        c->waves = r->waves;
+        c->packed_lanes = r->packed_lanes;
         ASP_TRY(c->stream.acquire());
         for (auto &e : c->swept) ASP_TRY(events.make(&e));
       }
       c->members.push_back(i);
       c->lds = std::max(c->lds, r->lds);
+      c->waves = std::max(c->waves, r->waves);
     }
     const int m = runs[0]->m;
+    // (a kernel is keyed by (m, layout, packing), a class also by its wavefronts and block size:
+    // classes may share a kernel, and its dynamic-LDS limit must cover the largest of them)
+    std::vector<std::pair<ShuffledBatchKernel, size_t>> kernel_lds;
     for (auto &c : classes) {
+      // the longest problems first: a workgroup's time is sweeps x levels x one block visit whatever
+      // the cluster's size, but the large clusters have more levels and wider rows
+      std::stable_sort(c->members.begin(), c->members.end(),
+                       [&](uint32_t x, uint32_t y) { return runs[x]->K > runs[y]->K; });
       std::vector<ShuffledSlot> slots;
       for (uint32_t i : c->members) {
-        for (uint32_t g = 0; g < runs[i]->groups; ++g) slots.push_back(ShuffledSlot{i, g});
+        for (uint32_t g = 0; g < runs[i]->wgs; ++g) slots.push_back(ShuffledSlot{i, g});
       }
       c->num_slots = static_cast<uint32_t>(slots.size());
       ASP_TRY(c->slots.alloc(slots.size()));
       ASP_TRY(c->slots.upload(slots.data(), slots.size(), c->stream.stream));
       ASP_HIP_TRY(hipStreamSynchronize(c->stream.stream));  // `slots` dies with this scope
-      ShuffledBatchKernel kernel = shuffled_batch_kernel_for(m, c->layout);
+      ShuffledBatchKernel kernel = shuffled_batch_kernel_for(m, c->layout, c->packed_lanes);
       if (!kernel) return asp::set_error(ASP_ERR_INVALID, "no batched shuffled kernel for %d chains per group", m);
-      if (c->lds > 64 * 1024) {
-        ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(c->lds)));
+      bool seen = false;
+      for (auto &k : kernel_lds) {
+        if (k.first == kernel) {
+          k.second = std::max(k.second, c->lds);
+          seen = true;
+        }
+      }
+      if (!seen) kernel_lds.emplace_back(kernel, c->lds);
+    }
+    for (auto &k : kernel_lds) {
+      if (k.second > 64 * 1024) {
+        ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k.first),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(k.second)));
       }
     }
     // ---- descriptors of every (chunk, problem) ----
@@ -1629,6 +1961,11 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
                             &sargs[static_cast<size_t>(turn) * P + i]);
       }
     }
+    // Timing-only ablations (results are WRONG; tools/time_shuffled_batch_only.py): 1 = orders of
+    // the first buffer sets only, every later chunk sweeps through stale ones (the cost of the
+    // sweep kernels alone); 2 = no sweep launches after the first chunk (the order kernels alone)
+    int ablate = 0;
+    if (const char *env = std::getenv("ASP_SHUFFLED_ABLATE")) ablate = std::atoi(env);
     hipStream_t os0 = order_stream[0].stream;
     ASP_TRY(d_oargs.ensure(oargs.size()));
     ASP_TRY(d_sargs.ensure(sargs.size()));
@@ -1643,7 +1980,7 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
       const uint32_t now = num_sweeps > done ? std::min(chunk, num_sweeps - done) : 0u;
       const uint32_t which = turn % nsets;
       hipStream_t os = order_stream[turn % nlanes].stream;
-      if (now) {
+      if (now && !(ablate == 1 && turn >= nsets)) {
         if (turn >= nsets) {
           for (auto &c : classes) ASP_HIP_TRY(hipStreamWaitEvent(os, c->swept[which], 0));
         }
@@ -1653,9 +1990,10 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
         ASP_HIP_TRY(hipEventRecord(ordered[which], os));
       }
       for (auto &c : classes) {
+        if (ablate == 2 && turn > 0) continue;
         hipStream_t cs = c->stream.stream;
         if (now) ASP_HIP_TRY(hipStreamWaitEvent(cs, ordered[which], 0));
-        ShuffledBatchKernel kernel = shuffled_batch_kernel_for(m, c->layout);
+        ShuffledBatchKernel kernel = shuffled_batch_kernel_for(m, c->layout, c->packed_lanes);
         hipLaunchKernelGGL(kernel, dim3(c->num_slots), dim3(c->waves * 64), c->lds, cs,
                            d_sargs.ptr + static_cast<size_t>(turn) * P, c->slots.ptr);
         ASP_HIP_TRY(hipGetLastError());
@@ -1700,6 +2038,7 @@ int sa_shuffled_batch(asp_sa_batch_item const *items, const uint32_t *which, uin
   if (const char *env = std::getenv("ASP_SHUFFLED_BATCH_BYTES")) budget = std::strtoull(env, nullptr, 10);
   // chains per workgroup for the whole batch: as many as still leave two workgroups per compute unit
   int m = 1;
+  bool saturates = false;  // more groups of chains than the chip holds workgroups (two per compute unit)
   if (count > 1) {
     const int num_cus = items[which[0]].plan ? items[which[0]].plan->num_cus : 256;
     for (int cand : {4, 2}) {
@@ -1707,6 +2046,7 @@ int sa_shuffled_batch(asp_sa_batch_item const *items, const uint32_t *which, uin
       for (uint32_t k = 0; k < count; ++k) groups += (items[which[k]].repetitions + cand - 1) / cand;
       if (groups >= 2ull * static_cast<uint64_t>(num_cus)) {
         m = cand;
+        saturates = true;
         break;
       }
     }
@@ -1725,6 +2065,10 @@ int sa_shuffled_batch(asp_sa_batch_item const *items, const uint32_t *which, uin
     r.out_e = it.out_e;
     r.budget = std::max<uint64_t>(64ull << 20, std::min<uint64_t>(3ull << 30, budget / count));
     if (count > 1 && it.plan && !it.plan->shuffled_m) r.forced_m = m;
+    r.batch_saturates = saturates;
+    if (const char *env = std::getenv("ASP_SHUFFLED_ORDER_THREADS")) {  // (development: scanned 128 .. 1024, no effect)
+      r.order_threads_cap = static_cast<uint32_t>(std::max(64l, std::min(1024l, std::strtol(env, nullptr, 10) / 64 * 64)));
+    }
     ASP_TRY(r.setup());
   }
   // groups of equal ladder length (and equal chains per workgroup: a plan with a forced width
@@ -1786,6 +2130,13 @@ int asp_sa_last_shuffled(asp_sa_plan const *p, uint32_t *levels, float *order_ms
   if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
   if (levels) *levels = static_cast<uint32_t>(p->last_shuffled_levels);
   if (order_ms) *order_ms = p->last_order_ms;
+  return ASP_OK;
+}
+
+int asp_sa_last_shuffled_blocks(asp_sa_plan const *p, uint32_t *spins_per_block, uint32_t *workgroups) {
+  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  if (spins_per_block) *spins_per_block = 1u << p->last_shuffled_log_s;
+  if (workgroups) *workgroups = p->last_shuffled_wgs;
   return ASP_OK;
 }
 

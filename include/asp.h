@@ -440,6 +440,12 @@ int asp_sa_set_shuffled_launch(asp_sa_plan *p, int chains_per_group, int wavefro
 int asp_sa_set_shuffled_teams(asp_sa_plan *p, int teams);
 /* Of the last asp_sa_anneal_shuffled call: the largest number of levels of a sweep. */
 int asp_sa_last_shuffled(asp_sa_plan const *p, uint32_t *levels, float *order_ms);
+/* Of the last shuffled call or batch item of this plan: spins per block of the level-major coupling
+ * stream (64, or 4 .. 32 with lane packing: a wavefront then visits a block for 64 / spins_per_block
+ * groups of chains at once — small levels filled with chains instead of padding lanes) and the
+ * workgroups of its sweep launches.  Results never depend on either; ASP_SHUFFLED_LOG_S=2..6 in
+ * the environment forces the block size, ASP_SHUFFLED_NO_PACKING=1 keeps blocks of 64. */
+int asp_sa_last_shuffled_blocks(asp_sa_plan const *p, uint32_t *spins_per_block, uint32_t *workgroups);
 
 /* MANY independent problems in one call — the shape of the reference's production job: tens of
  * thousands of sampled clusters, each solved with 64 repetitions x 5120 sweeps

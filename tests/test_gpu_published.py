@@ -57,7 +57,8 @@ def test_success_probability_matches_published_curve(name, sweeps):
     with open(os.path.join(GOLDEN, "published_sa_curves.json")) as f:
         row = json.load(f)["models"][name][str(sweeps)]
     sim = _simulation(name)
-    results = np.array([sim.run(sweeps, 1024, seed=435834 + 1000003 * trial + sweeps)
+    # (the COLOUR order, explicitly: the drop-in default is the shuffled order, tested below)
+    results = np.array([sim.run(sweeps, 1024, seed=435834 + 1000003 * trial + sweeps, sweep_order="colour")
                         for trial in range(TRIALS)])
     acc, residual = results[:, 0].mean(), results[:, 2].mean()
     assert residual == acc, "P(residual <= 1e-12) and P(accuracy > 0.995) differ"

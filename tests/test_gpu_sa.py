@@ -1200,3 +1200,78 @@ def test_sweep_order_reaches_the_solver_entry_points(monkeypatch):
     assert np.array_equal(common.solve_ising_model(model, seed=3, number_sweeps=50, repetitions=4), expected)
     with pytest.raises(ValueError):
         sa.anneal(ham, seed=3, number_sweeps=5, sweep_order="typewriter")
+
+
+def _shuffled_blocks(ham):
+    from annealing_sign_problem_amd import _lib
+
+    spins, wgs = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    _lib.check(_lib.load().asp_sa_last_shuffled_blocks(ham.plan(), ctypes.byref(spins), ctypes.byref(wgs)))
+    return spins.value, wgs.value
+
+
+@pytest.mark.parametrize("n,degree,reps,offset,m,log_s", [
+    (90, 20.0, 64, 0, 4, None),    # one workgroup holds all 64 chains: 16 groups x 4 spins per wavefront
+    (90, 20.0, 13, 2, 4, None),    # ragged: 4 groups (one of a single chain), idle groups in the wavefront
+    (400, 22.0, 64, 0, 4, None),
+    (1000, 23.0, 64, 7, 4, None),  # replica offset not a multiple of four: two Philox calls per lane
+    (1000, 23.0, 20, 1, 2, 3),     # M = 2, blocks of 8 forced: 8 groups per workgroup, 10 groups in the call
+    (700, 9.0, 19, 0, 1, 2),       # M = 1, blocks of 4: 16 chains per wavefront, 19 in the call
+    (2500, 23.0, 33, 5, 4, 5),     # blocks of 32, two groups per workgroup, an odd number of groups
+    (300, 30.0, 40, 0, 4, 4),      # rows wider than... a level smaller than the forced block
+])
+def test_shuffled_sweep_lane_packing(monkeypatch, n, degree, reps, offset, m, log_s):
+    """levels of fewer than 64 spins are cut into blocks of S = 4 .. 32 spins and
+    a wavefront visits a block for 64 / S groups of chains at once (lane = (group, spin)).  Every
+    chain must be the oracle's, whatever S, M, the number of chains and the replica offset; x0 too."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    J, h, ham, info, betas = _shuffled_case(n, degree, 12, seed=n)
+    S = info.energy_scale_exp
+    lib = _lib.load()
+    if log_s is not None:
+        monkeypatch.setenv("ASP_SHUFFLED_LOG_S", str(log_s))
+    _lib.check(lib.asp_sa_set_shuffled_launch(ham.plan(), m, 0))
+    xs, es = sa.anneal_raw(ham, 4711, betas, reps, offset, None, shuffled=True)
+    spins_per_block, wgs = _shuffled_blocks(ham)
+    assert spins_per_block < 64 and wgs == -(-(-(-reps // m)) // (64 // spins_per_block))
+    if log_s is not None:
+        assert spins_per_block == 1 << log_s
+    tracked, accepted = _stats(ham, reps)
+    oxs, oes, otracked, oaccepted = oracle.sa_anneal_shuffled(J, h, 4711, betas, reps, offset, None, S,
+                                                             num_threads=8)
+    assert np.array_equal(accepted, oaccepted) and np.array_equal(tracked, otracked)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    x0 = sa.signs_to_bits(np.where(np.random.default_rng(n).random(n) < 0.5, 1.0, -1.0))
+    xs, es = sa.anneal_raw(ham, 5, betas, 6, 1, x0, shuffled=True)
+    oxs, oes, _, _ = oracle.sa_anneal_shuffled(J, h, 5, betas, 6, 1, x0, S, num_threads=6)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    # the same chains without packing (blocks of 64 spins, one group per workgroup)
+    monkeypatch.setenv("ASP_SHUFFLED_NO_PACKING", "1")
+    plain_x, plain_e = sa.anneal_raw(ham, 5, betas, 6, 1, x0, shuffled=True)
+    assert _shuffled_blocks(ham)[0] == 64
+    assert np.array_equal(plain_x, xs) and plain_e.tobytes() == es.tobytes()
+
+
+def test_shuffled_lane_packing_over_many_chunks_and_in_a_batch():
+    """Packed problems keep their chain state between the chunks of a long ladder, and a batch
+    mixes block sizes (one launch per class of workgroup shape): every problem is its own call."""
+    from annealing_sign_problem_amd import annealer as sa
+
+    cases = [_shuffled_case(k, d, 600 if k == 150 else 40, seed=k) for k, d in
+             ((150, 15.0), (800, 23.0), (60, 10.0), (5000, 23.0), (2000, 23.0))]
+    J, h, ham, info, betas = cases[0]
+    xs, es = sa.anneal_raw(ham, 21, betas, 10, 0, None, shuffled=True)
+    assert _shuffled_blocks(ham)[0] < 64
+    oxs, oes, _, _ = oracle.sa_anneal_shuffled(J, h, 21, betas, 10, 0, None, info.energy_scale_exp, num_threads=8)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    batch = cases[1:]
+    results = sa.anneal_batch_raw([c[2] for c in batch], [3, 4, 5, 6], [c[4] for c in batch], [64, 64, 17, 64],
+                                  shuffled=True)
+    sizes = [_shuffled_blocks(c[2])[0] for c in batch]
+    assert len(set(sizes)) >= 3 and max(sizes) == 64
+    for (J, h, ham, info, betas), seed, reps, (bx, be) in zip(batch, (3, 4, 5, 6), (64, 64, 17, 64), results):
+        oxs, oes, _, _ = oracle.sa_anneal_shuffled(J, h, seed, betas, reps, 0, None, info.energy_scale_exp,
+                                                   num_threads=16)
+        assert np.array_equal(bx, oxs) and be.tobytes() == oes.tobytes()
