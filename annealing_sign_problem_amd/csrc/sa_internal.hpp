@@ -59,6 +59,7 @@ struct asp_sa_plan {
   int shuffled_teams = 0;                  // asp_sa_set_shuffled_teams (0 = automatic)
   int last_shuffled_levels = 0;            // largest number of levels of the last shuffled call
   uint32_t last_shuffled_log_s = 6, last_shuffled_wgs = 0;  // block size and workgroups of the last shuffled call
+  uint32_t last_shuffled_blocks = 0, last_shuffled_quads = 0;  // most blocks / quads of one sweep of that call
   float last_order_ms = 0.0f;              // device time of the last call's order kernels
 };
 

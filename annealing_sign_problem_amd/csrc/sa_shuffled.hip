@@ -76,6 +76,13 @@ struct OrderArgs {
   uint32_t lanes_per_row;                   // power of two <= 64: lanes sharing a row in the graph passes
   uint32_t threads;                         // threads of this problem's order workgroups (a multiple of 64)
   uint32_t lds_arrays;                      // 1: priorities, counters and the order in LDS (PeelArrays)
+  // The WIDE path (large clusters: the per-spin arrays in HBM): priorities, counts, every level of
+  // the peel and the stream are kernels of their own over ALL sweeps of the chunk (k_order_prio,
+  // k_order_counts, k_order_level, k_order_stream) and only what needs a sweep's tables in LDS
+  // stays in a workgroup per sweep (k_shuffled_orders with finish_only = 1).
+  uint32_t finish_only;                     // 1: the levels have been peeled by k_order_level
+  uint32_t *peel_ctl;                       // [count][8]: members of level l % 3 | first position of level l % 3 | -
+  uint32_t *level_start_g;                  // [count][level_cap + 2] first position of every level
   uint32_t col_shift;                       // columns are written as (neighbour << col_shift): LDS addresses
   // scratch, [count][K] each
   uint32_t *prio, *indeg, *order;
@@ -128,6 +135,53 @@ __device__ uint32_t block_exclusive_scan(uint32_t *a, uint32_t n, uint32_t *wave
 
 __device__ __forceinline__ bool comes_before(uint32_t pa, uint32_t a, uint32_t pb, uint32_t b) {
   return pa < pb || (pa == pb && a < b);
+}
+
+// One pass of a wavefront over the coupling stream of a sweep: the 64 / S blocks b0 .. of the
+// sweep (lane = (block of the pass, slot)): header slab and quad slabs of each.  `first` / `quads`:
+// slab offset and width of every block (LDS or HBM).
+template <typename Args>
+__device__ __forceinline__ void write_stream_pass(const Args &a, uint8_t *stream, const uint32_t *sop, uint32_t b,
+                                                  bool live, uint32_t first_slab, uint32_t quads_of_block,
+                                                  uint32_t lane) {
+  const uint32_t S = 1u << a.log_s;
+  const uint32_t slot = lane & (S - 1u);
+  const uint32_t slab_bytes = 16u << a.log_s;
+  const uint32_t i = live ? sop[(b << a.log_s) + slot] : kDummySpin;
+  const bool real = i != kDummySpin;
+  const uint32_t row = real ? a.rq_ptr[i] : 0u;
+  const uint32_t mine = real ? a.rq_ptr[i + 1] - row : 0u;
+  const uint32_t own = real ? i << a.col_shift : 0u;  // padding reads the lane's own spin (x +0.0)
+  const uint32_t quads = live ? quads_of_block : 0u;
+  uint32_t most = quads;  // the widest block of the pass
+#pragma unroll
+  for (int step = 1; step < 64; step <<= 1) most = max(most, static_cast<uint32_t>(__shfl_xor(most, step, 64)));
+  uint8_t *block = stream + static_cast<uint64_t>(live ? first_slab : 0u) * slab_bytes;
+  if (live) {
+    const double h = real ? a.field[i] : 0.0;
+    const unsigned long long hb = static_cast<unsigned long long>(__double_as_longlong(h));
+    reinterpret_cast<uint4 *>(block)[slot] =
+        make_uint4(i, 0u, static_cast<uint32_t>(hb), static_cast<uint32_t>(hb >> 32));
+  }
+  for (uint32_t q = 0; q < most; ++q) {
+    if (!live || q >= quads) continue;
+    uint4 c = make_uint4(own, own, own, own);
+    double2 v01 = make_double2(0.0, 0.0), v23 = make_double2(0.0, 0.0);
+    if (q < mine) {
+      // (padding entries of a row carry the row's own index: shifted like every column)
+      c = a.rq_col[row + q];
+      c.x <<= a.col_shift;
+      c.y <<= a.col_shift;
+      c.z <<= a.col_shift;
+      c.w <<= a.col_shift;
+      v01 = a.rq_val[static_cast<uint64_t>(row + q) * 2u];
+      v23 = a.rq_val[static_cast<uint64_t>(row + q) * 2u + 1u];
+    }
+    uint8_t *quad = block + static_cast<uint64_t>(1u + 3u * q) * slab_bytes;
+    reinterpret_cast<uint4 *>(quad)[slot] = c;
+    reinterpret_cast<double2 *>(quad + slab_bytes)[slot] = v01;
+    reinterpret_cast<double2 *>(quad + 2u * slab_bytes)[slot] = v23;
+  }
 }
 
 // The three per-spin arrays of the peel — priority, number of earlier neighbours still unvisited,
@@ -227,73 +281,88 @@ __device__ __forceinline__ void shuffled_orders_impl(const Args &a, const uint32
 #define ASP_OTICK(slot) do {} while (0)
 #endif
 
-  // ---- 1. priorities ----
-  for (uint32_t i = tid; i < K; i += nthreads) {
-    prio[i] = philox4x32_10(i, t, kPriorityCounter, 0u, key0, key1).w[0];
-  }
-  if (tid == 0) ctl[0] = 0;
-  __syncthreads();
-  ASP_OTICK(0);
-
-  // ---- 2. number of earlier neighbours; spins without any open level 0 ----
-  // G lanes share a row: one quad of four neighbours per lane and trip
-  const uint32_t G = a.lanes_per_row;
-  const uint32_t sub = tid & (G - 1u), gid = tid / G, groups = nthreads / G;
-  for (uint32_t i = gid; i < K; i += groups) {
-    const uint32_t pi = prio[i];
-    const uint32_t q1 = a.rq_ptr[i + 1];
-    uint32_t count = 0;
-    for (uint32_t q = a.rq_ptr[i] + sub; q < q1; q += G) {
-      const uint4 c = a.rq_col[q];
-      const uint32_t cs[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (cs[j] != i && comes_before(prio[cs[j]], cs[j], pi, i)) ++count;
-      }
+  uint32_t levels = 0;
+  if (a.finish_only) {
+    // the wide path: k_order_level has peeled the levels; their first positions are in HBM
+    // (entries beyond the last level are zero).  The number of levels: the l with start[l] = K.
+    const uint32_t *from = a.level_start_g + static_cast<uint64_t>(s) * (a.level_cap + 2u);
+    for (uint32_t l = tid; l < a.level_cap + 2u; l += nthreads) level_start[l] = from[l];
+    if (tid == 0) ctl[4] = a.level_cap + 1u;  // (no such l: more levels than level launches — the host repeats the call)
+    __syncthreads();
+    for (uint32_t l = 1u + tid; l <= a.level_cap + 1u; l += nthreads) {
+      if (level_start[l] == K) atomicMin(&ctl[4], l);
     }
-    for (uint32_t step = G >> 1; step > 0; step >>= 1) count += __shfl_xor(count, step, 64);
-    if (sub == 0) {
-      peel.set_count(i, count);
-      if (count == 0) peel.append(&ctl[0], i);
+    __syncthreads();
+    levels = ctl[4];
+  } else {
+    // ---- 1. priorities ----
+    for (uint32_t i = tid; i < K; i += nthreads) {
+      prio[i] = philox4x32_10(i, t, kPriorityCounter, 0u, key0, key1).w[0];
     }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    ctl[1] = ctl[0];
-    level_start[0] = 0;
-    level_start[1] = ctl[0];
-  }
-  __syncthreads();
+    if (tid == 0) ctl[0] = 0;
+    __syncthreads();
+    ASP_OTICK(0);
 
-  ASP_OTICK(1);
-  // ---- 3. peel the levels ----
-  uint32_t begin = 0, end = ctl[1], levels = 0;
-  while (begin < end) {
-    ++levels;
-    for (uint32_t m = begin + gid; m < end; m += groups) {
-      const uint32_t i = peel.order_at(m);
+    // ---- 2. number of earlier neighbours; spins without any open level 0 ----
+    // G lanes share a row: one quad of four neighbours per lane and trip
+    const uint32_t G = a.lanes_per_row;
+    const uint32_t sub = tid & (G - 1u), gid = tid / G, groups = nthreads / G;
+    for (uint32_t i = gid; i < K; i += groups) {
       const uint32_t pi = prio[i];
       const uint32_t q1 = a.rq_ptr[i + 1];
+      uint32_t count = 0;
       for (uint32_t q = a.rq_ptr[i] + sub; q < q1; q += G) {
         const uint4 c = a.rq_col[q];
         const uint32_t cs[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
+  #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const uint32_t n = cs[j];
-          if (n != i && comes_before(pi, i, prio[n], n)) {
-            if (peel.visited_one(n)) peel.append(&ctl[0], n);
-          }
+          if (cs[j] != i && comes_before(prio[cs[j]], cs[j], pi, i)) ++count;
         }
+      }
+      for (uint32_t step = G >> 1; step > 0; step >>= 1) count += __shfl_xor(count, step, 64);
+      if (sub == 0) {
+        peel.set_count(i, count);
+        if (count == 0) peel.append(&ctl[0], i);
       }
     }
     __syncthreads();
     if (tid == 0) {
-      ctl[1 + (levels & 1u)] = ctl[0];
-      if (levels + 1u <= a.level_cap + 1u) level_start[levels + 1u] = ctl[0];
+      ctl[1] = ctl[0];
+      level_start[0] = 0;
+      level_start[1] = ctl[0];
     }
     __syncthreads();
-    begin = end;
-    end = ctl[1 + (levels & 1u)];
+
+    ASP_OTICK(1);
+    // ---- 3. peel the levels ----
+    uint32_t begin = 0, end = ctl[1];
+    while (begin < end) {
+      ++levels;
+      for (uint32_t m = begin + gid; m < end; m += groups) {
+        const uint32_t i = peel.order_at(m);
+        const uint32_t pi = prio[i];
+        const uint32_t q1 = a.rq_ptr[i + 1];
+        for (uint32_t q = a.rq_ptr[i] + sub; q < q1; q += G) {
+          const uint4 c = a.rq_col[q];
+          const uint32_t cs[4] = {c.x, c.y, c.z, c.w};
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t n = cs[j];
+            if (n != i && comes_before(pi, i, prio[n], n)) {
+              if (peel.visited_one(n)) peel.append(&ctl[0], n);
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        ctl[1 + (levels & 1u)] = ctl[0];
+        if (levels + 1u <= a.level_cap + 1u) level_start[levels + 1u] = ctl[0];
+      }
+      __syncthreads();
+      begin = end;
+      end = ctl[1 + (levels & 1u)];
+    }
   }
   // (begin == K here: the priority order is a total order, so the peel reaches every spin)
   const uint32_t L = levels;
@@ -392,46 +461,13 @@ __device__ __forceinline__ void shuffled_orders_impl(const Args &a, const uint32
   }
 
   ASP_OTICK(5);
-  // ---- 7. the sweep's coupling stream ----
-  uint8_t *stream = a.stream + static_cast<uint64_t>(s) * a.stream_kib * 1024u;
-  const uint32_t slab_bytes = 16u << a.log_s;
-  for (uint32_t b0 = wave * per_pass; b0 < B; b0 += waves * per_pass) {
-    const uint32_t b = b0 + pass_block;
-    const bool live = b < B;
-    const uint32_t i = live ? sop[(b << a.log_s) + slot] : kDummySpin;
-    const bool real = i != kDummySpin;
-    const uint32_t row = real ? a.rq_ptr[i] : 0u;
-    const uint32_t mine = real ? a.rq_ptr[i + 1] - row : 0u;
-    const uint32_t own = real ? i << a.col_shift : 0u;  // padding reads the lane's own spin (x +0.0)
-    const uint32_t quads = live ? block_quads[b] : 0u;
-    uint32_t most = quads;  // the widest block of the pass
-#pragma unroll
-    for (int step = 1; step < 64; step <<= 1) most = max(most, static_cast<uint32_t>(__shfl_xor(most, step, 64)));
-    uint8_t *block = stream + static_cast<uint64_t>(live ? block_first[b] : 0u) * slab_bytes;
-    if (live) {
-      const double h = real ? a.field[i] : 0.0;
-      const unsigned long long hb = static_cast<unsigned long long>(__double_as_longlong(h));
-      reinterpret_cast<uint4 *>(block)[slot] =
-          make_uint4(i, 0u, static_cast<uint32_t>(hb), static_cast<uint32_t>(hb >> 32));
-    }
-    for (uint32_t q = 0; q < most; ++q) {
-      if (!live || q >= quads) continue;
-      uint4 c = make_uint4(own, own, own, own);
-      double2 v01 = make_double2(0.0, 0.0), v23 = make_double2(0.0, 0.0);
-      if (q < mine) {
-        // (padding entries of a row carry the row's own index: shifted like every column)
-        c = a.rq_col[row + q];
-        c.x <<= a.col_shift;
-        c.y <<= a.col_shift;
-        c.z <<= a.col_shift;
-        c.w <<= a.col_shift;
-        v01 = a.rq_val[static_cast<uint64_t>(row + q) * 2u];
-        v23 = a.rq_val[static_cast<uint64_t>(row + q) * 2u + 1u];
-      }
-      uint8_t *quad = block + static_cast<uint64_t>(1u + 3u * q) * slab_bytes;
-      reinterpret_cast<uint4 *>(quad)[slot] = c;
-      reinterpret_cast<double2 *>(quad + slab_bytes)[slot] = v01;
-      reinterpret_cast<double2 *>(quad + 2u * slab_bytes)[slot] = v23;
+  // ---- 7. the sweep's coupling stream (the wide path writes it from a grid of its own) ----
+  if (!a.finish_only) {
+    uint8_t *stream = a.stream + static_cast<uint64_t>(s) * a.stream_kib * 1024u;
+    for (uint32_t b0 = wave * per_pass; b0 < B; b0 += waves * per_pass) {
+      const uint32_t b = b0 + pass_block;
+      const bool live = b < B;
+      write_stream_pass(a, stream, sop, b, live, live ? block_first[b] : 0u, live ? block_quads[b] : 0u, lane);
     }
   }
 
@@ -463,6 +499,153 @@ __device__ __forceinline__ void shuffled_orders_body(const Args &a, const uint32
   } else {
     shuffled_orders_impl<false>(a, s);
   }
+}
+
+// ---------------------------------------------------------------------------
+// The wide path of the order build (clusters whose per-spin arrays do not fit the LDS).
+// One workgroup per sweep is a chain of dependent HBM accesses per row — read the level's spin,
+// its row pointers, its columns, the neighbours' priorities, a device-scope atomic — with a
+// handful of rows in flight: 13.5 ms per chunk for the order-2 models of the kagome_36 pipeline
+// (1.5e5 .. 3e5 spins), 70 % of its annealing time, beside sweep kernels of 6-8 ms
+// (profiles/r04_pipeline_trace.txt).  Here every phase without a dependence between rows is a
+// grid over ALL (problem, sweep) pairs of the chunk — priorities, counts, the stream —, and the
+// peel is LEVEL-SYNCHRONOUS ACROSS THE GRID: launch l visits level l of every pair (the launch
+// boundary is the barrier), rows by the thousand in flight.  Per pair: cnt[l % 3] members of
+// level l, start[l % 3] its first position in the order (launch l reads slot l % 3, appends
+// through slot (l + 1) % 3 and clears slot (l + 2) % 3 for launch l + 1).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kWideThreads = 256;
+
+template <typename Args>
+__device__ __forceinline__ void order_prio_body(const Args &a, uint32_t s, uint32_t part, uint32_t parts) {
+  if (!a.finish_only) return;  // (a problem of the fused path in a shared launch)
+  const uint32_t K = a.num_spins, t = a.first_sweep + s;
+  const uint32_t key0 = static_cast<uint32_t>(a.seed), key1 = static_cast<uint32_t>(a.seed >> 32);
+  uint32_t *prio = a.prio + static_cast<uint64_t>(s) * K;
+  for (uint32_t i = part * blockDim.x + threadIdx.x; i < K; i += parts * blockDim.x) {
+    prio[i] = philox4x32_10(i, t, kPriorityCounter, 0u, key0, key1).w[0];
+  }
+  if (part == 0) {  // the pair's control words and level table start from zero
+    uint32_t *ctl = a.peel_ctl + static_cast<uint64_t>(s) * 8u;
+    if (threadIdx.x < 8u) ctl[threadIdx.x] = 0u;
+    uint32_t *starts = a.level_start_g + static_cast<uint64_t>(s) * (a.level_cap + 2u);
+    for (uint32_t l = threadIdx.x; l < a.level_cap + 2u; l += blockDim.x) starts[l] = 0u;
+  }
+}
+
+template <typename Args>
+__device__ __forceinline__ void order_counts_body(const Args &a, uint32_t s, uint32_t part, uint32_t parts) {
+  if (!a.finish_only) return;
+  const uint32_t K = a.num_spins;
+  const uint32_t G = a.lanes_per_row, tid = threadIdx.x;
+  const uint32_t sub = tid & (G - 1u), gid = tid / G, groups = blockDim.x / G;
+  const uint32_t *prio = a.prio + static_cast<uint64_t>(s) * K;
+  uint32_t *indeg = a.indeg + static_cast<uint64_t>(s) * K;
+  uint32_t *order = a.order + static_cast<uint64_t>(s) * K;
+  uint32_t *ctl = a.peel_ctl + static_cast<uint64_t>(s) * 8u;
+  // (trip counts are uniform over the G lanes of a row; the shuffles below stay inside them)
+  for (uint32_t i = part * groups + gid; i < K; i += parts * groups) {
+    const uint32_t pi = prio[i];
+    const uint32_t q1 = a.rq_ptr[i + 1];
+    uint32_t count = 0;
+    for (uint32_t q = a.rq_ptr[i] + sub; q < q1; q += G) {
+      const uint4 c = a.rq_col[q];
+      const uint32_t cs[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (cs[j] != i && comes_before(prio[cs[j]], cs[j], pi, i)) ++count;
+      }
+    }
+    for (uint32_t step = G >> 1; step > 0; step >>= 1) count += __shfl_xor(count, step, 64);
+    if (sub == 0) {
+      indeg[i] = count;
+      if (count == 0) order[atomicAdd(&ctl[0], 1u)] = i;  // level 0
+    }
+  }
+}
+
+template <typename Args>
+__device__ __forceinline__ void order_level_body(const Args &a, uint32_t s, uint32_t part, uint32_t parts,
+                                                 uint32_t l) {
+  if (!a.finish_only) return;
+  uint32_t *ctl = a.peel_ctl + static_cast<uint64_t>(s) * 8u;
+  const uint32_t lo = ctl[3u + l % 3u], n = ctl[l % 3u];  // (written by earlier launches: stable here)
+  if (n == 0) return;                                     // the pair has no level l: peeled already
+  const uint32_t K = a.num_spins;
+  const uint32_t G = a.lanes_per_row, tid = threadIdx.x;
+  const uint32_t sub = tid & (G - 1u), gid = tid / G, groups = blockDim.x / G;
+  const uint32_t *prio = a.prio + static_cast<uint64_t>(s) * K;
+  uint32_t *indeg = a.indeg + static_cast<uint64_t>(s) * K;
+  uint32_t *order = a.order + static_cast<uint64_t>(s) * K;
+  uint32_t *next = ctl + (l + 1u) % 3u;
+  const uint32_t base = lo + n;  // first position of level l + 1
+  if (part == 0 && tid == 0) {
+    ctl[3u + (l + 1u) % 3u] = base;
+    ctl[(l + 2u) % 3u] = 0u;  // (level l - 1's count: read by launch l - 1 only)
+    if (l + 1u <= a.level_cap + 1u) a.level_start_g[static_cast<uint64_t>(s) * (a.level_cap + 2u) + l + 1u] = base;
+  }
+  for (uint32_t m = part * groups + gid; m < n; m += parts * groups) {
+    const uint32_t i = order[lo + m];
+    const uint32_t pi = prio[i];
+    const uint32_t q1 = a.rq_ptr[i + 1];
+    for (uint32_t q = a.rq_ptr[i] + sub; q < q1; q += G) {
+      const uint4 c = a.rq_col[q];
+      const uint32_t cs[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t nb = cs[j];
+        if (nb != i && comes_before(pi, i, prio[nb], nb)) {
+          if (atomicSub(indeg + nb, 1u) == 1u) order[base + atomicAdd(next, 1u)] = nb;
+        }
+      }
+    }
+  }
+}
+
+template <typename Args>
+__device__ __forceinline__ void order_stream_body(const Args &a, uint32_t s, uint32_t part, uint32_t parts) {
+  if (!a.finish_only) return;
+  const uint32_t L = a.num_levels[s];
+  if (L == 0) return;  // (the sweep ran out of room: flagged, the host repeats the call)
+  const uint32_t B = a.level_block[static_cast<uint64_t>(s) * (a.level_cap + 1u) + L];
+  const uint2 *meta = a.block_meta + static_cast<uint64_t>(s) * a.block_cap;
+  const uint32_t *sop = a.spin_of_pos + (static_cast<uint64_t>(s) * a.block_cap << a.log_s);
+  uint8_t *stream = a.stream + static_cast<uint64_t>(s) * a.stream_kib * 1024u;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  const uint32_t per_pass = 64u >> a.log_s, pass_block = lane >> a.log_s;
+  for (uint32_t b0 = (part * waves + wave) * per_pass; b0 < B; b0 += parts * waves * per_pass) {
+    const uint32_t b = b0 + pass_block;
+    const bool live = b < B;
+    const uint2 info = live ? meta[b] : make_uint2(0u, 0u);
+    write_stream_pass(a, stream, sop, b, live, info.x, info.y, lane);
+  }
+}
+
+// Launch shapes: blockIdx -> (problem, sweep of the chunk, part of the pair's work); `problems` of a
+// single call is one descriptor (the same kernels serve asp_sa_anneal_shuffled and the batch).
+struct WideGrid {
+  uint32_t count, parts;  // sweeps of the chunk, workgroups per (problem, sweep)
+};
+template <typename F>
+__device__ __forceinline__ void wide_dispatch(const OrderArgs *problems, WideGrid g, F body) {
+  using ConstArgs = const OrderArgs __attribute__((address_space(4)));
+  const uint32_t per_problem = g.count * g.parts;
+  const uint32_t problem = blockIdx.x / per_problem, rest = blockIdx.x - problem * per_problem;
+  ConstArgs *a = reinterpret_cast<ConstArgs *>(reinterpret_cast<uintptr_t>(problems + problem));
+  body(*a, rest / g.parts, rest % g.parts);
+}
+__global__ __launch_bounds__(kWideThreads) void k_order_prio(const OrderArgs *problems, WideGrid g) {
+  wide_dispatch(problems, g, [&](const auto &a, uint32_t s, uint32_t part) { order_prio_body(a, s, part, g.parts); });
+}
+__global__ __launch_bounds__(kWideThreads) void k_order_counts(const OrderArgs *problems, WideGrid g) {
+  wide_dispatch(problems, g, [&](const auto &a, uint32_t s, uint32_t part) { order_counts_body(a, s, part, g.parts); });
+}
+__global__ __launch_bounds__(kWideThreads) void k_order_level(const OrderArgs *problems, WideGrid g, uint32_t level) {
+  wide_dispatch(problems, g,
+                [&](const auto &a, uint32_t s, uint32_t part) { order_level_body(a, s, part, g.parts, level); });
+}
+__global__ __launch_bounds__(kWideThreads) void k_order_stream(const OrderArgs *problems, WideGrid g) {
+  wide_dispatch(problems, g, [&](const auto &a, uint32_t s, uint32_t part) { order_stream_body(a, s, part, g.parts); });
 }
 
 __global__ __launch_bounds__(kOrderThreads) void k_shuffled_orders(OrderArgs a) {
@@ -786,6 +969,17 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
   const uint32_t waves = a.waves;
   const uint32_t team = TEAMS == 1 ? 0u : __builtin_amdgcn_readfirstlane(tid >> 6) / waves;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6) - team * waves;
+#ifdef ASP_SHUF_PRIO
+  // experiment: the wavefront with the widest blocks of every level (wave 0: the levels are sorted
+  // by row length) issues first where it shares a SIMD with another workgroup's wavefront
+  if (wave == 0) {
+    __builtin_amdgcn_s_setprio(3);
+  } else if (wave == 1) {
+    __builtin_amdgcn_s_setprio(2);
+  } else if (wave == 2) {
+    __builtin_amdgcn_s_setprio(1);
+  }
+#endif
   const uint32_t r0 = a.replica_first + group * MT;  // first chain of the (lane's) group
   const uint32_t c0 = team * M;                      // first chain of this wavefront's team
   // this team's chains inside a spin's LDS word (byte per chain) or byte (bit per chain)
@@ -1175,6 +1369,7 @@ __global__ __launch_bounds__(512) void k_sa_sweep_shuffled_batch(const ShuffledA
                                                                  const ShuffledSlot *slots) {
   using ConstArgs = const ShuffledArgs __attribute__((address_space(4)));
   const ShuffledSlot slot = slots[blockIdx.x];
+  if (slot.problem == 0xFFFFFFFFu) return;  // (padding of the XCD-aware slot table)
   ConstArgs *a = reinterpret_cast<ConstArgs *>(
       reinterpret_cast<uintptr_t>(problems + __builtin_amdgcn_readfirstlane(slot.problem)));
   shuffled_sweep_body<M, LAYOUT, 1, PK>(*a, __builtin_amdgcn_readfirstlane(slot.group));
@@ -1283,6 +1478,32 @@ int ensure_static(asp_sa_plan *p) {
   return ASP_OK;
 }
 
+// The wide launches of one chunk in front of the per-sweep workgroups (k_shuffled_orders with
+// finish_only): priorities, counts, one launch per level.  `problems`: device descriptors of the
+// chunk (P of them), `now` sweeps; parts: workgroups per (problem, sweep).
+struct WidePartsMax {
+  uint32_t prio = 1, counts = 1, level = 1, stream = 1, levels = 0;
+};
+int launch_wide_front(hipStream_t os, const OrderArgs *problems, uint32_t P, uint32_t now, const WidePartsMax &w) {
+  hipLaunchKernelGGL(k_order_prio, dim3(P * now * w.prio), dim3(kWideThreads), 0, os, problems, WideGrid{now, w.prio});
+  ASP_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_order_counts, dim3(P * now * w.counts), dim3(kWideThreads), 0, os, problems,
+                     WideGrid{now, w.counts});
+  ASP_HIP_TRY(hipGetLastError());
+  for (uint32_t l = 0; l < w.levels; ++l) {
+    hipLaunchKernelGGL(k_order_level, dim3(P * now * w.level), dim3(kWideThreads), 0, os, problems,
+                       WideGrid{now, w.level}, l);
+  }
+  ASP_HIP_TRY(hipGetLastError());
+  return ASP_OK;
+}
+int launch_wide_stream(hipStream_t os, const OrderArgs *problems, uint32_t P, uint32_t now, const WidePartsMax &w) {
+  hipLaunchKernelGGL(k_order_stream, dim3(P * now * w.stream), dim3(kWideThreads), 0, os, problems,
+                     WideGrid{now, w.stream});
+  ASP_HIP_TRY(hipGetLastError());
+  return ASP_OK;
+}
+
 // ---------------------------------------------------------------------------
 // One call = one ShuffledRun: set-up, then attempts (enqueue everything, collect the status
 // words; an order kernel that ran out of room makes the run grow its capacities and try again
@@ -1379,8 +1600,12 @@ struct ShuffledRun {
     } else if (p->shuffled_m) {
       m = p->shuffled_m;
     } else {
+      // (eight chains — the byte layout — only when that still leaves TWO workgroups per compute
+      // unit: 2048 chains on K = 12 870 run at 99.7 G flips/s as 512 groups of four and at 70 G
+      // as 256 groups of eight, profiles/r03_shuffled_scan.txt)
       for (int cand : {8, 4, 2}) {
-        if ((repetitions + cand - 1) / cand >= static_cast<uint32_t>(p->num_cus)) {
+        const uint32_t want_groups = static_cast<uint32_t>(p->num_cus) * (cand == 8 ? 2u : 1u);
+        if ((repetitions + cand - 1) / cand >= want_groups) {
           m = cand;
           break;
         }
@@ -1441,7 +1666,18 @@ struct ShuffledRun {
     packed_lanes = false;
     if (teams == 1 && m <= 4 && !std::getenv("ASP_SHUFFLED_NO_PACKING")) {
       const double mean_level = static_cast<double>(K) / levels_guess;
-      uint32_t want = std::max(4u, std::min(64u, next_pow2(static_cast<uint32_t>(std::ceil(0.75 * mean_level)))));
+      // ... and a QUARTER of the mean level in a batch that oversubscribes the chip: blocks of 16-32
+      // spins up to ~8000 spins, i.e. half to a quarter of the workgroups (each with more wavefronts
+      // and G = 2-4 groups).  What such a batch needs is to be RESIDENT at once: at two wavefronts
+      // per SIMD the 128-problem production mix was 7 % over the chip's capacity with blocks of 64
+      // above 2500 spins, and every chunk launch then takes two critical paths instead of one
+      // (2560 sweeps, sweeps alone: 0.80 s; with factor <= 0.5: 0.62 s = the critical path of the
+      // largest clusters, the same for 64 .. 112 problems; profiles/r04_shuffled_batch_trace.txt).
+      // A call that does not fill the chip keeps blocks of 64 where a level has them: lane packing
+      // costs an add per gather and per-lane chain ids (K = 3000 x 64 chains: 43.7 against 49.5 ms).
+      double s_factor = batch_saturates ? 0.25 : 0.75;
+      if (const char *env = std::getenv("ASP_SHUFFLED_S_FACTOR")) s_factor = std::atof(env);
+      uint32_t want = std::max(4u, std::min(64u, next_pow2(static_cast<uint32_t>(std::ceil(s_factor * mean_level)))));
       if (const char *env = std::getenv("ASP_SHUFFLED_LOG_S")) {
         want = 1u << std::max(2l, std::min(6l, std::strtol(env, nullptr, 10)));
       }
@@ -1495,6 +1731,27 @@ struct ShuffledRun {
   int layout = kBytes;
   size_t lds = 0, order_lds = 0;
   bool order_in_lds = false;
+  bool wide_orders = false;  // the order build as grids over the chunk (k_order_*): large clusters
+  bool trimmed_levels = false, levels_overran = false;  // fewer level launches than level_cap / that was too few
+  DeviceBuffer<uint32_t> d_peel_ctl[kLanes], d_level_start[kLanes];
+  DeviceBuffer<OrderArgs> d_oargs;  // descriptors of every chunk (the single call's wide launches)
+  std::vector<OrderArgs> h_oargs;
+
+  // Workgroups per (problem, sweep) of the wide kernels for a cluster of `spins` spins.
+  struct WideParts {
+    uint32_t prio, counts, level, stream;
+  };
+  static WideParts wide_parts(uint64_t spins, uint32_t lanes_per_row, uint32_t log_s) {
+    auto clamp = [](uint64_t v, uint64_t hi) { return static_cast<uint32_t>(std::max<uint64_t>(1, std::min(v, hi))); };
+    const uint64_t groups = kWideThreads / std::max(1u, lanes_per_row);  // rows per workgroup and trip
+    WideParts w;
+    w.prio = clamp((spins + kWideThreads * 8 - 1) / (kWideThreads * 8), 64);
+    w.counts = clamp((spins + groups * 16 - 1) / (groups * 16), 128);
+    w.level = clamp((spins / 48 + groups * 16 - 1) / (groups * 16), 16);  // (a level: ~ 1/60 of the spins)
+    const uint64_t blocks = (spins >> log_s) + 64, per_workgroup = (kWideThreads / 64) * (64u >> log_s) * 8;
+    w.stream = clamp((blocks + per_workgroup - 1) / per_workgroup, 128);
+    return w;
+  }
   ShuffledKernel kernel = nullptr;
   int nsets = 1, nlanes = 1;
   OrderArgs oa{};
@@ -1542,6 +1799,7 @@ struct ShuffledRun {
     order_in_lds = K < 65536 && p->rq_max_quads * 4u <= 255u && !std::getenv("ASP_SHUFFLED_ORDER_IN_HBM") &&
                    order_lds_bytes(level_cap, block_cap, order_threads / 64, K) <= p->max_lds * 9 / 16;
     order_lds = order_lds_bytes(level_cap, block_cap, order_threads / 64, order_in_lds ? K : 0);
+    wide_orders = !order_in_lds && !std::getenv("ASP_SHUFFLED_ORDER_FUSED");
     if (order_lds > p->max_lds) {
       return asp::set_error(ASP_ERR_TOO_LARGE, "%u levels x %u blocks do not fit the order kernel's LDS",
                             level_cap, block_cap);
@@ -1563,6 +1821,10 @@ struct ShuffledRun {
       ASP_TRY(d_prio[i].ensure(scratch));
       ASP_TRY(d_indeg[i].ensure(scratch));
       ASP_TRY(d_order[i].ensure(scratch));
+      if (wide_orders) {
+        ASP_TRY(d_peel_ctl[i].ensure(static_cast<uint64_t>(chunk) * 8));
+        ASP_TRY(d_level_start[i].ensure(static_cast<uint64_t>(chunk) * (level_cap + 2)));
+      }
     }
     for (int i = 0; i < nsets; ++i) {
       OrderSet &o = sets[i];
@@ -1589,6 +1851,7 @@ struct ShuffledRun {
     oa.log_s = log_s;
     oa.threads = order_threads;
     oa.lds_arrays = order_in_lds ? 1u : 0u;
+    oa.finish_only = wide_orders ? 1u : 0u;
     oa.col_shift = layout == kWide ? 2u : 0u;
     oa.status = d_status.ptr;
     sa = ShuffledArgs{};
@@ -1624,6 +1887,8 @@ struct ShuffledRun {
     x.prio = d_prio[lane].ptr;
     x.indeg = d_indeg[lane].ptr;
     x.order = d_order[lane].ptr;
+    x.peel_ctl = d_peel_ctl[lane].ptr;
+    x.level_start_g = d_level_start[lane].ptr;
     x.first_sweep = done;
     x.count = now;
     x.level_block = o.level_block.ptr;
@@ -1662,6 +1927,29 @@ struct ShuffledRun {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(order_lds)));
     }
     ASP_TRY(plan_buffers(chunk));
+    WidePartsMax wide;
+    trimmed_levels = false;
+    if (wide_orders) {
+      // descriptors of every chunk on the device (the wide kernels read them from a table)
+      h_oargs.clear();
+      for (uint32_t done = 0, turn = 0; done < num_sweeps; done += chunk, ++turn) {
+        OrderArgs o_args;
+        ShuffledArgs unused;
+        chunk_args(turn, done, std::min(chunk, num_sweeps - done), turn == 0, &o_args, &unused);
+        h_oargs.push_back(o_args);
+      }
+      if (!h_oargs.empty()) {
+        ASP_TRY(d_oargs.ensure(h_oargs.size()));
+        ASP_TRY(d_oargs.upload(h_oargs.data(), h_oargs.size(), s));
+        ASP_HIP_TRY(hipEventRecord(p->ev[0], s));  // (the order streams wait for this event below)
+      }
+      const WideParts parts = wide_parts(K, lanes_per_row, log_s);
+      wide.prio = parts.prio;
+      wide.counts = parts.counts;
+      wide.level = parts.level;
+      wide.stream = parts.stream;
+      wide.levels = level_cap;
+    }
     for (int i = 0; i < nlanes; ++i) {
       ASP_HIP_TRY(hipStreamWaitEvent(order_stream[i].stream, p->ev[0], 0));  // status zeroed, buffers ours
     }
@@ -1678,9 +1966,22 @@ struct ShuffledRun {
         // the orders of this chunk: after the sweep kernel that last read this buffer set has let
         // go of it; chunks alternate between the two order streams (a scratch area each)
         if (turn >= static_cast<uint32_t>(nsets)) ASP_HIP_TRY(hipStreamWaitEvent(os, swept[which], 0));
+        if (wide_orders) ASP_TRY(launch_wide_front(os, d_oargs.ptr + turn, 1, now, wide));
         hipLaunchKernelGGL(k_shuffled_orders, dim3(now), dim3(order_threads), order_lds, os, o_args);
         ASP_HIP_TRY(hipGetLastError());
+        if (wide_orders) ASP_TRY(launch_wide_stream(os, d_oargs.ptr + turn, 1, now, wide));
         ASP_HIP_TRY(hipEventRecord(ordered[which], os));
+        if (wide_orders && turn == 0 && !levels_overran) {
+          // One launch per level: the capacity (level_cap) is about twice what a sweep has, and
+          // an empty launch still dispatches its whole grid.  After the FIRST chunk the host looks
+          // at the levels its sweeps had and launches a quarter more than that from then on; a
+          // later sweep with more levels flags the call, which is repeated with all of them.
+          uint32_t seen = 0;
+          ASP_HIP_TRY(hipStreamSynchronize(os));
+          ASP_HIP_TRY(hipMemcpy(&seen, d_status.ptr + kStatLevels, sizeof seen, hipMemcpyDeviceToHost));
+          if (seen > 0 && seen <= level_cap) wide.levels = std::min(level_cap, seen + seen / 4 + 8);
+          trimmed_levels = wide.levels < level_cap;
+        }
         ASP_HIP_TRY(hipStreamWaitEvent(s, ordered[which], 0));
       }
       hipLaunchKernelGGL(kernel, dim3(wgs), dim3(waves * teams * 64), lds, s, s_args);
@@ -1708,9 +2009,16 @@ struct ShuffledRun {
   int grow(bool *again) {
     *again = false;
     if (status[kStatBad] == 0) return ASP_OK;
-    if (++attempt > 4) {
+    if (++attempt > 5) {
       return asp::set_error(ASP_ERR_TOO_LARGE, "visiting orders of %u levels / %u quads per sweep do not fit",
                             status[kStatLevels], status[kStatQuads]);
+    }
+    if (trimmed_levels && status[kStatLevels] > level_cap) {
+      // (a sweep had more levels than the trimmed number of level launches: once more with all)
+      trimmed_levels = false;
+      levels_overran = true;
+      *again = true;
+      return ASP_OK;
     }
     if (status[kStatLevels] > level_cap) {
       level_cap = static_cast<uint32_t>(std::min<uint64_t>(K, 2ull * status[kStatLevels] + 16));
@@ -1773,6 +2081,8 @@ struct ShuffledRun {
     p->last_groups = static_cast<int>(groups);
     p->last_shuffled_log_s = log_s;
     p->last_shuffled_wgs = wgs;
+    p->last_shuffled_blocks = status[kStatBlocks];
+    p->last_shuffled_quads = status[kStatQuads];
     if (!batched) {
       ASP_HIP_TRY(hipEventElapsedTime(&p->last_sweep_ms, p->ev[0], p->ev[2]));
       ASP_HIP_TRY(hipEventElapsedTime(&p->last_total_ms, p->ev[0], p->ev[3]));
@@ -1818,6 +2128,7 @@ ShuffledBatchKernel shuffled_batch_kernel_for(int m, int layout, bool packed_lan
     case 1: return k_sa_sweep_shuffled_batch<1, kBytes>;
     case 2: return k_sa_sweep_shuffled_batch<2, kBytes>;
     case 4: return k_sa_sweep_shuffled_batch<4, kBytes>;
+    case 8: return k_sa_sweep_shuffled_batch<8, kBytes>;
     default: return nullptr;
   }
 }
@@ -1853,7 +2164,7 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
   }
   // (declared before the streams: released after the streams have been waited for, also on an
   // early error return)
-  DeviceBuffer<OrderArgs> d_oargs;
+  DeviceBuffer<OrderArgs> d_oargs, d_oargs_wide;
   DeviceBuffer<ShuffledArgs> d_sargs;
   asp::ScopedStream order_stream[ShuffledRun::kLanes];
   for (auto &o : order_stream) ASP_TRY(o.acquire());
@@ -1864,7 +2175,7 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
   // block size) — eleven streams on the production mix — kernels waiting for their chunk's orders
   // blocked the queues of kernels that could have run (profiles/r04_shuffled_batch_trace.txt).
   struct Class {
-    int layout;
+    int layout, m;
     uint32_t waves = 0;  // of the launch: the most any member wants
     bool packed_lanes;
     std::vector<uint32_t> members;
@@ -1901,12 +2212,13 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
       ShuffledRun *r = runs[i];
       Class *c = nullptr;
       for (auto &k : classes) {
-        if (k->layout == r->layout && k->packed_lanes == r->packed_lanes) c = k.get();
+        if (k->layout == r->layout && k->m == r->m && k->packed_lanes == r->packed_lanes) c = k.get();
       }
       if (!c) {
         classes.emplace_back(new Class());
         c = classes.back().get();
         c->layout = r->layout;
+        c->m = r->m;
         c->packed_lanes = r->packed_lanes;
         ASP_TRY(c->stream.acquire());
         for (auto &e : c->swept) ASP_TRY(events.make(&e));
@@ -1915,7 +2227,6 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
       c->lds = std::max(c->lds, r->lds);
       c->waves = std::max(c->waves, r->waves);
     }
-    const int m = runs[0]->m;
     // (a kernel is keyed by (m, layout, packing), a class also by its wavefronts and block size:
     // classes may share a kernel, and its dynamic-LDS limit must cover the largest of them)
     std::vector<std::pair<ShuffledBatchKernel, size_t>> kernel_lds;
@@ -1924,16 +2235,31 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
       // the cluster's size, but the large clusters have more levels and wider rows
       std::stable_sort(c->members.begin(), c->members.end(),
                        [&](uint32_t x, uint32_t y) { return runs[x]->K > runs[y]->K; });
-      std::vector<ShuffledSlot> slots;
+      // XCD-aware slot table: workgroups are dealt round-robin over the chip's eight XCDs (blocks b
+      // and b + 8 share one, each XCD with an L2 of its own), so the workgroups of ONE problem get
+      // slots of equal index mod 8 — the sweep's coupling stream, read by every workgroup of the
+      // problem, is then fetched from HBM by one L2 instead of eight (a placement for speed only:
+      // nothing depends on it).  Problems go to the XCD with the fewest workgroups so far.
+      std::vector<ShuffledSlot> per_xcd[8];
       for (uint32_t i : c->members) {
-        for (uint32_t g = 0; g < runs[i]->wgs; ++g) slots.push_back(ShuffledSlot{i, g});
+        int least = 0;
+        for (int x = 1; x < 8; ++x) {
+          if (per_xcd[x].size() < per_xcd[least].size()) least = x;
+        }
+        for (uint32_t g = 0; g < runs[i]->wgs; ++g) per_xcd[least].push_back(ShuffledSlot{i, g});
+      }
+      size_t longest = 0;
+      for (auto &list : per_xcd) longest = std::max(longest, list.size());
+      std::vector<ShuffledSlot> slots;
+      for (size_t j = 0; j < longest; ++j) {
+        for (auto &list : per_xcd) slots.push_back(j < list.size() ? list[j] : ShuffledSlot{0xFFFFFFFFu, 0u});
       }
       c->num_slots = static_cast<uint32_t>(slots.size());
       ASP_TRY(c->slots.alloc(slots.size()));
       ASP_TRY(c->slots.upload(slots.data(), slots.size(), c->stream.stream));
       ASP_HIP_TRY(hipStreamSynchronize(c->stream.stream));  // `slots` dies with this scope
-      ShuffledBatchKernel kernel = shuffled_batch_kernel_for(m, c->layout, c->packed_lanes);
-      if (!kernel) return asp::set_error(ASP_ERR_INVALID, "no batched shuffled kernel for %d chains per group", m);
+      ShuffledBatchKernel kernel = shuffled_batch_kernel_for(c->m, c->layout, c->packed_lanes);
+      if (!kernel) return asp::set_error(ASP_ERR_INVALID, "no batched shuffled kernel for %d chains per group", c->m);
       bool seen = false;
       for (auto &k : kernel_lds) {
         if (k.first == kernel) {
@@ -1966,11 +2292,42 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
     // sweep kernels alone); 2 = no sweep launches after the first chunk (the order kernels alone)
     int ablate = 0;
     if (const char *env = std::getenv("ASP_SHUFFLED_ABLATE")) ablate = std::atoi(env);
+    // the wide order launches (large clusters): shapes for the largest of them; problems of the
+    // fused path leave these kernels at once
+    WidePartsMax wide;
+    std::vector<uint32_t> wide_members;
+    bool may_trim = true;
+    for (ShuffledRun *r : runs) r->trimmed_levels = false;
+    for (uint32_t i = 0; i < P; ++i) {
+      ShuffledRun *r = runs[i];
+      if (!r->wide_orders) continue;
+      wide_members.push_back(i);
+      may_trim = may_trim && !r->levels_overran;
+      const ShuffledRun::WideParts parts = ShuffledRun::wide_parts(r->K, r->lanes_per_row, r->log_s);
+      wide.prio = std::max(wide.prio, parts.prio);
+      wide.counts = std::max(wide.counts, parts.counts);
+      wide.level = std::max(wide.level, parts.level);
+      wide.stream = std::max(wide.stream, parts.stream);
+      wide.levels = std::max(wide.levels, r->level_cap);
+    }
+    // (the wide kernels read a table of the wide problems only: their grids are workgroups per
+    // (problem, sweep), and two thirds of a pipeline round are small models of the fused path)
+    const uint32_t Pw = static_cast<uint32_t>(wide_members.size());
+    std::vector<OrderArgs> oargs_wide(static_cast<size_t>(chunks) * Pw);
+    for (uint32_t turn = 0; turn < chunks; ++turn) {
+      for (uint32_t k = 0; k < Pw; ++k) {
+        oargs_wide[static_cast<size_t>(turn) * Pw + k] = oargs[static_cast<size_t>(turn) * P + wide_members[k]];
+      }
+    }
     hipStream_t os0 = order_stream[0].stream;
     ASP_TRY(d_oargs.ensure(oargs.size()));
     ASP_TRY(d_sargs.ensure(sargs.size()));
     ASP_TRY(d_oargs.upload(oargs.data(), oargs.size(), os0));
     ASP_TRY(d_sargs.upload(sargs.data(), sargs.size(), os0));
+    if (Pw) {
+      ASP_TRY(d_oargs_wide.ensure(oargs_wide.size()));
+      ASP_TRY(d_oargs_wide.upload(oargs_wide.data(), oargs_wide.size(), os0));
+    }
     ASP_HIP_TRY(hipStreamSynchronize(os0));
     // ---- the pipeline of runs' enqueue(), with shared launches ----
     const uint32_t nsets = static_cast<uint32_t>(runs[0]->nsets), nlanes = static_cast<uint32_t>(runs[0]->nlanes);
@@ -1984,16 +2341,39 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
         if (turn >= nsets) {
           for (auto &c : classes) ASP_HIP_TRY(hipStreamWaitEvent(os, c->swept[which], 0));
         }
+        const OrderArgs *chunk_problems = d_oargs.ptr + static_cast<size_t>(turn) * P;
+        const OrderArgs *chunk_wide = Pw ? d_oargs_wide.ptr + static_cast<size_t>(turn) * Pw : nullptr;
+        if (Pw) ASP_TRY(launch_wide_front(os, chunk_wide, Pw, now, wide));
         hipLaunchKernelGGL(k_shuffled_orders_batch, dim3(P * now), dim3(order_threads), order_lds, os,
-                           d_oargs.ptr + static_cast<size_t>(turn) * P, now);
+                           chunk_problems, now);
         ASP_HIP_TRY(hipGetLastError());
+        if (Pw) ASP_TRY(launch_wide_stream(os, chunk_wide, Pw, now, wide));
         ASP_HIP_TRY(hipEventRecord(ordered[which], os));
+        if (Pw && turn == 0 && may_trim) {
+          // (as in ShuffledRun::enqueue: the levels the first chunk's sweeps had, a quarter more from now on)
+          ASP_HIP_TRY(hipStreamSynchronize(os));
+          uint32_t seen = 0;
+          bool valid = true;
+          for (uint32_t i : wide_members) {
+            uint32_t mine = 0;
+            ASP_HIP_TRY(hipMemcpy(&mine, runs[i]->d_status.ptr + kStatLevels, sizeof mine, hipMemcpyDeviceToHost));
+            valid = valid && mine > 0 && mine <= runs[i]->level_cap;
+            seen = std::max(seen, mine);
+          }
+          if (valid) {
+            const uint32_t trimmed = std::min(wide.levels, seen + seen / 4 + 8);
+            if (trimmed < wide.levels) {
+              wide.levels = trimmed;
+              for (uint32_t i : wide_members) runs[i]->trimmed_levels = true;
+            }
+          }
+        }
       }
       for (auto &c : classes) {
         if (ablate == 2 && turn > 0) continue;
         hipStream_t cs = c->stream.stream;
         if (now) ASP_HIP_TRY(hipStreamWaitEvent(cs, ordered[which], 0));
-        ShuffledBatchKernel kernel = shuffled_batch_kernel_for(m, c->layout, c->packed_lanes);
+        ShuffledBatchKernel kernel = shuffled_batch_kernel_for(c->m, c->layout, c->packed_lanes);
         hipLaunchKernelGGL(kernel, dim3(c->num_slots), dim3(c->waves * 64), c->lds, cs,
                            d_sargs.ptr + static_cast<size_t>(turn) * P, c->slots.ptr);
         ASP_HIP_TRY(hipGetLastError());
@@ -2064,7 +2444,16 @@ int sa_shuffled_batch(asp_sa_batch_item const *items, const uint32_t *which, uin
     r.out_x = it.out_x;
     r.out_e = it.out_e;
     r.budget = std::max<uint64_t>(64ull << 20, std::min<uint64_t>(3ull << 30, budget / count));
-    if (count > 1 && it.plan && !it.plan->shuffled_m) r.forced_m = m;
+    if (count > 1 && it.plan && !it.plan->shuffled_m) {
+      r.forced_m = m;
+      // A cluster beyond the word layout (a word per spin and four chains: ~3.8e4 spins) in a batch
+      // that fills the chip: eight chains per workgroup in the byte layout (setup() falls back to
+      // four / one where bytes do not fit either).  The sweep's coupling stream — 12 bytes per
+      // coupling, written once and read by EVERY workgroup of the problem — is the traffic of such a
+      // model: 350 bytes per spin and sweep over M chains; the real kagome_36 order-2 models (3.5e4 ..
+      // 3e5 spins, 64 chains each) moved 87 bytes per flip at M = 4.
+      if (saturates && it.plan->host.num_spins * 4ull > it.plan->max_lds * 15 / 16) r.forced_m = 8;
+    }
     r.batch_saturates = saturates;
     if (const char *env = std::getenv("ASP_SHUFFLED_ORDER_THREADS")) {  // (development: scanned 128 .. 1024, no effect)
       r.order_threads_cap = static_cast<uint32_t>(std::max(64l, std::min(1024l, std::strtol(env, nullptr, 10) / 64 * 64)));
@@ -2078,8 +2467,8 @@ int sa_shuffled_batch(asp_sa_batch_item const *items, const uint32_t *which, uin
     if (taken[i] || runs[i]->trivial) continue;
     std::vector<ShuffledRun *> group;
     for (size_t j = i; j < runs.size(); ++j) {
-      if (!taken[j] && !runs[j]->trivial && runs[j]->num_sweeps == runs[i]->num_sweeps && runs[j]->m == runs[i]->m &&
-          runs[j]->m <= 4) {
+      if (!taken[j] && !runs[j]->trivial && runs[j]->num_sweeps == runs[i]->num_sweeps &&
+          shuffled_batch_kernel_for(runs[j]->m, kBytes, false)) {
         group.push_back(runs[j].get());
         taken[j] = true;
       }
@@ -2137,6 +2526,18 @@ int asp_sa_last_shuffled_blocks(asp_sa_plan const *p, uint32_t *spins_per_block,
   if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
   if (spins_per_block) *spins_per_block = 1u << p->last_shuffled_log_s;
   if (workgroups) *workgroups = p->last_shuffled_wgs;
+  return ASP_OK;
+}
+
+int asp_sa_last_shuffled_fill(asp_sa_plan const *p, double *lane_fill, double *row_fill) {
+  if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
+  const double S = static_cast<double>(1u << p->last_shuffled_log_s);
+  if (lane_fill) {
+    *lane_fill = p->last_shuffled_blocks ? static_cast<double>(p->host.num_spins) / (p->last_shuffled_blocks * S) : 0.0;
+  }
+  if (row_fill) {
+    *row_fill = p->last_shuffled_quads ? static_cast<double>(p->rq_quads) / (p->last_shuffled_quads * S) : 0.0;
+  }
   return ASP_OK;
 }
 

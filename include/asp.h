@@ -446,6 +446,13 @@ int asp_sa_last_shuffled(asp_sa_plan const *p, uint32_t *levels, float *order_ms
  * workgroups of its sweep launches.  Results never depend on either; ASP_SHUFFLED_LOG_S=2..6 in
  * the environment forces the block size, ASP_SHUFFLED_NO_PACKING=1 keeps blocks of 64. */
 int asp_sa_last_shuffled_blocks(asp_sa_plan const *p, uint32_t *spins_per_block, uint32_t *workgroups);
+/* Of the last shuffled call or batch item of this plan, how full its level-major blocks were (the
+ * sweep of the call with the most blocks / quads): lane_fill = spins / lane slots (K over blocks x
+ * spins per block: what is lost to levels that do not fill their last block), row_fill = couplings
+ * of the rows (in quads) / coupling slots (blocks x their width: what is lost to a block being as
+ * wide as its longest row).  The exec-mask counters of a profiler do not see either: a padding lane
+ * and a padding coupling execute like real ones. */
+int asp_sa_last_shuffled_fill(asp_sa_plan const *p, double *lane_fill, double *row_fill);
 
 /* MANY independent problems in one call — the shape of the reference's production job: tens of
  * thousands of sampled clusters, each solved with 64 repetitions x 5120 sweeps

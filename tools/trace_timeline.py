@@ -12,7 +12,7 @@ window = float(sys.argv[3]) if len(sys.argv) > 3 else 25.0
 events = []
 for r in rows:
     n = r["Kernel_Name"]
-    if "orders" in n:
+    if "orders" in n or "k_order_" in n:
         short = "order"
     elif "sweep_shuffled" in n:
         short = "sweep<" + n.split("<")[1].split(">")[0] + ">"
