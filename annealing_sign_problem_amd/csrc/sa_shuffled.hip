@@ -1478,6 +1478,14 @@ int ensure_static(asp_sa_plan *p) {
   return ASP_OK;
 }
 
+// Level launches from the second chunk on, given the most levels a sweep of the first chunk had.
+uint32_t trimmed_level_launches(uint32_t seen) {
+  if (const char *env = std::getenv("ASP_SHUFFLED_TRIM_TO")) {  // test hook: provoke the overrun
+    return std::max(1u, static_cast<uint32_t>(std::strtoul(env, nullptr, 10)));
+  }
+  return seen + seen / 4 + 8;
+}
+
 // The wide launches of one chunk in front of the per-sweep workgroups (k_shuffled_orders with
 // finish_only): priorities, counts, one launch per level.  `problems`: device descriptors of the
 // chunk (P of them), `now` sweeps; parts: workgroups per (problem, sweep).
@@ -1747,7 +1755,9 @@ struct ShuffledRun {
     WideParts w;
     w.prio = clamp((spins + kWideThreads * 8 - 1) / (kWideThreads * 8), 64);
     w.counts = clamp((spins + groups * 16 - 1) / (groups * 16), 128);
-    w.level = clamp((spins / 48 + groups * 16 - 1) / (groups * 16), 16);  // (a level: ~ 1/60 of the spins)
+    // (a level: ~ 1/60 of the spins, the first ones twice that; a row is a chain of six dependent HBM
+    // accesses, so a level wants ALL its rows in flight at once: one or two trips per group of lanes)
+    w.level = clamp((spins / 48 + groups * 2 - 1) / (groups * 2), 64);
     const uint64_t blocks = (spins >> log_s) + 64, per_workgroup = (kWideThreads / 64) * (64u >> log_s) * 8;
     w.stream = clamp((blocks + per_workgroup - 1) / per_workgroup, 128);
     return w;
@@ -1979,7 +1989,7 @@ struct ShuffledRun {
           uint32_t seen = 0;
           ASP_HIP_TRY(hipStreamSynchronize(os));
           ASP_HIP_TRY(hipMemcpy(&seen, d_status.ptr + kStatLevels, sizeof seen, hipMemcpyDeviceToHost));
-          if (seen > 0 && seen <= level_cap) wide.levels = std::min(level_cap, seen + seen / 4 + 8);
+          if (seen > 0 && seen <= level_cap) wide.levels = std::min(level_cap, trimmed_level_launches(seen));
           trimmed_levels = wide.levels < level_cap;
         }
         ASP_HIP_TRY(hipStreamWaitEvent(s, ordered[which], 0));
@@ -2361,7 +2371,7 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
             seen = std::max(seen, mine);
           }
           if (valid) {
-            const uint32_t trimmed = std::min(wide.levels, seen + seen / 4 + 8);
+            const uint32_t trimmed = std::min(wide.levels, trimmed_level_launches(seen));
             if (trimmed < wide.levels) {
               wide.levels = trimmed;
               for (uint32_t i : wide_members) runs[i]->trimmed_levels = true;
@@ -2430,6 +2440,10 @@ int sa_shuffled_batch(asp_sa_batch_item const *items, const uint32_t *which, uin
         break;
       }
     }
+  }
+  if (const char *env = std::getenv("ASP_SHUFFLED_BATCH_M")) {  // (development: scan the chains per group of a batch)
+    const int forced = std::atoi(env);
+    if (forced == 1 || forced == 2 || forced == 4) m = forced;
   }
   for (uint32_t k = 0; k < count; ++k) {
     const asp_sa_batch_item &it = items[which[k]];

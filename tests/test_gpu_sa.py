@@ -1,6 +1,7 @@
 """GPU parity: the annealing sweep through the C ABI vs the CPU oracle (bit-exact
 packed spins, energies, tracked fixed-point energies and accepted-flip counts)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -1275,3 +1276,74 @@ def test_shuffled_lane_packing_over_many_chunks_and_in_a_batch():
         oxs, oes, _, _ = oracle.sa_anneal_shuffled(J, h, seed, betas, reps, 0, None, info.energy_scale_exp,
                                                    num_threads=16)
         assert np.array_equal(bx, oxs) and be.tobytes() == oes.tobytes()
+
+
+@pytest.mark.parametrize("n,degree,reps,sweeps,env", [
+    (3000, 12.0, 6, 40, {"ASP_SHUFFLED_ORDER_IN_HBM": "1"}),                     # the wide grids on a small cluster
+    (3000, 12.0, 6, 40, {"ASP_SHUFFLED_ORDER_IN_HBM": "1", "ASP_SHUFFLED_ORDER_FUSED": "1"}),  # one workgroup per sweep, arrays in HBM
+    (700, 9.0, 20, 300, {"ASP_SHUFFLED_ORDER_IN_HBM": "1", "ASP_SHUFFLED_BYTES": "400000"}),   # many chunks, lane packing
+    (70000, 6.0, 3, 24, {}),                                                     # beyond 16-bit indices: wide by itself
+])
+def test_shuffled_order_build_paths(monkeypatch, n, degree, reps, sweeps, env):
+    """The visiting orders are built by one of three device paths — a workgroup per sweep with the
+    peel's arrays in LDS, the same with the arrays in HBM, or (large clusters) grids over all sweeps of
+    the chunk with one launch per level — and every path must give the oracle's chains."""
+    from annealing_sign_problem_amd import annealer as sa
+
+    for key, value in env.items():
+        monkeypatch.setenv(key, value)
+    J, h, ham, info, betas = _shuffled_case(n, degree, sweeps, seed=n + 1)
+    xs, es = sa.anneal_raw(ham, 99, betas, reps, 2, None, shuffled=True)
+    oxs, oes, _, _ = oracle.sa_anneal_shuffled(J, h, 99, betas, reps, 2, None, info.energy_scale_exp,
+                                               num_threads=min(reps, 8))
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+
+
+def test_shuffled_wide_orders_trim_their_level_launches_and_recover(monkeypatch):
+    """The wide path launches one kernel per level; after the first chunk it launches only a quarter
+    more than the levels seen so far.  When a later sweep has more levels than that, the call is
+    flagged and repeated with all launches: same chains either way (here the trim is forced below the
+    number of levels)."""
+    from annealing_sign_problem_amd import annealer as sa
+
+    monkeypatch.setenv("ASP_SHUFFLED_ORDER_IN_HBM", "1")
+    monkeypatch.setenv("ASP_SHUFFLED_BYTES", "2000000")  # several chunks
+    J, h, ham, info, betas = _shuffled_case(2500, 10.0, 60, seed=17)
+    expected = sa.anneal_raw(ham, 5, betas, 4, 0, None, shuffled=True)
+    monkeypatch.setenv("ASP_SHUFFLED_TRIM_TO", "5")
+    xs, es = sa.anneal_raw(ham, 5, betas, 4, 0, None, shuffled=True)
+    assert np.array_equal(xs, expected[0]) and es.tobytes() == expected[1].tobytes()
+    oxs, oes, _, _ = oracle.sa_anneal_shuffled(J, h, 5, betas, 4, 0, None, info.energy_scale_exp, num_threads=4)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    # ... and inside a batch (shared launches, a table of the wide problems only)
+    other = _shuffled_case(400, 8.0, 60, seed=18)
+    monkeypatch.delenv("ASP_SHUFFLED_ORDER_IN_HBM")  # (the small one stays on the fused path, the large one is forced wide)
+    monkeypatch.setenv("ASP_SHUFFLED_ORDER_IN_HBM", "1")
+    results = sa.anneal_batch_raw([ham, other[2]], [5, 6], [betas, other[4]], [4, 4], shuffled=True)
+    assert np.array_equal(results[0][0], oxs) and results[0][1].tobytes() == oes.tobytes()
+    o2, e2, _, _ = oracle.sa_anneal_shuffled(other[0], other[1], 6, other[4], 4, 0, None, other[3].energy_scale_exp,
+                                             num_threads=4)
+    assert np.array_equal(results[1][0], o2) and results[1][1].tobytes() == e2.tobytes()
+
+
+def test_shuffled_fill_statistics():
+    """asp_sa_last_shuffled_fill: spins / lane slots and couplings / coupling slots of the level-major
+    blocks — what lane packing improves for small clusters and what no exec-mask counter shows."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    lib = _lib.load()
+    J, h, ham, info, betas = _shuffled_case(400, 22.0, 10, seed=3)
+    fills = {}
+    for packing in (True, False):
+        if not packing:
+            os.environ["ASP_SHUFFLED_NO_PACKING"] = "1"
+        try:
+            sa.anneal_raw(ham, 1, betas, 64, 0, None, shuffled=True)
+        finally:
+            os.environ.pop("ASP_SHUFFLED_NO_PACKING", None)
+        lane, row = ctypes.c_double(0), ctypes.c_double(0)
+        _lib.check(lib.asp_sa_last_shuffled_fill(ham.plan(), ctypes.byref(lane), ctypes.byref(row)))
+        fills[packing] = (lane.value, row.value)
+    assert 0.5 < fills[True][0] <= 1.0 and 0.3 < fills[True][1] <= 1.0
+    assert fills[False][0] < 0.3 < fills[True][0]  # ~9 spins per level: 64-lane blocks are mostly padding
