@@ -121,6 +121,25 @@ def issue_fraction(case, counters, flips_per_s):
     return per_flip * counters["cycles_per_valu_inst"] * flips_per_s / 1e9 / (NUM_SIMDS * CLOCK_GHZ)
 
 
+def lane_utilisation(case, counters):
+    """Of one profiled case: lanes with exec = 1 per VALU instruction (SQ_THREAD_CYCLES_VALU over
+    SQ_ACTIVE_INST_VALU x 64, its own rocprofv3 pass) — what the hardware counters can see; the
+    padding lanes and padding couplings of a block execute like real ones and are reported as
+    `lane_fill` / `row_fill` by the library (shuffled sweep) or follow from the plan (colour sweep)."""
+    if not counters or case not in counters.get("cases", {}):
+        return None
+    return counters["cases"][case].get("exec_lane_utilisation")
+
+
+def shuffled_fill(lib, plan):
+    lane, row = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    spins, wgs = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    lib.asp_sa_last_shuffled_fill(plan, ctypes.byref(lane), ctypes.byref(row))
+    lib.asp_sa_last_shuffled_blocks(plan, ctypes.byref(spins), ctypes.byref(wgs))
+    return {"spins_per_block": int(spins.value), "workgroups": int(wgs.value), "lane_fill": lane.value,
+            "row_fill": row.value}
+
+
 def usable_cores() -> int:
     """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     try:
@@ -404,6 +423,21 @@ def bench_batched_clusters(num_problems=128, serial_every=8):
     t0 = time.perf_counter()
     shuffled = sa.anneal_batch(hams, seed=12345, number_sweeps=sweeps, repetitions=reps, sweep_order="shuffled")
     t_shuffled = time.perf_counter() - t0
+    shuffled_kernel_ms = float(lib.asp_sa_batch_last_ms())
+    # how the batch was cut: spins per block (lane packing below 64) -> problems, workgroups, fill
+    shapes = {}
+    for ham, k in zip(hams, sizes):
+        f = shuffled_fill(lib, ham.plan())
+        e = shapes.setdefault(f["spins_per_block"], {"problems": 0, "workgroups": 0, "spins": 0, "slots": 0.0,
+                                                      "coupling_slots": 0.0, "couplings": 0.0})
+        e["problems"] += 1
+        e["workgroups"] += f["workgroups"]
+        e["spins"] += k
+        e["slots"] += k / f["lane_fill"] if f["lane_fill"] else 0.0
+    for e in shapes.values():
+        e["lane_fill"] = e["spins"] / e["slots"] if e["slots"] else None
+        for key in ("slots", "coupling_slots", "couplings"):
+            e.pop(key)
     x, e = sa.anneal(hams[subset[1]], seed=12345, number_sweeps=sweeps, repetitions=reps, sweep_order="shuffled")
     if not (np.array_equal(x, shuffled[subset[1]][0]) and e == shuffled[subset[1]][1]):
         raise RuntimeError("batched shuffled anneal disagrees with the per-cluster call")
@@ -425,6 +459,9 @@ def bench_batched_clusters(num_problems=128, serial_every=8):
         "shuffled_order_batched_s": t_shuffled,
         "shuffled_order_batched_flips_per_s": flips_all / t_shuffled,
         "shuffled_order_batched_problems_per_s": num_problems / t_shuffled,
+        "shuffled_order_batched_kernels_ms": shuffled_kernel_ms,
+        "shuffled_order_batched_kernel_flips_per_s": flips_all / (shuffled_kernel_ms * 1e-3),
+        "shuffled_order_blocks": {str(k): v for k, v in sorted(shapes.items())},
     }
 
 
@@ -596,7 +633,9 @@ def bench_shuffled_order(clusters, replicas, sweeps, offset, counters):
             "K": k, "levels_per_sweep_max": int(levels.value), "chains_per_group": m.value,
             "wavefronts": th.value // 64, "groups": g.value, "call_ms": call_s * 1e3,
             "kernels_ms": kern_s * 1e3, "kernel_flips_per_s": rate,
-            "valu_issue_frac": issue_fraction("shuffled_%d" % k, counters, rate)})
+            "valu_issue_frac": issue_fraction("shuffled_%d" % k, counters, rate),
+            "exec_lane_utilisation": lane_utilisation("shuffled_%d" % k, counters),
+            "blocks": shuffled_fill(lib, c["ham"].plan())})
         flips += k * replicas * sweeps
         seconds += call_s
         kernel_s += kern_s
@@ -613,7 +652,9 @@ def bench_shuffled_order(clusters, replicas, sweeps, offset, counters):
     out["reference_default_call"] = {
         "workload": "64 chains x 5120 sweeps, K=%d" % k, "call_s": t, "flips_per_s": k * 64 * 5120 / t,
         "kernel_flips_per_s": k * 64 * 5120 / kern,
-        "valu_issue_frac": issue_fraction("shuffled64_%d" % k, counters, k * 64 * 5120 / kern)}
+        "valu_issue_frac": issue_fraction("shuffled64_%d" % k, counters, k * 64 * 5120 / kern),
+        "exec_lane_utilisation": lane_utilisation("shuffled64_%d" % k, counters),
+        "blocks": shuffled_fill(lib, c["ham"].plan())}
     return out
 
 
@@ -784,6 +825,9 @@ def main():
             else:
                 hbm_bytes = float("nan")
         issue = issue_cycles / kernel_s if have_all else None
+        hits = [(traffic or {}).get("cases", {}).get("colour_%d" % c["J"].shape[0], {}).get("l2_hit_rate")
+                for c in clusters]
+        l2_hit = sum(hits) / len(hits) if hits and all(h is not None for h in hits) else None
         hbm_per_launch = hbm_bytes / launches if hbm_bytes == hbm_bytes and traffic else None
         mean_offdiag = sum((c["dbar"] - 1.0) * c["J"].shape[0] for c in clusters) / sum(
             c["J"].shape[0] for c in clusters)
@@ -809,6 +853,48 @@ def main():
             "frac_at_measured_clock": (issue / (NUM_SIMDS * clock) if issue is not None and clock else None),
             "hbm_measured_frac": (hbm_per_launch / (kernel_s / launches) / 1e9 / HBM_PEAK_GBS
                                   if hbm_per_launch else None),
+            # SURVEY §8(d)'s contract figures as a sub-object of their own: the HBM roofline by the
+            # letter (algorithmic bytes of a one-replica CPU sweep over the kernel's time: above 1
+            # because a row is shared by the chains of a workgroup and by the workgroups through
+            # L2), what the counters say really crossed the HBM interface, and the L2 hit rate.
+            "hbm": {
+                "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "algorithmic_achieved": alg_bytes / kernel_s / 1e9,
+                "algorithmic_frac": alg_bytes / kernel_s / 1e9 / HBM_PEAK_GBS,
+                "measured_achieved": (hbm_per_launch / (kernel_s / launches) / 1e9 if hbm_per_launch else None),
+                "measured_frac": (hbm_per_launch / (kernel_s / launches) / 1e9 / HBM_PEAK_GBS
+                                  if hbm_per_launch else None),
+                "l2_hit_rate": l2_hit,
+            },
+            # the same fraction with every proposal evaluated (field cache and inert-block skipping
+            # off; identical chains): the instructions per flip of the profiled run are those of the
+            # skipping kernel, so this is frac scaled by the rate ratio — a LOWER bound of the
+            # no-skip kernel's issue occupancy (it executes more instructions per flip, not fewer)
+            "frac_no_skip_lower_bound": (issue / peak_issue * kernel_flips_no_skip / kernel_flips
+                                         if issue is not None and kernel_flips_no_skip else None),
+            "lane_utilisation": {
+                "exec_mask": {("colour_%d" % c["J"].shape[0]): lane_utilisation("colour_%d" % c["J"].shape[0], counters)
+                              for c in clusters},
+                "slots": {str(c["J"].shape[0]): c["J"].shape[0] / (64.0 * c["info"].num_blocks) for c in clusters},
+                "rows": {str(c["J"].shape[0]): float(c["info"].nnz_offdiag) / max(1, c["info"].ell_entries)
+                         for c in clusters},
+                "note": "exec_mask: lanes with exec = 1 per VALU instruction (PMC, own pass); slots: spins per "
+                        "64-lane block slot of the colour classes; rows: couplings per ELL slot (a block is as "
+                        "wide as its longest row).  A padding lane or coupling executes like a real one.",
+            },
+            "cycles_per_valu_inst_by_class": {
+                "source": "profiles/r02_issue_rate_probe.txt (4 wavefronts per SIMD)",
+                "v_fma_f64 / v_add_f64": 4.36, "v_mul_f64": 4.92, "v_or_b32_sdwa (sign, word layout)": 4.41,
+                "v_lshl_or_b32 / v_bfi_b32 (VOP3)": 4.39, "v_mul_hi_u32 / v_mul_lo_u32 (Philox)": 4.34,
+                "v_lshlrev_b32": 4.23, "v_xor_b32 / v_add_u32 / v_lshrrev_b32 (plain VOP2)": 2.54,
+                "v_exp_f32": 8.27,
+                "note": "the guide's 2 cycles per wave64 VOP2 is what the probe finds for xor / add / right shift "
+                        "(2.5); every f64, SDWA, VOP3, left-shift and 32x32-multiply instruction issues at "
+                        "4.2-4.4.  Of the colour kernel's 1.58 instructions per flip the integer ones that are "
+                        "or could be plain VOP2 are the Philox xors and key adds (already VOP2) and the byte "
+                        "layout's sign shift (v_lshrrev since round 2); the word layout's sign is one SDWA "
+                        "instruction (4.4) for a shift + VOP3 pair (2.5 + 4.4), the rest is f64",
+            },
             "f64_fma_frac": kernel_flips * mean_offdiag * 2.0 / 1e12 / F64_VALU_PEAK_TFLOPS,
             "algorithmic_GBps": alg_bytes / kernel_s / 1e9,
             "algorithmic_bytes_per_launch": alg_bytes / launches,

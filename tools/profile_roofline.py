@@ -7,8 +7,9 @@ profiles/sweep_counters.json and profiles/traffic.json).
 Every annealing launch of the process belongs to the case (no warm-up launches), so the counters
 of all dispatches of the case's kernel, divided by the flips written to DIR/<case>.json, are per
 flip.  Cases: colour_<K>, shuffled_<K>, shuffled64_<K> (the reference's default call: 64 chains x
-5120 sweeps), batch (128 small clusters, 64 chains x 512 sweeps each), team (64 chains on a
-1e5-spin cluster), real_kagome_36 (three real clusters, colour order).
+5120 sweeps), batch / batch_shuffled (128 small clusters, 64 chains x 512 sweeps each, colour /
+shuffled order), team (64 chains on a 1e5-spin cluster), real_kagome_36 (three real clusters,
+colour order).
 """
 import argparse
 import json
@@ -52,7 +53,7 @@ def main():
             flips += k * chains * sweeps
         record.update(K=k, dbar=J.nnz / k, chains=chains, sweeps=sweeps,
                       kernel="k_sa_sweep_shuffled" if kind != "colour" else "k_sa_sweep<",
-                      side_kernels=["k_shuffled_orders"] if kind != "colour" else [])
+                      side_kernels=["k_shuffled_orders", "k_order_"] if kind != "colour" else [])
     elif kind == "batch":
         rng = np.random.default_rng(SEED)
         sizes = [int(round(np.exp(rng.uniform(np.log(1e2), np.log(1e4))))) for _ in range(128)]
@@ -60,11 +61,15 @@ def main():
         for i, k in enumerate(sizes):
             J, h, _ = synthetic.planted_cluster(k, seed=SEED + i)
             hams.append(sa.Hamiltonian(J, h))
+        shuffled = arg == "shuffled"  # case "batch" (colour order) or "batch_shuffled"
         for _ in range(a.runs):
-            sa.anneal_batch(hams, seed=12345, number_sweeps=512, repetitions=64)
+            sa.anneal_batch(hams, seed=12345, number_sweeps=512, repetitions=64,
+                            sweep_order="shuffled" if shuffled else "colour")
             sweep_ms.append(float(lib.asp_sa_batch_last_ms()))
             flips += sum(sizes) * 64 * 512
-        record.update(kernel="k_sa_sweep_batch", problems=len(sizes), chains=64, sweeps=512)
+        record.update(kernel="k_sa_sweep_shuffled_batch" if shuffled else "k_sa_sweep_batch", problems=len(sizes),
+                      chains=64, sweeps=512,
+                      side_kernels=["k_shuffled_orders", "k_order_"] if shuffled else [])
     elif kind == "team":
         J, h, _ = synthetic.planted_cluster(100000, seed=1, mean_degree=8.0)
         ham = sa.Hamiltonian(J, h)

@@ -1,10 +1,11 @@
-"""Condense the rocprofv3 passes of tools/gpu_profile_r3.sh into profiles/sweep_counters.json and
+"""Condense the rocprofv3 passes of tools/gpu_profile_r4.sh into profiles/sweep_counters.json and
 profiles/traffic.json (what bench.py's `roofline` objects are computed from) and copy the kernel
 stats.  Usage: python tools/summarise_roofline.py <prof_dir> <tag>
 
 Layout of <prof_dir>: cases/<case>.json (tools/profile_roofline.py), <case>/<set>/**/*_counter_collection.csv
-for the counter sets `sq` (instruction counts, busy cycles, GRBM_GUI_ACTIVE), `fetch` (FETCH_SIZE) and
-`l2` (WRITE_SIZE, TCC hits / misses), and calib/ for tools/fetch_calibrate.hip.
+for the counter sets `sq` (instruction counts, busy cycles, GRBM_GUI_ACTIVE), `lanes`
+(SQ_THREAD_CYCLES_VALU over SQ_ACTIVE_INST_VALU: lanes with exec = 1 per VALU instruction), `fetch`
+(FETCH_SIZE) and `l2` (WRITE_SIZE, TCC hits / misses), and calib/ for tools/fetch_calibrate.hip.
 
 Both files carry the fingerprint of the library the counters were taken from
 (annealing_sign_problem_amd/build.py); bench.py refuses to compute a fraction from counters of
@@ -73,6 +74,10 @@ for path in sorted(glob.glob(os.path.join(prof, "cases", "*.json"))):
             entry["clock_ghz"] = sq["GRBM_GUI_ACTIVE"] / 8.0 / ns
         if "SQ_WAVE_CYCLES" in sq and "SQ_BUSY_CYCLES" in sq and sq["SQ_BUSY_CYCLES"]:
             entry["mean_waves_per_busy_cycle"] = sq["SQ_WAVE_CYCLES"] / sq["SQ_BUSY_CYCLES"]
+    lanes, n_lanes, _ = counters(os.path.join(prof, case, "lanes"), rec["kernel"])
+    if n_lanes and lanes.get("SQ_ACTIVE_INST_VALU"):
+        # lanes with exec = 1 per VALU instruction (VALUThreadUtilization of the counter definitions)
+        entry["exec_lane_utilisation"] = lanes["SQ_THREAD_CYCLES_VALU"] / (lanes["SQ_ACTIVE_INST_VALU"] * 64.0)
     fetch, n_fetch, _ = counters(os.path.join(prof, case, "fetch"), rec["kernel"])
     l2, n_l2, _ = counters(os.path.join(prof, case, "l2"), rec["kernel"])
     if n_fetch and "FETCH_SIZE" in fetch:
@@ -114,7 +119,8 @@ common = {
     "method": "one rocprofv3 run per case and counter set (tools/gpu_profile_r3.sh): --pmc SQ_INSTS_VALU "
               "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES "
               "GRBM_GUI_ACTIVE, summed over every dispatch of the case's kernel and divided by the flip "
-              "attempts of the case; clock = GRBM_GUI_ACTIVE / 8 / kernel time",
+              "attempts of the case; clock = GRBM_GUI_ACTIVE / 8 / kernel time; exec_lane_utilisation = "
+              "SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64) from a pass of its own (tools/gpu_profile_r4.sh)",
 }
 counters_out = dict(common)
 counters_out["cases"] = {k: {kk: vv for kk, vv in v.items() if not kk.startswith("hbm_") and kk != "l2_hit_rate"}
