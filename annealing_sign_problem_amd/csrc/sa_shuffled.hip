@@ -75,6 +75,7 @@ struct OrderArgs {
   uint32_t log_s;                           // a block is S = 1 << log_s spins of one level (S = 4 .. 64)
   uint32_t lanes_per_row;                   // power of two <= 64: lanes sharing a row in the graph passes
   uint32_t threads;                         // threads of this problem's order workgroups (a multiple of 64)
+  uint32_t num_quads, max_quads;            // quads of all rows of A / of its longest row
   uint32_t lds_arrays;                      // 1: priorities, counters and the order in LDS (PeelArrays)
   // The WIDE path (large clusters: the per-spin arrays in HBM): priorities, counts, every level of
   // the peel and the stream are kernels of their own over ALL sweeps of the chunk (k_order_prio,
@@ -83,6 +84,7 @@ struct OrderArgs {
   uint32_t finish_only;                     // 1: the levels have been peeled by k_order_level
   uint32_t *peel_ctl;                       // [count][8]: members of level l % 3 | first position of level l % 3 | -
   uint32_t *level_start_g;                  // [count][level_cap + 2] first position of every level
+  uint8_t *later;                           // [count][quads of A] bit j: entry j of the quad is a LATER neighbour
   uint32_t col_shift;                       // columns are written as (neighbour << col_shift): LDS addresses
   // scratch, [count][K] each
   uint32_t *prio, *indeg, *order;
@@ -544,6 +546,9 @@ __device__ __forceinline__ void order_counts_body(const Args &a, uint32_t s, uin
   uint32_t *order = a.order + static_cast<uint64_t>(s) * K;
   uint32_t *ctl = a.peel_ctl + static_cast<uint64_t>(s) * 8u;
   // (trip counts are uniform over the G lanes of a row; the shuffles below stay inside them)
+  // later[q]: which entries of quad q are neighbours that come AFTER the row's spin — the peel then
+  // needs no priorities (four random gathers per quad and a link of its dependence chain less)
+  uint8_t *later = a.later + static_cast<uint64_t>(s) * a.num_quads;
   for (uint32_t i = part * groups + gid; i < K; i += parts * groups) {
     const uint32_t pi = prio[i];
     const uint32_t q1 = a.rq_ptr[i + 1];
@@ -551,10 +556,18 @@ __device__ __forceinline__ void order_counts_body(const Args &a, uint32_t s, uin
     for (uint32_t q = a.rq_ptr[i] + sub; q < q1; q += G) {
       const uint4 c = a.rq_col[q];
       const uint32_t cs[4] = {c.x, c.y, c.z, c.w};
+      uint32_t mask = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (cs[j] != i && comes_before(prio[cs[j]], cs[j], pi, i)) ++count;
+        if (cs[j] != i) {
+          if (comes_before(prio[cs[j]], cs[j], pi, i)) {
+            ++count;
+          } else {
+            mask |= 1u << j;
+          }
+        }
       }
+      later[q] = static_cast<uint8_t>(mask);
     }
     for (uint32_t step = G >> 1; step > 0; step >>= 1) count += __shfl_xor(count, step, 64);
     if (sub == 0) {
@@ -562,6 +575,21 @@ __device__ __forceinline__ void order_counts_body(const Args &a, uint32_t s, uin
       if (count == 0) order[atomicAdd(&ctl[0], 1u)] = i;  // level 0
     }
   }
+}
+
+// `push`: this lane appends `value` to the list at list[base + ...] whose length is *tail — ONE atomic
+// per wavefront instruction (the lanes that push are counted by a ballot), not one per lane: a level
+// of thousands of spins otherwise serialises on its tail counter.
+__device__ __forceinline__ void wave_append(bool push, uint32_t value, uint32_t *list, uint32_t base,
+                                            uint32_t *tail) {
+  const uint64_t pushing = __ballot(push);
+  if (pushing == 0ull) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(pushing));
+  uint32_t first = 0;
+  if (lane == leader) first = atomicAdd(tail, static_cast<uint32_t>(__builtin_popcountll(pushing)));
+  first = __shfl(first, static_cast<int>(leader), 64);
+  if (push) list[base + first + static_cast<uint32_t>(__builtin_popcountll(pushing & ((1ull << lane) - 1ull)))] = value;
 }
 
 template <typename Args>
@@ -574,7 +602,6 @@ __device__ __forceinline__ void order_level_body(const Args &a, uint32_t s, uint
   const uint32_t K = a.num_spins;
   const uint32_t G = a.lanes_per_row, tid = threadIdx.x;
   const uint32_t sub = tid & (G - 1u), gid = tid / G, groups = blockDim.x / G;
-  const uint32_t *prio = a.prio + static_cast<uint64_t>(s) * K;
   uint32_t *indeg = a.indeg + static_cast<uint64_t>(s) * K;
   uint32_t *order = a.order + static_cast<uint64_t>(s) * K;
   uint32_t *next = ctl + (l + 1u) % 3u;
@@ -584,19 +611,36 @@ __device__ __forceinline__ void order_level_body(const Args &a, uint32_t s, uint
     ctl[(l + 2u) % 3u] = 0u;  // (level l - 1's count: read by launch l - 1 only)
     if (l + 1u <= a.level_cap + 1u) a.level_start_g[static_cast<uint64_t>(s) * (a.level_cap + 2u) + l + 1u] = base;
   }
-  for (uint32_t m = part * groups + gid; m < n; m += parts * groups) {
-    const uint32_t i = order[lo + m];
-    const uint32_t pi = prio[i];
-    const uint32_t q1 = a.rq_ptr[i + 1];
-    for (uint32_t q = a.rq_ptr[i] + sub; q < q1; q += G) {
-      const uint4 c = a.rq_col[q];
+  const uint8_t *later = a.later + static_cast<uint64_t>(s) * a.num_quads;
+  // (every lane of the wavefront runs the same number of trips — lanes without a row or a quad
+  // take part in the ballots of wave_append with nothing to push)
+  const uint32_t trips = (n + parts * groups - 1u) / (parts * groups);
+  const uint32_t quad_trips = (a.max_quads + G - 1u) / G;
+  for (uint32_t trip = 0; trip < trips; ++trip) {
+    const uint32_t m = (trip * parts + part) * groups + gid;
+    const bool have_row = m < n;
+    const uint32_t i = have_row ? order[lo + m] : 0u;
+    const uint32_t q0 = have_row ? a.rq_ptr[i] : 0u, q1 = have_row ? a.rq_ptr[i + 1] : 0u;
+    // (rows are at most max_quads long; the loop bound is uniform, most rows end earlier)
+    uint32_t longest = q1 - q0;
+#pragma unroll
+    for (int step = 1; step < 64; step <<= 1) longest = max(longest, static_cast<uint32_t>(__shfl_xor(longest, step, 64)));
+    const uint32_t my_trips = min(quad_trips, (longest + G - 1u) / G);
+    for (uint32_t qt = 0; qt < my_trips; ++qt) {
+      const uint32_t q = q0 + qt * G + sub;
+      const bool have_quad = q < q1;
+      uint4 c = make_uint4(0u, 0u, 0u, 0u);
+      uint32_t mask = 0;
+      if (have_quad) {
+        c = a.rq_col[q];
+        mask = later[q];
+      }
       const uint32_t cs[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const uint32_t nb = cs[j];
-        if (nb != i && comes_before(pi, i, prio[nb], nb)) {
-          if (atomicSub(indeg + nb, 1u) == 1u) order[base + atomicAdd(next, 1u)] = nb;
-        }
+        const bool is_later = (mask >> j) & 1u;
+        const bool last = is_later && atomicSub(indeg + cs[j], 1u) == 1u;
+        wave_append(last, cs[j], order, base, next);
       }
     }
   }
@@ -1742,6 +1786,7 @@ struct ShuffledRun {
   bool wide_orders = false;  // the order build as grids over the chunk (k_order_*): large clusters
   bool trimmed_levels = false, levels_overran = false;  // fewer level launches than level_cap / that was too few
   DeviceBuffer<uint32_t> d_peel_ctl[kLanes], d_level_start[kLanes];
+  DeviceBuffer<uint8_t> d_later[kLanes];
   DeviceBuffer<OrderArgs> d_oargs;  // descriptors of every chunk (the single call's wide launches)
   std::vector<OrderArgs> h_oargs;
 
@@ -1834,6 +1879,7 @@ struct ShuffledRun {
       if (wide_orders) {
         ASP_TRY(d_peel_ctl[i].ensure(static_cast<uint64_t>(chunk) * 8));
         ASP_TRY(d_level_start[i].ensure(static_cast<uint64_t>(chunk) * (level_cap + 2)));
+        ASP_TRY(d_later[i].ensure(static_cast<uint64_t>(chunk) * p->rq_quads));
       }
     }
     for (int i = 0; i < nsets; ++i) {
@@ -1860,6 +1906,8 @@ struct ShuffledRun {
     oa.lanes_per_row = lanes_per_row;
     oa.log_s = log_s;
     oa.threads = order_threads;
+    oa.num_quads = p->rq_quads;
+    oa.max_quads = p->rq_max_quads;
     oa.lds_arrays = order_in_lds ? 1u : 0u;
     oa.finish_only = wide_orders ? 1u : 0u;
     oa.col_shift = layout == kWide ? 2u : 0u;
@@ -1899,6 +1947,7 @@ struct ShuffledRun {
     x.order = d_order[lane].ptr;
     x.peel_ctl = d_peel_ctl[lane].ptr;
     x.level_start_g = d_level_start[lane].ptr;
+    x.later = d_later[lane].ptr;
     x.first_sweep = done;
     x.count = now;
     x.level_block = o.level_block.ptr;
