@@ -1593,9 +1593,14 @@ struct ShuffledRun {
   // the sweep kernel of a third: an order workgroup is a chain of dependent global accesses (23 ms
   // for a sweep of 1e5 spins), so their THROUGHPUT is workgroups in flight / that latency, and a
   // 128-sweep call has only 32 sweeps per chunk to offer.
-  static constexpr int kSets = 3, kLanes = 2;
+  // (round 4, -DASP_SHUF_LANES=2/3/4/6: no difference on the kagome_36 pipeline — 23.6 / 23.7 / 23.1 s —
+  // nor on the synthetic batches, and every lane is one more buffer set to allocate)
+#ifndef ASP_SHUF_LANES
+#define ASP_SHUF_LANES 2
+#endif
+  static constexpr int kLanes = ASP_SHUF_LANES, kSets = kLanes + 1;
   asp::ScopedStream order_stream[kLanes];
-  hipEvent_t ordered[kSets] = {nullptr, nullptr, nullptr}, swept[kSets] = {nullptr, nullptr, nullptr};
+  hipEvent_t ordered[kSets] = {}, swept[kSets] = {};
   DeviceBuffer<double> d_betas, d_partial, d_e;
   DeviceBuffer<uint64_t> d_x0, d_best, d_perm;
   DeviceBuffer<uint8_t> d_state;
@@ -1848,7 +1853,8 @@ struct ShuffledRun {
     const uint64_t per_sweep = static_cast<uint64_t>(stream_kib) * 1024 + static_cast<uint64_t>(block_cap) * (4 * S + 8) +
                                (level_cap + 1ull) * 4 + 12ull * K;
     chunk = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(256, budget / per_sweep)));
-    chunk = std::max(1u, std::min(chunk, (num_sweeps + 3) / 4));  // at least four chunks: the pipeline needs them
+    // (at least two chunks per order lane: the pipeline needs them)
+    chunk = std::max(1u, std::min(chunk, (num_sweeps + 2 * kLanes - 1) / (2 * kLanes)));
     // the peel's arrays in LDS when they fit half of it (the sweep workgroups of the previous chunk
     // are resident beside the order workgroups) and the counters fit a byte
     order_in_lds = K < 65536 && p->rq_max_quads * 4u <= 255u && !std::getenv("ASP_SHUFFLED_ORDER_IN_HBM") &&
@@ -2242,7 +2248,7 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
     asp::ScopedStream stream;
     uint32_t num_slots = 0;
     size_t lds = 0;
-    hipEvent_t swept[ShuffledRun::kSets] = {nullptr, nullptr, nullptr};
+    hipEvent_t swept[ShuffledRun::kSets] = {};
   };
   EventPool events;
   hipEvent_t ordered[ShuffledRun::kSets], t_begin, t_end;
