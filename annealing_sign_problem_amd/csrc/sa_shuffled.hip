@@ -751,7 +751,11 @@ __device__ __forceinline__ uint32_t to_lds(uint32_t mask) {
 // The LDS representation of spin i.
 template <int LAYOUT>
 __device__ __forceinline__ uint32_t read_spin(const uint8_t *spins, uint32_t i) {
-  if constexpr (LAYOUT == kWide) {
+  if constexpr (LAYOUT == kGlobal) {
+    // a 32-bit word per spin in HBM (one chain): written by other wavefronts of the workgroup in
+    // earlier levels — read at device scope, past the compute unit's vector L1
+    return __hip_atomic_load(reinterpret_cast<const uint32_t *>(spins) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if constexpr (LAYOUT == kWide) {
     return reinterpret_cast<const uint32_t *>(spins)[i];
   } else if constexpr (kPackedLayout<LAYOUT>) {
     constexpr uint32_t B = kSpinBits<LAYOUT>;
@@ -828,14 +832,19 @@ __device__ __forceinline__ void load_quad_slabs(HeldQuad &q, BufferRsrc stream, 
   q.v23 = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(stream, lane16, at + 2u * slab, 0));
 }
 
-// (`gbase`, lane packing only: LDS byte address of the spins of the lane's group)
+// (`gbase`, lane packing only: LDS byte address of the spins of the lane's group; `hbm`, kGlobal only:
+// the chain's spin words in HBM)
 template <int LAYOUT, bool PK = false>
-__device__ __forceinline__ void gather_quad(const HeldQuad &q, uint32_t (&s)[4], uint32_t gbase = 0) {
+__device__ __forceinline__ void gather_quad(const HeldQuad &q, uint32_t (&s)[4], uint32_t gbase = 0,
+                                            const uint8_t *hbm = nullptr) {
   const uint32_t cs[4] = {q.c.x, q.c.y, q.c.z, q.c.w};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     // columns are LDS byte addresses (sa_device.hpp: the spins start at LDS address 0)
-    if constexpr (LAYOUT == kWide && PK) {
+    if constexpr (LAYOUT == kGlobal) {  // (columns: byte offsets of the spins' words)
+      s[j] = __hip_atomic_load(reinterpret_cast<const uint32_t *>(hbm + cs[j]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    } else if constexpr (LAYOUT == kWide && PK) {
       s[j] = *reinterpret_cast<LdsWord *>(static_cast<uintptr_t>(cs[j] + gbase));
     } else if constexpr (LAYOUT == kWide) {
       s[j] = *reinterpret_cast<LdsWord *>(static_cast<uintptr_t>(cs[j]));
@@ -970,7 +979,13 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
   constexpr bool WIDE = LAYOUT == kWide;
   constexpr int MT = M * TEAMS;  // chains of a group
   constexpr bool PACKED = kPackedLayout<LAYOUT>;
-  static_assert(LAYOUT == kWide || LAYOUT == kBytes || PACKED, "spins are LDS words, bytes, nibbles or bits");
+  // kGlobal: a 32-bit word per spin in HBM (one chain per workgroup) — clusters beyond the LDS even
+  // at a bit per spin (~6e5 spins): every neighbour gather is an L2 access, the slow path that makes
+  // the DEFAULT visiting order accept a cluster of any size, as the colour order does
+  constexpr bool GLOBAL = LAYOUT == kGlobal;
+  static_assert(LAYOUT == kWide || LAYOUT == kBytes || PACKED || GLOBAL,
+                "spins are LDS words, bytes, nibbles or bits, or words in HBM");
+  static_assert(!GLOBAL || (M == 1 && TEAMS == 1 && !PK), "spins in HBM: one chain per workgroup");
   static_assert(!WIDE || MT <= 4, "the wide layout holds up to four chains");
   static_assert(!PACKED || (TEAMS == 1 && M <= static_cast<int>(kSpinBits<LAYOUT>)),
                 "a packed layout holds as many chains as it has bits per spin, in one team");
@@ -998,9 +1013,12 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
   const uint32_t group = wg * G + lg;                      // ... and inside the call
   const bool group_live = !PK || group < a.groups_total;   // (the last workgroup may have idle groups)
   const uint32_t gbase = PK ? lg * K * 4u : 0u;            // LDS byte address of the group's spins
-  uint8_t *spins = lds;  // original order: K words (byte m = 0x80 * chain m is -1) or K bytes, per group
+  // original order: K words (byte m = 0x80 * chain m is -1) or K bytes, per group; kGlobal: the
+  // chain's words in a.state (there a word per spin), which also carries them between chunks
+  uint8_t *spins = GLOBAL ? a.state + static_cast<uint64_t>(wg) * K * 4u : lds;
   uint32_t *wide = reinterpret_cast<uint32_t *>(lds);
-  const uint32_t P = ((WIDE ? G * K * 4u : (PACKED ? (K * kSpinBits<LAYOUT> + 7u) / 8u : K)) + 15u) & ~15u;
+  const uint32_t P = GLOBAL ? 0u
+                            : ((WIDE ? G * K * 4u : (PACKED ? (K * kSpinBits<LAYOUT> + 7u) / 8u : K)) + 15u) & ~15u;
   long long *delta = reinterpret_cast<long long *>(lds + P);  // [CH] energy change of the running sweep
   long long *book = delta + CH;  // [c] current tracked energy, [CH + c] best, [2 CH + c] accepted flips
   uint32_t *improved_flag = reinterpret_cast<uint32_t *>(book + 3 * CH);  // [2] bit c: chain c improved
@@ -1042,6 +1060,7 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
     const bool live = !PK || gg < a.groups_total;  // (workgroup-uniform)
     const uint8_t *state_g = a.state + static_cast<uint64_t>(gg) * K;
     const uint32_t r0g = a.replica_first + gg * MT;
+    if (GLOBAL && !a.initialise) break;  // (the words are where the previous chunk left them)
     for (uint32_t i = tid; i < K; i += nthreads) {
       uint32_t mask;
       if (!live) {
@@ -1064,7 +1083,9 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
           mask |= ((pick_word(rnd, r & 3u) & 1u) ^ 1u) << m;  // bit 0 of the word: 1 -> s = +1
         }
       }
-      if constexpr (WIDE) {
+      if constexpr (GLOBAL) {
+        __hip_atomic_store(reinterpret_cast<uint32_t *>(spins) + i, mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if constexpr (WIDE) {
         wide[g * K + i] = spread_mask(mask);
       } else if constexpr (PACKED) {
         constexpr uint32_t B = kSpinBits<LAYOUT>;
@@ -1084,6 +1105,7 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
     delta[x] = v;
   }
   if (tid < 2) improved_flag[tid] = 0;
+  if constexpr (GLOBAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stores above, before the barrier)
   __syncthreads();
   if (a.initialise) {
     for (uint32_t g = 0; g < G; ++g) {
@@ -1203,11 +1225,11 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
           // oracle's); the LDS gather of quad j + 1 is issued before the FMAs of quad j (past the
           // block's last quad it reads whatever the registers held: harmless, never applied)
           uint32_t sa[4], sb[4];
-          gather_quad<LAYOUT, PK>(hq[0], sa, gbase);
+          gather_quad<LAYOUT, PK>(hq[0], sa, gbase, spins);
 #pragma unroll
           for (int j = 0; j < kHeldQuads; ++j) {
             if (static_cast<uint32_t>(j) < quads) {
-              if (j + 1 < kHeldQuads) gather_quad<LAYOUT, PK>(hq[j + 1], (j & 1) ? sa : sb, gbase);
+              if (j + 1 < kHeldQuads) gather_quad<LAYOUT, PK>(hq[j + 1], (j & 1) ? sa : sb, gbase, spins);
               __builtin_amdgcn_sched_barrier(0);
               if constexpr (TEAMS > 1) {  // this team's chains to the low end (a plain VOP2 shift)
 #pragma unroll
@@ -1225,7 +1247,7 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
               // (one quad past the block at the end: never used)
               load_quad_at(qb, j + 1u);
               __builtin_amdgcn_sched_barrier(0);
-              gather_quad<LAYOUT, PK>(qa, sa, gbase);
+              gather_quad<LAYOUT, PK>(qa, sa, gbase, spins);
               if constexpr (TEAMS > 1) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) sa[k] >>= team_shift;
@@ -1301,6 +1323,9 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
               } else {
                 reinterpret_cast<uint8_t *>(wide + me)[team] = static_cast<uint8_t>(own ^ spread_mask(flip));
               }
+            } else if constexpr (GLOBAL) {
+              __hip_atomic_store(reinterpret_cast<uint32_t *>(spins) + me, own ^ flip, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
             } else if constexpr (WIDE) {
               wide[(gbase >> 2) + me] = own ^ spread_mask(flip);
             } else if constexpr (PACKED) {
@@ -1323,6 +1348,8 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
         b = nb;
       }
 #if ASP_SHUF_ABL != 4
+      // (spins in HBM: the flips must have arrived before another wavefront gathers them)
+      if constexpr (GLOBAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
 #endif
       ASP_TICK(3);
@@ -1380,6 +1407,7 @@ __device__ __forceinline__ void shuffled_sweep_body(const Args &a, const uint32_
 #endif
 
   for (uint32_t g = 0; g < G; ++g) {
+    if (GLOBAL) break;  // (the spin words ARE the state)
     const uint32_t gg = wg * G + g;
     if (PK && gg >= a.groups_total) break;
     uint8_t *state_g = a.state + static_cast<uint64_t>(gg) * K;
@@ -1463,6 +1491,7 @@ ShuffledKernel shuffled_kernel_for(int m, int layout, int teams = 1, bool packed
     }
   }
   if (layout == kBits) return m == 1 ? k_sa_sweep_shuffled<1, kBits, 1> : nullptr;
+  if (layout == kGlobal) return m == 1 ? k_sa_sweep_shuffled<1, kGlobal, 1> : nullptr;
   switch (m) {
     case 1: return k_sa_sweep_shuffled<1, kBytes, 1>;
     case 2: return k_sa_sweep_shuffled<2, kBytes, 1>;
@@ -1475,7 +1504,7 @@ ShuffledKernel shuffled_kernel_for(int m, int layout, int teams = 1, bool packed
 // spins (of `groups` groups: lane packing) | delta[CH] book[3 CH] | flags (16 B) | meta[block_cap] |
 // level_block[level_cap + 2]; CH = 8 chains, 64 with lane packing (groups > 0)
 size_t sweep_lds_bytes(uint64_t K, int layout, uint32_t level_cap, uint32_t block_cap, uint32_t groups = 0) {
-  uint64_t spin_bytes = layout == kWide ? K * 4 : (layout == kNibbles ? (K + 1) / 2 : (layout == kBits ? (K + 7) / 8 : K));
+  uint64_t spin_bytes = layout == kGlobal ? 0 : (layout == kWide ? K * 4 : (layout == kNibbles ? (K + 1) / 2 : (layout == kBits ? (K + 7) / 8 : K)));
   if (groups) spin_bytes *= groups;
   return ((spin_bytes + 15) & ~size_t{15}) + (groups ? 256 : 32) * sizeof(long long) + 16 +
          static_cast<size_t>(block_cap) * sizeof(uint2) + (static_cast<size_t>(level_cap) + 2) * sizeof(uint32_t);
@@ -1487,6 +1516,8 @@ int shuffled_layout_for(uint64_t K, int m, uint32_t level_cap, uint32_t block_ca
   if (sweep_lds_bytes(K, kBytes, level_cap, block_cap) <= max_lds) return kBytes;
   if (m <= 4 && sweep_lds_bytes(K, kNibbles, level_cap, block_cap) <= max_lds) return kNibbles;
   if (m == 1 && sweep_lds_bytes(K, kBits, level_cap, block_cap) <= max_lds) return kBits;
+  // beyond a bit per spin in LDS: the spins of a chain as words in HBM (one chain per workgroup)
+  if (m == 1 && sweep_lds_bytes(K, kGlobal, level_cap, block_cap) <= max_lds) return kGlobal;
   return -1;
 }
 
@@ -1766,7 +1797,9 @@ struct ShuffledRun {
     }
     hipStream_t s = p->stream;
     ASP_TRY(d_betas.alloc(num_sweeps));
-    ASP_TRY(d_state.alloc(static_cast<uint64_t>(groups) * K));
+    // (a byte per spin and group between chunks — or, beyond every LDS layout, the chains' spin words)
+    const bool spins_in_hbm = shuffled_layout_for(K, m, level_cap, words + level_cap, p->max_lds) == kGlobal;
+    ASP_TRY(d_state.alloc(static_cast<uint64_t>(groups) * K * (spins_in_hbm ? 4 : 1)));
     ASP_TRY(d_best.alloc(padded * words));
     ASP_TRY(d_ecur.alloc(padded));
     ASP_TRY(d_ebest.alloc(padded));
@@ -1916,8 +1949,10 @@ struct ShuffledRun {
     oa.max_quads = p->rq_max_quads;
     oa.lds_arrays = order_in_lds ? 1u : 0u;
     oa.finish_only = wide_orders ? 1u : 0u;
-    oa.col_shift = layout == kWide ? 2u : 0u;
+    oa.col_shift = (layout == kWide || layout == kGlobal) ? 2u : 0u;  // (byte offsets of 32-bit spin words)
     oa.status = d_status.ptr;
+    // (the layout may change between attempts — capacities grow —: the HBM form needs a word per spin)
+    ASP_TRY(d_state.ensure(static_cast<uint64_t>(groups) * K * (layout == kGlobal ? 4 : 1)));
     sa = ShuffledArgs{};
     sa.status = d_status.ptr;
     sa.betas = d_betas.ptr;
@@ -2189,6 +2224,7 @@ ShuffledBatchKernel shuffled_batch_kernel_for(int m, int layout, bool packed_lan
     }
   }
   if (layout == kBits) return m == 1 ? k_sa_sweep_shuffled_batch<1, kBits> : nullptr;
+  if (layout == kGlobal) return m == 1 ? k_sa_sweep_shuffled_batch<1, kGlobal> : nullptr;
   switch (m) {
     case 1: return k_sa_sweep_shuffled_batch<1, kBytes>;
     case 2: return k_sa_sweep_shuffled_batch<2, kBytes>;

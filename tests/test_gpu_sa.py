@@ -1347,3 +1347,24 @@ def test_shuffled_fill_statistics():
         fills[packing] = (lane.value, row.value)
     assert 0.5 < fills[True][0] <= 1.0 and 0.3 < fills[True][1] <= 1.0
     assert fills[False][0] < 0.3 < fills[True][0]  # ~9 spins per level: 64-lane blocks are mostly padding
+
+
+def test_shuffled_sweep_with_the_spins_in_hbm(monkeypatch):
+    """Beyond a bit per spin in LDS (~6e5 spins) the default visiting order keeps a chain's spins as
+    words in HBM (one chain per workgroup, every gather an L2 access): slow, but `sa.anneal` then
+    accepts a cluster of any size in its default order, as it does in the colour order.  Parity on
+    a cluster that needs it (sparse, so that the oracle finishes), and forced on a small one."""
+    from annealing_sign_problem_amd import _lib
+    from annealing_sign_problem_amd import annealer as sa
+
+    n = 700000
+    J, h, _ = _planted(n, 5, mean_degree=3.0)
+    ham = sa.Hamiltonian(J, h)
+    info = ham.info()
+    betas = sa.make_schedule(info.beta0_auto, info.beta1_auto, 6)
+    xs, es = sa.anneal_raw(ham, 3, betas, 2, 1, None, shuffled=True)
+    oxs, oes, _, _ = oracle.sa_anneal_shuffled(J, h, 3, betas, 2, 1, None, info.energy_scale_exp, num_threads=2)
+    assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    # the public entry point in its default order
+    x, e = sa.anneal(ham, seed=3, number_sweeps=4, repetitions=1)
+    assert x.shape == ((n + 63) // 64,) and np.isfinite(e)
