@@ -72,7 +72,10 @@ struct Pool {
   std::unordered_map<void *, PoolBlock> live;                 // handed out
   std::map<std::pair<int, size_t>, std::vector<void *>> idle;  // (device, class) -> blocks
   size_t idle_bytes = 0;
-  size_t cap = 16ull << 30;  // of 288 GB: sixteen pipeline threads each recycle ~0.3 GB of buffers
+  // of 288 GB: sixteen pipeline threads each recycle ~0.3 GB of buffers, and a batched shuffled
+  // anneal three sets of up to 16 GB of visiting orders per round of the pipeline — with a cap of
+  // 16 GB those were given back to and taken from the driver every round (0.2 s per batch call)
+  size_t cap = 64ull << 30;
   Pool() {
     if (const char *env = std::getenv("ASP_POOL_BYTES")) cap = std::strtoull(env, nullptr, 10);
   }

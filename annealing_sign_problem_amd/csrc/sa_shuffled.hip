@@ -31,7 +31,9 @@
 //   chain state waits in HBM between chunks.  Integer + f64 work bound by per-level latency
 //   and VALU issue: no MFMA.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <memory>
 #include <vector>
@@ -2513,6 +2515,16 @@ namespace asp {
 // asp_sa_anneal_shuffled call.  Items are grouped by their number of sweeps; the problems of a
 // group share launches (run_shuffled_group), a group of one takes the single-problem path.
 int sa_shuffled_batch(asp_sa_batch_item const *items, const uint32_t *which, uint32_t count, float *sweep_ms) {
+  // ASP_SHUFFLED_HOST_TIMING=1: wall-clock phases of this function on stderr (development aid)
+  const bool host_timing = std::getenv("ASP_SHUFFLED_HOST_TIMING") != nullptr;
+  auto phase_start = std::chrono::steady_clock::now();
+  auto phase = [&](const char *name) {
+    if (!host_timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "  shuffled batch: %-18s %8.2f ms\n", name,
+                 std::chrono::duration<double, std::milli>(now - phase_start).count());
+    phase_start = now;
+  };
   std::vector<std::unique_ptr<ShuffledRun>> runs;
   runs.reserve(count);
   uint64_t budget = 16ull << 30;  // bytes of visiting orders for the whole batch, per buffer set
@@ -2565,6 +2577,7 @@ int sa_shuffled_batch(asp_sa_batch_item const *items, const uint32_t *which, uin
     }
     ASP_TRY(r.setup());
   }
+  phase("setup");
   // groups of equal ladder length (and equal chains per workgroup: a plan with a forced width
   // keeps it and runs alone)
   std::vector<bool> taken(runs.size(), false);
@@ -2590,11 +2603,15 @@ int sa_shuffled_batch(asp_sa_batch_item const *items, const uint32_t *which, uin
       }
     }
   }
+  phase("launches + wait");
   for (auto &r : runs) ASP_TRY(r->finish_enqueue());
   for (auto &r : runs) {
     ASP_TRY(r->finish_wait());
     if (sweep_ms && r->p && !r->batched) *sweep_ms += r->p->last_sweep_ms;
   }
+  phase("energies + copies");
+  runs.clear();
+  phase("release");
   return ASP_OK;
 }
 

@@ -420,14 +420,17 @@ int asp_sa_anneal_trace(asp_sa_plan *p, uint64_t seed, double const *betas, uint
 
 /* asp_sa_anneal with a fresh visiting order every sweep — what the reference's annealer almost
  * certainly does (its published success probabilities are reproduced by this order and by no
- * fixed one: DESIGN.md §6.1).  Sweep t visits the spins in ascending (priority, index), priority =
- * word 0 of Philox4x32-10(counter (i, t, 0xFFFFFFFE, 0), key seed); every chain uses the same
- * order.  Proposal arithmetic, random words, energy bookkeeping, outputs and determinism are those
- * of asp_sa_anneal; only the order differs.  The orders are built ON THE DEVICE, a chunk of sweeps
- * at a time (csrc/sa_shuffled.hip: priorities, levels of the priority graph, the sweep's couplings
- * re-laid level by level), by a kernel that runs beside the sweep kernel of the previous chunk;
- * spins stay in LDS in original order (K <= ~1.6e5).  out_x / out_e may be host or device
- * pointers.  asp_sa_last_layout reports 5. */
+ * fixed one: DESIGN.md §6.1), and therefore the order the Python entry points use by default.
+ * Sweep t visits the spins in ascending (priority, index), priority = word 0 of
+ * Philox4x32-10(counter (i, t, 0xFFFFFFFE, 0), key seed); every chain uses the same order.
+ * Proposal arithmetic, random words, energy bookkeeping, outputs and determinism are those of
+ * asp_sa_anneal; only the order differs.  The orders are built ON THE DEVICE, a chunk of sweeps at
+ * a time (csrc/sa_shuffled.hip: priorities, levels of the priority graph, the sweep's couplings
+ * re-laid level by level in blocks of 4 .. 64 spins), beside the sweep kernel of the previous
+ * chunk: a workgroup per sweep with its arrays in LDS for clusters up to ~1.2e4 spins, grids over
+ * all sweeps of the chunk with one launch per level beyond.  Spins stay in LDS in original order
+ * (a word, a byte, four bits or one bit per spin: up to ~6e5 spins) and in HBM beyond that.
+ * out_x / out_e may be host or device pointers.  asp_sa_last_layout reports 5. */
 int asp_sa_anneal_shuffled(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_sweeps,
                            uint32_t repetitions, uint32_t replica_offset, uint64_t const *x0,
                            uint64_t *out_x, double *out_e);
@@ -463,8 +466,11 @@ int asp_sa_last_shuffled_fill(asp_sa_plan const *p, double *lane_fill, double *r
  * clusters fills the chip instead of leaving > 90 % of it idle launch by launch.  Plans must
  * be distinct.  Problems that need the bit-packed spin layouts, and a batch of one, take the
  * single-problem path inside the call.  Items with ASP_SA_BATCH_SHUFFLED in `flags` are
- * asp_sa_anneal_shuffled calls (a fresh visiting order every sweep): their kernels are queued on
- * the plans' own streams before any of them is waited for, so they overlap on the device. */
+ * asp_sa_anneal_shuffled calls (a fresh visiting order every sweep): the items with the same
+ * number of sweeps SHARE their launches — per chunk of sweeps one order build over (problem, sweep)
+ * and one sweep launch per kernel class (chains per group, spin layout, lane packing) over
+ * (problem, workgroup), workgroups of one problem on one XCD —, so a batch of small clusters fills
+ * its wavefronts with chains (blocks of 4 .. 32 spins) and the chip with problems. */
 #define ASP_SA_BATCH_SHUFFLED 1u
 typedef struct asp_sa_batch_item {
   asp_sa_plan *plan;
