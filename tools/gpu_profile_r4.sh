@@ -26,4 +26,5 @@ done
 # (a few dispatches each, small) and tools/summarise_roofline.py runs where they have all arrived:
 #   python tools/summarise_roofline.py gpurun_out/prof4 r04
 find $OUT -name "*.db" -delete; find $OUT -name "*agent_info.csv" -delete
+python3 tools/reduce_counters.py $OUT
 ls $OUT/cases

@@ -26,17 +26,25 @@ os.makedirs(out_dir, exist_ok=True)
 
 def counters(directory, match):
     """Sum over all dispatches of kernels whose name contains `match`: {counter: total}, the
-    number of dispatches and their total duration in ns (per counter set)."""
-    files = glob.glob(os.path.join(directory, "**", "*_counter_collection.csv"), recursive=True)
+    number of dispatches and their total duration in ns (per counter set).  Reads the per-kernel
+    sums of tools/reduce_counters.py (*_counter_collection.json) or rocprofv3's own CSVs."""
     total = collections.defaultdict(float)
+    dispatches, ns = 0, 0.0
+    for f in glob.glob(os.path.join(directory, "**", "*_counter_collection.json"), recursive=True):
+        for name, k in json.load(open(f)).items():
+            if match in name:
+                for counter, value in k["counters"].items():
+                    total[counter] += value
+                dispatches += k["dispatches"]
+                ns += k["ns"]
     seen = {}
-    for f in files:
+    for f in glob.glob(os.path.join(directory, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if match in r["Kernel_Name"]:
                 total[r["Counter_Name"]] += float(r["Counter_Value"])
                 # (per file: two runs of one command number their dispatches alike)
                 seen[(f, r["Dispatch_Id"])] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    return dict(total), len(seen), float(sum(seen.values()))
+    return dict(total), dispatches + len(seen), ns + float(sum(seen.values()))
 
 
 # FETCH_SIZE calibration on this chip: fraction of the true bytes the counter reports
