@@ -83,7 +83,8 @@ struct OrderArgs {
   // the peel and the stream are kernels of their own over ALL sweeps of the chunk (k_order_prio,
   // k_order_counts, k_order_level, k_order_stream) and only what needs a sweep's tables in LDS
   // stays in a workgroup per sweep (k_shuffled_orders with finish_only = 1).
-  uint32_t finish_only;                     // 1: the levels have been peeled by k_order_level
+  uint32_t finish_only;                     // 1: the first wide_levels levels are peeled by k_order_level launches
+  uint32_t wide_levels;                     // number of those launches per chunk
   uint32_t *peel_ctl;                       // [count][8]: members of level l % 3 | first position of level l % 3 | -
   uint32_t *level_start_g;                  // [count][level_cap + 2] first position of every level
   uint8_t *later;                           // [count][quads of A] bit j: entry j of the quad is a LATER neighbour
@@ -285,19 +286,42 @@ __device__ __forceinline__ void shuffled_orders_impl(const Args &a, const uint32
 #define ASP_OTICK(slot) do {} while (0)
 #endif
 
-  uint32_t levels = 0;
+  // G lanes share a row: one quad of four neighbours per lane and trip
+  const uint32_t G = a.lanes_per_row;
+  const uint32_t sub = tid & (G - 1u), gid = tid / G, groups = nthreads / G;
+  uint32_t levels = 0, begin = 0, end = 0;
   if (a.finish_only) {
-    // the wide path: k_order_level has peeled the levels; their first positions are in HBM
-    // (entries beyond the last level are zero).  The number of levels: the l with start[l] = K.
+    // The wide path: k_order_level has peeled the first a.wide_levels levels as grids over the
+    // chunk (the bulk of the spins: a sweep's levels shrink from K / 25 spins to a handful); the
+    // first positions of those levels are in HBM.  Either one of them is K — the peel is complete
+    // — or this workgroup peels the short rest itself, from where the last launch stopped: the
+    // members of level wide_levels are in the pair's control words.
+    const uint32_t W = min(a.wide_levels, a.level_cap);
     const uint32_t *from = a.level_start_g + static_cast<uint64_t>(s) * (a.level_cap + 2u);
-    for (uint32_t l = tid; l < a.level_cap + 2u; l += nthreads) level_start[l] = from[l];
-    if (tid == 0) ctl[4] = a.level_cap + 1u;  // (no such l: more levels than level launches — the host repeats the call)
+    const uint32_t *pair = a.peel_ctl + static_cast<uint64_t>(s) * 8u;
+    for (uint32_t l = tid; l <= W; l += nthreads) level_start[l] = from[l];
+    if (tid == 0) ctl[4] = 0xFFFFFFFFu;
     __syncthreads();
-    for (uint32_t l = 1u + tid; l <= a.level_cap + 1u; l += nthreads) {
+    for (uint32_t l = 1u + tid; l <= W; l += nthreads) {
       if (level_start[l] == K) atomicMin(&ctl[4], l);
     }
     __syncthreads();
-    levels = ctl[4];
+    if (ctl[4] != 0xFFFFFFFFu) {
+      levels = ctl[4];  // (begin == end: nothing left to peel)
+    } else if (a.wide_levels > a.level_cap) {
+      // (a shared launch sequence longer than this problem's level table, and the peel is not
+      // complete inside the table: more levels than its capacity — the host repeats the call)
+      levels = a.level_cap + 1u;
+    } else {
+      levels = W;
+      begin = level_start[W];
+      end = begin + pair[W % 3u];
+      if (tid == 0) {
+        ctl[0] = end;
+        level_start[W + 1u] = end;
+      }
+      __syncthreads();
+    }
   } else {
     // ---- 1. priorities ----
     for (uint32_t i = tid; i < K; i += nthreads) {
@@ -308,9 +332,6 @@ __device__ __forceinline__ void shuffled_orders_impl(const Args &a, const uint32
     ASP_OTICK(0);
 
     // ---- 2. number of earlier neighbours; spins without any open level 0 ----
-    // G lanes share a row: one quad of four neighbours per lane and trip
-    const uint32_t G = a.lanes_per_row;
-    const uint32_t sub = tid & (G - 1u), gid = tid / G, groups = nthreads / G;
     for (uint32_t i = gid; i < K; i += groups) {
       const uint32_t pi = prio[i];
       const uint32_t q1 = a.rq_ptr[i + 1];
@@ -337,36 +358,36 @@ __device__ __forceinline__ void shuffled_orders_impl(const Args &a, const uint32
     }
     __syncthreads();
 
-    ASP_OTICK(1);
-    // ---- 3. peel the levels ----
-    uint32_t begin = 0, end = ctl[1];
-    while (begin < end) {
-      ++levels;
-      for (uint32_t m = begin + gid; m < end; m += groups) {
-        const uint32_t i = peel.order_at(m);
-        const uint32_t pi = prio[i];
-        const uint32_t q1 = a.rq_ptr[i + 1];
-        for (uint32_t q = a.rq_ptr[i] + sub; q < q1; q += G) {
-          const uint4 c = a.rq_col[q];
-          const uint32_t cs[4] = {c.x, c.y, c.z, c.w};
-  #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const uint32_t n = cs[j];
-            if (n != i && comes_before(pi, i, prio[n], n)) {
-              if (peel.visited_one(n)) peel.append(&ctl[0], n);
-            }
+    end = ctl[1];
+  }
+  ASP_OTICK(1);
+  // ---- 3. peel the levels ----
+  while (begin < end) {
+    ++levels;
+    for (uint32_t m = begin + gid; m < end; m += groups) {
+      const uint32_t i = peel.order_at(m);
+      const uint32_t pi = prio[i];
+      const uint32_t q1 = a.rq_ptr[i + 1];
+      for (uint32_t q = a.rq_ptr[i] + sub; q < q1; q += G) {
+        const uint4 c = a.rq_col[q];
+        const uint32_t cs[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t n = cs[j];
+          if (n != i && comes_before(pi, i, prio[n], n)) {
+            if (peel.visited_one(n)) peel.append(&ctl[0], n);
           }
         }
       }
-      __syncthreads();
-      if (tid == 0) {
-        ctl[1 + (levels & 1u)] = ctl[0];
-        if (levels + 1u <= a.level_cap + 1u) level_start[levels + 1u] = ctl[0];
-      }
-      __syncthreads();
-      begin = end;
-      end = ctl[1 + (levels & 1u)];
     }
+    __syncthreads();
+    if (tid == 0) {
+      ctl[1 + (levels & 1u)] = ctl[0];
+      if (levels + 1u <= a.level_cap + 1u) level_start[levels + 1u] = ctl[0];
+    }
+    __syncthreads();
+    begin = end;
+    end = ctl[1 + (levels & 1u)];
   }
   // (begin == K here: the priority order is a total order, so the peel reaches every spin)
   const uint32_t L = levels;
@@ -1555,12 +1576,21 @@ int ensure_static(asp_sa_plan *p) {
   return ASP_OK;
 }
 
-// Level launches from the second chunk on, given the most levels a sweep of the first chunk had.
-uint32_t trimmed_level_launches(uint32_t seen) {
-  if (const char *env = std::getenv("ASP_SHUFFLED_TRIM_TO")) {  // test hook: provoke the overrun
-    return std::max(1u, static_cast<uint32_t>(std::strtoul(env, nullptr, 10)));
+// Level launches of the wide path per chunk, given the levels a sweep is expected to have: the first
+// three quarters of them.  A sweep's levels shrink roughly linearly from ~2.5 x the mean to a handful
+// of spins, so those launches peel ~94 % of the spins with thousands of rows in flight each, and the
+// per-sweep workgroup (k_shuffled_orders, finish_only) peels the short rest itself, however many levels
+// that is: no launch count has to be guessed right.  (Scanned on the kagome_36 pipeline, 64 clusters:
+// 20 / 30 / 45 launches and 0.6 of the expected levels 29.8 / 29.0 / 24.6 / 25.3 s; one launch per
+// level of the capacity trimmed after the first chunk, with a retry when a sweep overran it, 24.1 s:
+// a level launch costs ~0.2 ms beside the sweep kernels, the tail of a sweep in ONE workgroup about
+// as much per level.)
+uint32_t wide_level_launches(double expected_levels, uint32_t level_cap) {
+  uint32_t launches = static_cast<uint32_t>(std::ceil(0.75 * expected_levels));
+  if (const char *env = std::getenv("ASP_SHUFFLED_WIDE_LEVELS")) {  // tests, measurements
+    launches = static_cast<uint32_t>(std::strtoul(env, nullptr, 10));
   }
-  return seen + seen / 4 + 8;
+  return std::max(1u, std::min(launches, level_cap));
 }
 
 // The wide launches of one chunk in front of the per-sweep workgroups (k_shuffled_orders with
@@ -1707,6 +1737,7 @@ struct ShuffledRun {
     // the clusters of this problem (measured: 29 at degree 8, 59-69 at degree 23); the last
     // call's count when there is one
     const double levels_guess = p->last_shuffled_levels > 0 ? p->last_shuffled_levels : 2.5 * mean_degree + 4.0;
+    expected_levels = levels_guess;
     waves = static_cast<uint32_t>(p->shuffled_waves);
     // one wavefront more than the blocks of an average level: the first levels of a sweep are its
     // widest (K = 12 870 alone on the chip: +6 %) — but not in a batch that oversubscribes the chip,
@@ -1792,11 +1823,8 @@ struct ShuffledRun {
         1u, static_cast<uint32_t>(std::ceil(mean_degree / 4.0))))));
     if (const char *env = std::getenv("ASP_SHUFFLED_BYTES")) budget = std::strtoull(env, nullptr, 10);
 
-    for (auto &o : order_stream) ASP_TRY(o.acquire());
-    for (int i = 0; i < kSets; ++i) {
-      ASP_HIP_TRY(hipEventCreateWithFlags(&ordered[i], hipEventDisableTiming));
-      ASP_HIP_TRY(hipEventCreateWithFlags(&swept[i], hipEventDisableTiming));
-    }
+    // (the run's own order streams and events: made by enqueue(), which the batched driver — with
+    // its shared streams — never calls; 128 problems x (2 streams, 6 events) were 0.1 s of a batch)
     hipStream_t s = p->stream;
     ASP_TRY(d_betas.alloc(num_sweeps));
     // (a byte per spin and group between chunks — or, beyond every LDS layout, the chains' spin words)
@@ -1824,7 +1852,8 @@ struct ShuffledRun {
   size_t lds = 0, order_lds = 0;
   bool order_in_lds = false;
   bool wide_orders = false;  // the order build as grids over the chunk (k_order_*): large clusters
-  bool trimmed_levels = false, levels_overran = false;  // fewer level launches than level_cap / that was too few
+  uint32_t wide_levels = 0;  // level launches per chunk of the wide path (wide_level_launches)
+  double expected_levels = 0.0;  // levels a sweep is expected to have (setup())
   DeviceBuffer<uint32_t> d_peel_ctl[kLanes], d_level_start[kLanes];
   DeviceBuffer<uint8_t> d_later[kLanes];
   DeviceBuffer<OrderArgs> d_oargs;  // descriptors of every chunk (the single call's wide launches)
@@ -1896,6 +1925,7 @@ struct ShuffledRun {
                    order_lds_bytes(level_cap, block_cap, order_threads / 64, K) <= p->max_lds * 9 / 16;
     order_lds = order_lds_bytes(level_cap, block_cap, order_threads / 64, order_in_lds ? K : 0);
     wide_orders = !order_in_lds && !std::getenv("ASP_SHUFFLED_ORDER_FUSED");
+    wide_levels = wide_orders ? wide_level_launches(expected_levels, level_cap) : 0u;
     if (order_lds > p->max_lds) {
       return asp::set_error(ASP_ERR_TOO_LARGE, "%u levels x %u blocks do not fit the order kernel's LDS",
                             level_cap, block_cap);
@@ -1951,6 +1981,7 @@ struct ShuffledRun {
     oa.max_quads = p->rq_max_quads;
     oa.lds_arrays = order_in_lds ? 1u : 0u;
     oa.finish_only = wide_orders ? 1u : 0u;
+    oa.wide_levels = wide_levels;
     oa.col_shift = (layout == kWide || layout == kGlobal) ? 2u : 0u;  // (byte offsets of 32-bit spin words)
     oa.status = d_status.ptr;
     // (the layout may change between attempts — capacities grow —: the HBM form needs a word per spin)
@@ -2014,6 +2045,13 @@ struct ShuffledRun {
   int enqueue() {
     if (trivial) return ASP_OK;
     hipStream_t s = p->stream;
+    for (auto &o : order_stream) {
+      if (!o.stream) ASP_TRY(o.acquire());
+    }
+    for (int i = 0; i < kSets; ++i) {
+      if (!ordered[i]) ASP_HIP_TRY(hipEventCreateWithFlags(&ordered[i], hipEventDisableTiming));
+      if (!swept[i]) ASP_HIP_TRY(hipEventCreateWithFlags(&swept[i], hipEventDisableTiming));
+    }
     ASP_TRY(plan_sizes());
     kernel = shuffled_kernel_for(m, layout, teams, packed_lanes);
     if (!kernel) {  // (no two-team form of this width and layout)
@@ -2030,7 +2068,6 @@ struct ShuffledRun {
     }
     ASP_TRY(plan_buffers(chunk));
     WidePartsMax wide;
-    trimmed_levels = false;
     if (wide_orders) {
       // descriptors of every chunk on the device (the wide kernels read them from a table)
       h_oargs.clear();
@@ -2050,7 +2087,7 @@ struct ShuffledRun {
       wide.counts = parts.counts;
       wide.level = parts.level;
       wide.stream = parts.stream;
-      wide.levels = level_cap;
+      wide.levels = wide_levels;
     }
     for (int i = 0; i < nlanes; ++i) {
       ASP_HIP_TRY(hipStreamWaitEvent(order_stream[i].stream, p->ev[0], 0));  // status zeroed, buffers ours
@@ -2073,17 +2110,7 @@ struct ShuffledRun {
         ASP_HIP_TRY(hipGetLastError());
         if (wide_orders) ASP_TRY(launch_wide_stream(os, d_oargs.ptr + turn, 1, now, wide));
         ASP_HIP_TRY(hipEventRecord(ordered[which], os));
-        if (wide_orders && turn == 0 && !levels_overran) {
-          // One launch per level: the capacity (level_cap) is about twice what a sweep has, and
-          // an empty launch still dispatches its whole grid.  After the FIRST chunk the host looks
-          // at the levels its sweeps had and launches a quarter more than that from then on; a
-          // later sweep with more levels flags the call, which is repeated with all of them.
-          uint32_t seen = 0;
-          ASP_HIP_TRY(hipStreamSynchronize(os));
-          ASP_HIP_TRY(hipMemcpy(&seen, d_status.ptr + kStatLevels, sizeof seen, hipMemcpyDeviceToHost));
-          if (seen > 0 && seen <= level_cap) wide.levels = std::min(level_cap, trimmed_level_launches(seen));
-          trimmed_levels = wide.levels < level_cap;
-        }
+
         ASP_HIP_TRY(hipStreamWaitEvent(s, ordered[which], 0));
       }
       hipLaunchKernelGGL(kernel, dim3(wgs), dim3(waves * teams * 64), lds, s, s_args);
@@ -2111,16 +2138,9 @@ struct ShuffledRun {
   int grow(bool *again) {
     *again = false;
     if (status[kStatBad] == 0) return ASP_OK;
-    if (++attempt > 5) {
+    if (++attempt > 4) {
       return asp::set_error(ASP_ERR_TOO_LARGE, "visiting orders of %u levels / %u quads per sweep do not fit",
                             status[kStatLevels], status[kStatQuads]);
-    }
-    if (trimmed_levels && status[kStatLevels] > level_cap) {
-      // (a sweep had more levels than the trimmed number of level launches: once more with all)
-      trimmed_levels = false;
-      levels_overran = true;
-      *again = true;
-      return ASP_OK;
     }
     if (status[kStatLevels] > level_cap) {
       level_cap = static_cast<uint32_t>(std::min<uint64_t>(K, 2ull * status[kStatLevels] + 16));
@@ -2378,6 +2398,24 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(k.second)));
       }
     }
+    // the wide order launches (large clusters): shapes for the largest of them; problems of the
+    // fused path leave these kernels at once
+    WidePartsMax wide;
+    std::vector<uint32_t> wide_members;
+    for (uint32_t i = 0; i < P; ++i) {
+      ShuffledRun *r = runs[i];
+      if (!r->wide_orders) continue;
+      wide_members.push_back(i);
+      const ShuffledRun::WideParts parts = ShuffledRun::wide_parts(r->K, r->lanes_per_row, r->log_s);
+      wide.prio = std::max(wide.prio, parts.prio);
+      wide.counts = std::max(wide.counts, parts.counts);
+      wide.level = std::max(wide.level, parts.level);
+      wide.stream = std::max(wide.stream, parts.stream);
+      wide.levels = std::max(wide.levels, r->wide_levels);
+    }
+    // (one number of level launches for the shared grids: every wide problem's finish workgroup
+    // must take over exactly where the launches stop)
+    for (uint32_t i : wide_members) runs[i]->oa.wide_levels = wide.levels;
     // ---- descriptors of every (chunk, problem) ----
     const uint32_t chunks = num_sweeps ? (num_sweeps + chunk - 1) / chunk : 1;
     std::vector<OrderArgs> oargs(static_cast<size_t>(chunks) * P);
@@ -2395,24 +2433,6 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
     // sweep kernels alone); 2 = no sweep launches after the first chunk (the order kernels alone)
     int ablate = 0;
     if (const char *env = std::getenv("ASP_SHUFFLED_ABLATE")) ablate = std::atoi(env);
-    // the wide order launches (large clusters): shapes for the largest of them; problems of the
-    // fused path leave these kernels at once
-    WidePartsMax wide;
-    std::vector<uint32_t> wide_members;
-    bool may_trim = true;
-    for (ShuffledRun *r : runs) r->trimmed_levels = false;
-    for (uint32_t i = 0; i < P; ++i) {
-      ShuffledRun *r = runs[i];
-      if (!r->wide_orders) continue;
-      wide_members.push_back(i);
-      may_trim = may_trim && !r->levels_overran;
-      const ShuffledRun::WideParts parts = ShuffledRun::wide_parts(r->K, r->lanes_per_row, r->log_s);
-      wide.prio = std::max(wide.prio, parts.prio);
-      wide.counts = std::max(wide.counts, parts.counts);
-      wide.level = std::max(wide.level, parts.level);
-      wide.stream = std::max(wide.stream, parts.stream);
-      wide.levels = std::max(wide.levels, r->level_cap);
-    }
     // (the wide kernels read a table of the wide problems only: their grids are workgroups per
     // (problem, sweep), and two thirds of a pipeline round are small models of the fused path)
     const uint32_t Pw = static_cast<uint32_t>(wide_members.size());
@@ -2452,25 +2472,7 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
         ASP_HIP_TRY(hipGetLastError());
         if (Pw) ASP_TRY(launch_wide_stream(os, chunk_wide, Pw, now, wide));
         ASP_HIP_TRY(hipEventRecord(ordered[which], os));
-        if (Pw && turn == 0 && may_trim) {
-          // (as in ShuffledRun::enqueue: the levels the first chunk's sweeps had, a quarter more from now on)
-          ASP_HIP_TRY(hipStreamSynchronize(os));
-          uint32_t seen = 0;
-          bool valid = true;
-          for (uint32_t i : wide_members) {
-            uint32_t mine = 0;
-            ASP_HIP_TRY(hipMemcpy(&mine, runs[i]->d_status.ptr + kStatLevels, sizeof mine, hipMemcpyDeviceToHost));
-            valid = valid && mine > 0 && mine <= runs[i]->level_cap;
-            seen = std::max(seen, mine);
-          }
-          if (valid) {
-            const uint32_t trimmed = std::min(wide.levels, trimmed_level_launches(seen));
-            if (trimmed < wide.levels) {
-              wide.levels = trimmed;
-              for (uint32_t i : wide_members) runs[i]->trimmed_levels = true;
-            }
-          }
-        }
+
       }
       for (auto &c : classes) {
         if (ablate == 2 && turn > 0) continue;

@@ -1299,26 +1299,22 @@ def test_shuffled_order_build_paths(monkeypatch, n, degree, reps, sweeps, env):
     assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
 
 
-def test_shuffled_wide_orders_trim_their_level_launches_and_recover(monkeypatch):
-    """The wide path launches one kernel per level; after the first chunk it launches only a quarter
-    more than the levels seen so far.  When a later sweep has more levels than that, the call is
-    flagged and repeated with all launches: same chains either way (here the trim is forced below the
-    number of levels)."""
+@pytest.mark.parametrize("wide_levels", [1, 7, 500])
+def test_shuffled_wide_orders_hand_over_to_the_sweep_workgroup(monkeypatch, wide_levels):
+    """The wide path peels the first levels of every sweep of a chunk as grids (one launch per level)
+    and the per-sweep workgroup peels the rest from where the launches stop: any split gives the
+    oracle's chains — one launch (nearly everything in the workgroup), a few, or more launches than
+    the sweeps have levels (the peel completes inside the launches); alone and inside a batch."""
     from annealing_sign_problem_amd import annealer as sa
 
     monkeypatch.setenv("ASP_SHUFFLED_ORDER_IN_HBM", "1")
     monkeypatch.setenv("ASP_SHUFFLED_BYTES", "2000000")  # several chunks
+    monkeypatch.setenv("ASP_SHUFFLED_WIDE_LEVELS", str(wide_levels))
     J, h, ham, info, betas = _shuffled_case(2500, 10.0, 60, seed=17)
-    expected = sa.anneal_raw(ham, 5, betas, 4, 0, None, shuffled=True)
-    monkeypatch.setenv("ASP_SHUFFLED_TRIM_TO", "5")
     xs, es = sa.anneal_raw(ham, 5, betas, 4, 0, None, shuffled=True)
-    assert np.array_equal(xs, expected[0]) and es.tobytes() == expected[1].tobytes()
     oxs, oes, _, _ = oracle.sa_anneal_shuffled(J, h, 5, betas, 4, 0, None, info.energy_scale_exp, num_threads=4)
     assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
-    # ... and inside a batch (shared launches, a table of the wide problems only)
     other = _shuffled_case(400, 8.0, 60, seed=18)
-    monkeypatch.delenv("ASP_SHUFFLED_ORDER_IN_HBM")  # (the small one stays on the fused path, the large one is forced wide)
-    monkeypatch.setenv("ASP_SHUFFLED_ORDER_IN_HBM", "1")
     results = sa.anneal_batch_raw([ham, other[2]], [5, 6], [betas, other[4]], [4, 4], shuffled=True)
     assert np.array_equal(results[0][0], oxs) and results[0][1].tobytes() == oes.tobytes()
     o2, e2, _, _ = oracle.sa_anneal_shuffled(other[0], other[1], 6, other[4], 4, 0, None, other[3].energy_scale_exp,
