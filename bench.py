@@ -594,6 +594,7 @@ def bench_pipeline(op, psi, log_psi, greedy_clusters=128, annealed_clusters=32, 
         "annealed_models": len(staged),
         "annealed_spins": int(spins),
         "annealed_build_s": staged_s,
+        "annealed_sweep_order": "shuffled (the drop-in default: sampled_components --annealing)",
         "annealed_anneal_s": anneal_s,
         "annealed_flips_per_s": spins * 64 * 5120 / anneal_s,
         "median_order2_sa_accuracy": float(np.median([r[2].sa_accuracy for r in annealed])),

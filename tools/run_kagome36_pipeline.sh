@@ -7,10 +7,8 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
 D=/tmp/k36; mkdir -p $D
 H5=$D/heisenberg_kagome_36.h5
 if [ ! -f $H5 ]; then
-  T0=$(date +%s.%N)
   python3 -m annealing_sign_problem_amd.sector_ed --model heisenberg_kagome_36 --output $H5 --tol 1e-8 > $D/ed.log 2>&1 || { tail -5 $D/ed.log; exit 1; }
   tail -1 $D/ed.log
-  echo "ground state: $(echo "$(date +%s.%N) - $T0" | bc) s wall"
 fi
 for run in "$@"; do
   set -- $run; samples=$1; shift
