@@ -145,6 +145,7 @@ SIGNATURES = {
     "asp_sa_set_shuffled_launch": (c_int, [c_void_p, c_int, c_int]),
     "asp_sa_set_shuffled_teams": (c_int, [c_void_p, c_int]),
     "asp_sa_last_shuffled": (c_int, [c_void_p, ctypes.POINTER(c_u32), ctypes.POINTER(c_float)]),
+    "asp_sa_team_watchdog_trips": (c_int, [c_void_p, ctypes.POINTER(c_u32), ctypes.POINTER(c_u64)]),
     "asp_sa_last_shuffled_blocks": (c_int, [c_void_p, ctypes.POINTER(c_u32), ctypes.POINTER(c_u32)]),
     "asp_sa_last_shuffled_fill": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "asp_sa_anneal_batch": (c_int, [ctypes.POINTER(SaBatchItem), c_u32]),

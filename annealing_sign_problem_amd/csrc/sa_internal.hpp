@@ -46,6 +46,7 @@ struct asp_sa_plan {
   int team_mode = -1;  // asp_sa_set_team: -1 auto, 0 off, G >= 2 forced
   bool use_field_cache = true;
   uint32_t team_abort_host = 0;  // landing place of the watchdog flag's asynchronous read-back
+  uint32_t team_watchdog_trips = 0;  // calls of this plan that the team barrier's watchdog cut short (each ~5 s lost)
   // Shuffled sweep (csrc/sa_shuffled.hip; uploaded on first use): rows of A over ORIGINAL
   // indices, padded to whole quads (padding: own index, +0.0) — row i is quads
   // rq_ptr[i] .. rq_ptr[i + 1]; per quad four columns and four values in the interleaving the

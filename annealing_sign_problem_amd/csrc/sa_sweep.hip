@@ -35,6 +35,7 @@
 //     greedy solver's relaxation).
 // f64-VALU- and vector-memory-bound integer+f64 work: no MFMA.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <initializer_list>
@@ -635,6 +636,9 @@ __global__ __launch_bounds__(ASP_MAX_THREADS) void k_sa_sweep_batch(BatchArgs b)
 // (the launcher keeps the grid within the CU count and serialises team launches); the barrier
 // carries a watchdog so that neither a bug nor a busy device can hang the GPU — on a timeout
 // the call is repeated without teams.  Chains are bit-identical to k_sa_sweep's.
+
+// team launches of the process that the barrier's watchdog cut short (asp_sa_team_watchdog_trips)
+std::atomic<uint64_t> g_team_watchdog_trips{0};
 
 struct TeamArgs {
   SweepArgs s;
@@ -1400,6 +1404,12 @@ int asp_sa_set_field_cache(asp_sa_plan *p, int enable) {
   return ASP_OK;
 }
 
+int asp_sa_team_watchdog_trips(asp_sa_plan const *p, uint32_t *of_plan, uint64_t *of_process) {
+  if (of_plan) *of_plan = p ? p->team_watchdog_trips : 0u;
+  if (of_process) *of_process = g_team_watchdog_trips.load(std::memory_order_relaxed);
+  return ASP_OK;
+}
+
 int asp_sa_set_team(asp_sa_plan *p, int team) {
   if (!p) return asp::set_error(ASP_ERR_INVALID, "null plan");
   if (team != -1 && team != 0 && team != 2 && team != 4 && team != 8) {
@@ -1704,6 +1714,8 @@ int run_chains(asp_sa_plan *p, uint64_t seed, double const *betas, uint32_t num_
     // of a refused launch.  Teams stay off for this plan.
     if (team_turn.owns_lock()) team_turn.unlock();
     p->team_mode = 0;
+    p->team_watchdog_trips += 1;
+    g_team_watchdog_trips.fetch_add(1, std::memory_order_relaxed);
     return run_chains(p, seed, betas, num_sweeps, repetitions, replica_offset, x0, descent, out_x,
                       out_e, out_trace);
   }

@@ -388,6 +388,11 @@ int asp_sa_last_layout(asp_sa_plan const *p);
  * team size when the chains fit (tests, measurements).  Chains are bit-identical either way;
  * asp_sa_last_layout reports 4 for a team launch. */
 int asp_sa_set_team(asp_sa_plan *p, int team);
+/* How often the team barrier's watchdog gave up (the members of a team were not resident together:
+ * another process or a long kernel held compute units): each trip costs the ~5 s the watchdog waits
+ * plus the repeat of the call without teams, and used to be silent.  of_plan: calls of this plan
+ * (NULL plan: 0); of_process: all plans of the process.  Either pointer may be NULL. */
+int asp_sa_team_watchdog_trips(asp_sa_plan const *p, uint32_t *of_plan, uint64_t *of_process);
 
 /* Field cache (default on): once a sweep flips few spins, a workgroup keeps the local fields
  * of every block in HBM and re-evaluates a block only after one of its neighbours flipped.

@@ -872,10 +872,17 @@ def test_team_watchdog_timeout_reruns_without_teams(monkeypatch):
     S = ham.info().energy_scale_exp
     oxs, oes, _, _ = oracle.sa_anneal(J, h, 99, betas, 4, 0, None, S, num_threads=4)
     _set_team(ham, 8)
+    trips, all_trips = ctypes.c_uint32(9), ctypes.c_uint64(0)
+    _lib.check(lib.asp_sa_team_watchdog_trips(ham.plan(), ctypes.byref(trips), ctypes.byref(all_trips)))
+    before = all_trips.value
+    assert trips.value == 0
     monkeypatch.setenv("ASP_TEAM_SPIN_LIMIT", "0")
     xs, es = sa.anneal_raw(ham, 99, betas, 4)
     assert lib.asp_sa_last_layout(ham.plan()) != 4          # answered by the fallback
     assert np.array_equal(xs, oxs) and es.tobytes() == oes.tobytes()
+    # the trip is no longer silent
+    _lib.check(lib.asp_sa_team_watchdog_trips(ham.plan(), ctypes.byref(trips), ctypes.byref(all_trips)))
+    assert trips.value == 1 and all_trips.value == before + 1
     monkeypatch.delenv("ASP_TEAM_SPIN_LIMIT")
     xs, es = sa.anneal_raw(ham, 99, betas, 4)                # teams stay off for this plan
     assert lib.asp_sa_last_layout(ham.plan()) != 4
