@@ -948,6 +948,9 @@ __device__ __forceinline__ void apply_quad(const HeldQuad &q, const uint32_t (&s
 #ifndef ASP_SHUF_TIMING
 #define ASP_SHUF_TIMING 0
 #endif
+#ifndef ASP_SHUF_ABLATE_ENV
+#define ASP_SHUF_ABLATE_ENV 0  // 1: honour $ASP_SHUFFLED_ABLATE (timing-only launches that skip work: WRONG results)
+#endif
 #if ASP_SHUF_TIMING
 #define ASP_TICK(slot)                                  \
   do {                                                  \
@@ -2431,8 +2434,11 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
     // Timing-only ablations (results are WRONG; tools/time_shuffled_batch_only.py): 1 = orders of
     // the first buffer sets only, every later chunk sweeps through stale ones (the cost of the
     // sweep kernels alone); 2 = no sweep launches after the first chunk (the order kernels alone)
+    // (only in a build with -DASP_SHUF_ABLATE_ENV=1: the product ignores the variable)
     int ablate = 0;
+#if ASP_SHUF_ABLATE_ENV
     if (const char *env = std::getenv("ASP_SHUFFLED_ABLATE")) ablate = std::atoi(env);
+#endif
     // (the wide kernels read a table of the wide problems only: their grids are workgroups per
     // (problem, sweep), and two thirds of a pipeline round are small models of the fused path)
     const uint32_t Pw = static_cast<uint32_t>(wide_members.size());

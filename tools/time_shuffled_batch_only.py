@@ -2,6 +2,10 @@
 [1e2, 1e4], 64 chains x SWEEPS sweeps, one asp_sa_anneal_batch call.  (Development aid; GPU.)
 
     python tools/time_shuffled_batch_only.py [N=128] [sweeps=5120] [repeat=1]
+
+ASP_SHUFFLED_ABLATE=1 (sweeps through stale orders: the sweep kernels alone) / =2 (no sweep launches after
+the first chunk: the order kernels alone) are honoured by a library built with -DASP_SHUF_ABLATE_ENV=1 only
+(ASP_LIB_TAG=abl ASP_EXTRA_FLAGS=-DASP_SHUF_ABLATE_ENV=1): the results are WRONG, the times are the point.
 """
 import ctypes
 import os
