@@ -79,6 +79,8 @@ struct OrderArgs {
   uint32_t threads;                         // threads of this problem's order workgroups (a multiple of 64)
   uint32_t num_quads, max_quads;            // quads of all rows of A / of its longest row
   uint32_t lds_arrays;                      // 1: priorities, counters and the order in LDS (PeelArrays)
+  uint32_t lds_counters;                    // 1 / 2: (with finish_only) the whole peel in the per-sweep workgroup, its
+                                            //    counters as bytes / nibbles in LDS, order and later-masks in HBM
   // The WIDE path (large clusters: the per-spin arrays in HBM): priorities, counts, every level of
   // the peel and the stream are kernels of their own over ALL sweeps of the chunk (k_order_prio,
   // k_order_counts, k_order_level, k_order_stream) and only what needs a sweep's tables in LDS
@@ -197,18 +199,25 @@ __device__ __forceinline__ void write_stream_pass(const Args &a, uint8_t *stream
 // atomic per later neighbour —, about 4 us per level and 0.97 s of device time for the 128-problem
 // production batch (orders alone; the sweeps alone took 1.7 s): LDS atomics and gathers cut a
 // level to a fraction of a microsecond.
-template <bool LDSA>
+// Where the peel's per-spin arrays live.  kPeelLdsCounters / kPeelLdsNibbles (large clusters): only the
+// counters in LDS — a byte per spin, or FOUR BITS with an escape: a spin with 15 or more earlier
+// neighbours keeps the nibble 15 for good and counts down in its exact HBM counter instead (whether
+// a spin is such a one never changes, so a plain read of the nibble decides).
+enum : int { kPeelHbm = 0, kPeelLds = 1, kPeelLdsCounters = 2, kPeelLdsNibbles = 3 };
+template <int MODE>
 struct PeelArrays {
+  static constexpr bool kOrderInLds = MODE == kPeelLds, kCountersInLds = MODE != kPeelHbm;
   uint32_t *prio;
-  uint32_t *indeg;  // LDSA: bytes packed in words
-  void *order;      // LDSA: uint16_t
+  uint32_t *indeg;  // kCountersInLds: bytes (kPeelLdsNibbles: nibbles) packed in words
+  uint32_t *exact;  // kPeelLdsNibbles: the counters as words in HBM
+  void *order;      // kOrderInLds: uint16_t
   __device__ __forceinline__ uint32_t order_at(uint32_t m) const {
-    if constexpr (LDSA) return static_cast<const uint16_t *>(order)[m];
+    if constexpr (kOrderInLds) return static_cast<const uint16_t *>(order)[m];
     return static_cast<const uint32_t *>(order)[m];
   }
   __device__ __forceinline__ void append(uint32_t *tail, uint32_t i) const {
     const uint32_t at = atomicAdd(tail, 1u);
-    if constexpr (LDSA) {
+    if constexpr (kOrderInLds) {
       static_cast<uint16_t *>(order)[at] = static_cast<uint16_t>(i);
     } else {
       static_cast<uint32_t *>(order)[at] = i;
@@ -216,16 +225,21 @@ struct PeelArrays {
   }
   // (called once per spin, on zeroed words in the LDS form)
   __device__ __forceinline__ void set_count(uint32_t i, uint32_t count) const {
-    if constexpr (LDSA) {
+    if constexpr (MODE == kPeelLds) {
       if (count) atomicAdd(indeg + (i >> 2), count << (8u * (i & 3u)));
-    } else {
+    } else if constexpr (MODE == kPeelHbm) {
       // (relaxed device-scope store: the decrements are device-scope atomics)
       __hip_atomic_store(indeg + i, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // (kPeelLdsCounters / kPeelLdsNibbles: loaded from k_order_counts' words, see the prologue)
   }
   // one earlier neighbour of spin n has been visited: true when it was the last one
   __device__ __forceinline__ bool visited_one(uint32_t n) const {
-    if constexpr (LDSA) {
+    if constexpr (MODE == kPeelLdsNibbles) {
+      const uint32_t shift = 4u * (n & 7u);
+      if (((indeg[n >> 3] >> shift) & 15u) == 15u) return atomicSub(exact + n, 1u) == 1u;
+      return ((atomicSub(indeg + (n >> 3), 1u << shift) >> shift) & 15u) == 1u;
+    } else if constexpr (kCountersInLds) {
       const uint32_t shift = 8u * (n & 3u);
       return ((atomicSub(indeg + (n >> 2), 1u << shift) >> shift) & 0xFFu) == 1u;
     } else {
@@ -236,7 +250,12 @@ struct PeelArrays {
 
 // (`Args` is OrderArgs, or OrderArgs in the constant address space: the batched kernel reads its
 // problem's descriptor from a table, like k_sa_sweep_batch does; `s` = sweep of the chunk)
-template <bool LDSA, typename Args>
+#ifndef ASP_SHUF_PEEL_ROWS
+#define ASP_SHUF_PEEL_ROWS 4
+#endif
+constexpr int kPeelRows = ASP_SHUF_PEEL_ROWS;  // rows in flight per group of lanes (kPeelLdsCounters)
+
+template <int MODE, typename Args>
 __device__ __forceinline__ void shuffled_orders_impl(const Args &a, const uint32_t s) {
   extern __shared__ __align__(16) uint8_t lds[];
   const uint32_t K = a.num_spins;
@@ -260,12 +279,18 @@ __device__ __forceinline__ void shuffled_orders_impl(const Args &a, const uint32
   uint32_t *block_first = block_quads + a.block_cap + 1;  // block_cap + 1
   uint32_t *hist = block_first + a.block_cap + 1;         // waves * 64
   uint32_t *cursor = hist + waves * 64u;                  // waves * 64
-  PeelArrays<LDSA> peel;
-  if constexpr (LDSA) {
+  PeelArrays<MODE> peel;
+  if constexpr (MODE == kPeelLds) {
     peel.prio = cursor + waves * 64u;            // K
     peel.indeg = peel.prio + K;                  // ceil(K / 4) words of four counters
     peel.order = peel.indeg + ((K + 3u) >> 2);   // K uint16_t
     for (uint32_t w = tid; w < ((K + 3u) >> 2); w += nthreads) peel.indeg[w] = 0u;
+  } else if constexpr (MODE == kPeelLdsCounters || MODE == kPeelLdsNibbles) {
+    // the counters take the place of the block tables, which nothing reads before the peel is over
+    peel.prio = nullptr;
+    peel.indeg = block_quads;                    // ceil(K / 4) words of four counters (K / 8: of eight)
+    peel.exact = a.indeg + static_cast<uint64_t>(s) * K;
+    peel.order = a.order + static_cast<uint64_t>(s) * K;
   } else {
     peel.prio = a.prio + static_cast<uint64_t>(s) * K;
     peel.indeg = a.indeg + static_cast<uint64_t>(s) * K;
@@ -296,7 +321,23 @@ __device__ __forceinline__ void shuffled_orders_impl(const Args &a, const uint32
     // first positions of those levels are in HBM.  Either one of them is K — the peel is complete
     // — or this workgroup peels the short rest itself, from where the last launch stopped: the
     // members of level wide_levels are in the pair's control words.
-    const uint32_t W = min(a.wide_levels, a.level_cap);
+    // (lds_counters: NO level launches — the whole peel is this workgroup's, from level 0 as
+    // k_order_counts left it)
+    constexpr bool kOwnPeel = MODE == kPeelLdsCounters || MODE == kPeelLdsNibbles;
+    const uint32_t W = kOwnPeel ? 0u : min(a.wide_levels, a.level_cap);
+    if constexpr (kOwnPeel) {
+      constexpr uint32_t kBits = MODE == kPeelLdsNibbles ? 4u : 8u, kPer = 32u / kBits, kMax = (1u << kBits) - 1u;
+      const uint32_t *counts = a.indeg + static_cast<uint64_t>(s) * K;
+      for (uint32_t w = tid; w < (K + kPer - 1u) / kPer; w += nthreads) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; ++j) {
+          const uint32_t i = kPer * w + j;
+          if (i < K) packed |= min(counts[i], kMax) << (kBits * j);
+        }
+        peel.indeg[w] = packed;
+      }
+    }
     const uint32_t *from = a.level_start_g + static_cast<uint64_t>(s) * (a.level_cap + 2u);
     const uint32_t *pair = a.peel_ctl + static_cast<uint64_t>(s) * 8u;
     for (uint32_t l = tid; l <= W; l += nthreads) level_start[l] = from[l];
@@ -308,7 +349,7 @@ __device__ __forceinline__ void shuffled_orders_impl(const Args &a, const uint32
     __syncthreads();
     if (ctl[4] != 0xFFFFFFFFu) {
       levels = ctl[4];  // (begin == end: nothing left to peel)
-    } else if (a.wide_levels > a.level_cap) {
+    } else if (!kOwnPeel && a.wide_levels > a.level_cap) {
       // (a shared launch sequence longer than this problem's level table, and the peel is not
       // complete inside the table: more levels than its capacity — the host repeats the call)
       levels = a.level_cap + 1u;
@@ -364,6 +405,53 @@ __device__ __forceinline__ void shuffled_orders_impl(const Args &a, const uint32
   // ---- 3. peel the levels ----
   while (begin < end) {
     ++levels;
+    if constexpr (MODE == kPeelLdsCounters || MODE == kPeelLdsNibbles) {
+      // A level is a chain of dependent HBM reads per row — its spin, its row pointers, its quads
+      // and their later-masks — in front of LDS atomics: kPeelRows rows per group of lanes are in
+      // flight at once (one workgroup has only its own loads to hide that latency with).
+      constexpr int U = kPeelRows;
+      const uint8_t *later = a.later + static_cast<uint64_t>(s) * a.num_quads;
+      const uint32_t *order = static_cast<const uint32_t *>(peel.order);
+      auto visit = [&](const uint4 c, const uint32_t mask) {
+        const uint32_t cs[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if ((mask >> j) & 1u) {
+            if (peel.visited_one(cs[j])) peel.append(&ctl[0], cs[j]);
+          }
+        }
+      };
+      for (uint32_t m0 = begin + gid; m0 < end; m0 += groups * U) {
+        uint32_t q0[U], q1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t m = m0 + static_cast<uint32_t>(u) * groups;
+          q0[u] = m < end ? order[m] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t i = q0[u];
+          q0[u] = i != 0xFFFFFFFFu ? a.rq_ptr[i] : 0u;
+          q1[u] = i != 0xFFFFFFFFu ? a.rq_ptr[i + 1] : 0u;
+        }
+        uint4 c[U];
+        uint32_t mask[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t q = q0[u] + sub;
+          const bool have = q < q1[u];
+          c[u] = have ? a.rq_col[q] : make_uint4(0u, 0u, 0u, 0u);
+          mask[u] = have ? later[q] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) visit(c[u], mask[u]);
+        // (rows of more than G quads)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          for (uint32_t q = q0[u] + sub + G; q < q1[u]; q += G) visit(a.rq_col[q], later[q]);
+        }
+      }
+    } else
     for (uint32_t m = begin + gid; m < end; m += groups) {
       const uint32_t i = peel.order_at(m);
       const uint32_t pi = prio[i];
@@ -520,9 +608,13 @@ __device__ __forceinline__ void shuffled_orders_impl(const Args &a, const uint32
 template <typename Args>
 __device__ __forceinline__ void shuffled_orders_body(const Args &a, const uint32_t s) {
   if (a.lds_arrays) {
-    shuffled_orders_impl<true>(a, s);
+    shuffled_orders_impl<kPeelLds>(a, s);
+  } else if (a.lds_counters == 1u) {
+    shuffled_orders_impl<kPeelLdsCounters>(a, s);
+  } else if (a.lds_counters == 2u) {
+    shuffled_orders_impl<kPeelLdsNibbles>(a, s);
   } else {
-    shuffled_orders_impl<false>(a, s);
+    shuffled_orders_impl<kPeelHbm>(a, s);
   }
 }
 
@@ -618,7 +710,7 @@ __device__ __forceinline__ void wave_append(bool push, uint32_t value, uint32_t 
 template <typename Args>
 __device__ __forceinline__ void order_level_body(const Args &a, uint32_t s, uint32_t part, uint32_t parts,
                                                  uint32_t l) {
-  if (!a.finish_only) return;
+  if (!a.finish_only || a.lds_counters) return;  // (fused path / the peel is the per-sweep workgroup's)
   uint32_t *ctl = a.peel_ctl + static_cast<uint64_t>(s) * 8u;
   const uint32_t lo = ctl[3u + l % 3u], n = ctl[l % 3u];  // (written by earlier launches: stable here)
   if (n == 0) return;                                     // the pair has no level l: peeled already
@@ -690,16 +782,28 @@ __device__ __forceinline__ void order_stream_body(const Args &a, uint32_t s, uin
 
 // Launch shapes: blockIdx -> (problem, sweep of the chunk, part of the pair's work); `problems` of a
 // single call is one descriptor (the same kernels serve asp_sa_anneal_shuffled and the batch).
+// XCD-LOCAL PAIRS: workgroups are dealt round-robin over the chip's eight XCDs (blocks b and b + 8
+// share one), each with an L2 of its own, and the peel of a pair is atomics on the pair's counters
+// and list tails: with the parts of a pair in consecutive blocks, every counter line travelled
+// between eight L2s.  The parts of one pair are therefore blocks of EQUAL index mod 8 — the same in
+// every launch of the chain, so the priorities, counters, masks and lists of a pair stay in one L2
+// from launch to launch.  (A placement for speed only: the atomics are device-scope.)
 struct WideGrid {
   uint32_t count, parts;  // sweeps of the chunk, workgroups per (problem, sweep)
+  uint32_t pairs;         // problems x count
 };
+__host__ __device__ inline uint32_t wide_grid_blocks(uint32_t pairs, uint32_t parts) {
+  return ((pairs + 7u) & ~7u) * parts;
+}
 template <typename F>
 __device__ __forceinline__ void wide_dispatch(const OrderArgs *problems, WideGrid g, F body) {
   using ConstArgs = const OrderArgs __attribute__((address_space(4)));
-  const uint32_t per_problem = g.count * g.parts;
-  const uint32_t problem = blockIdx.x / per_problem, rest = blockIdx.x - problem * per_problem;
+  const uint32_t xcd = blockIdx.x & 7u, y = blockIdx.x >> 3;
+  const uint32_t pair = (y / g.parts) * 8u + xcd, part = y % g.parts;
+  if (pair >= g.pairs) return;
+  const uint32_t problem = pair / g.count;
   ConstArgs *a = reinterpret_cast<ConstArgs *>(reinterpret_cast<uintptr_t>(problems + problem));
-  body(*a, rest / g.parts, rest % g.parts);
+  body(*a, pair - problem * g.count, part);
 }
 __global__ __launch_bounds__(kWideThreads) void k_order_prio(const OrderArgs *problems, WideGrid g) {
   wide_dispatch(problems, g, [&](const auto &a, uint32_t s, uint32_t part) { order_prio_body(a, s, part, g.parts); });
@@ -719,11 +823,15 @@ __global__ __launch_bounds__(kOrderThreads) void k_shuffled_orders(OrderArgs a) 
   shuffled_orders_body(a, blockIdx.x);
 }
 
-// Many problems, `count` sweeps of each: workgroup -> (problem, sweep).
-__global__ __launch_bounds__(kOrderThreads) void k_shuffled_orders_batch(const OrderArgs *problems, uint32_t count) {
+// Many problems, `count` sweeps of each: workgroup -> (problem, sweep).  `wide_pass`: the launch is
+// for the problems of the wide path only (1) or for the others only (0) — two launches, each with
+// the LDS its own problems need (the finish workgroup of a large cluster holds K bytes of counters).
+__global__ __launch_bounds__(kOrderThreads) void k_shuffled_orders_batch(const OrderArgs *problems, uint32_t count,
+                                                                         uint32_t wide_pass) {
   using ConstArgs = const OrderArgs __attribute__((address_space(4)));
   const uint32_t problem = blockIdx.x / count;
   ConstArgs *a = reinterpret_cast<ConstArgs *>(reinterpret_cast<uintptr_t>(problems + problem));
+  if ((a->finish_only != 0u) != (wide_pass != 0u)) return;
   shuffled_orders_body(*a, blockIdx.x - problem * count);
 }
 
@@ -1547,10 +1655,14 @@ int shuffled_layout_for(uint64_t K, int m, uint32_t level_cap, uint32_t block_ca
   return -1;
 }
 
-// (`arrays_of`: K when the peel's per-spin arrays live in LDS — PeelArrays<true> —, else 0)
-size_t order_lds_bytes(uint32_t level_cap, uint32_t block_cap, uint32_t waves, uint64_t arrays_of = 0) {
+// (`arrays_of`: K when the peel's per-spin arrays live in LDS — kPeelLds —, else 0; `counter_words`:
+// words of the counters when only they do — kPeelLdsCounters / kPeelLdsNibbles: they lie over the
+// block tables)
+size_t order_lds_bytes(uint32_t level_cap, uint32_t block_cap, uint32_t waves, uint64_t arrays_of = 0,
+                       uint64_t counter_words = 0) {
+  const size_t tables = 2 * (static_cast<size_t>(block_cap) + 1) + 2 * static_cast<size_t>(waves) * 64;
   return sizeof(uint32_t) * (8 + 16 + 2 * (static_cast<size_t>(level_cap) + 2) +
-                             2 * (static_cast<size_t>(block_cap) + 1) + 2 * static_cast<size_t>(waves) * 64 +
+                             std::max<size_t>(tables, counter_words) +
                              arrays_of + (arrays_of + 3) / 4 + (arrays_of + 1) / 2);
 }
 
@@ -1603,21 +1715,24 @@ struct WidePartsMax {
   uint32_t prio = 1, counts = 1, level = 1, stream = 1, levels = 0;
 };
 int launch_wide_front(hipStream_t os, const OrderArgs *problems, uint32_t P, uint32_t now, const WidePartsMax &w) {
-  hipLaunchKernelGGL(k_order_prio, dim3(P * now * w.prio), dim3(kWideThreads), 0, os, problems, WideGrid{now, w.prio});
+  const uint32_t pairs = P * now;
+  hipLaunchKernelGGL(k_order_prio, dim3(wide_grid_blocks(pairs, w.prio)), dim3(kWideThreads), 0, os, problems,
+                     WideGrid{now, w.prio, pairs});
   ASP_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_order_counts, dim3(P * now * w.counts), dim3(kWideThreads), 0, os, problems,
-                     WideGrid{now, w.counts});
+  hipLaunchKernelGGL(k_order_counts, dim3(wide_grid_blocks(pairs, w.counts)), dim3(kWideThreads), 0, os, problems,
+                     WideGrid{now, w.counts, pairs});
   ASP_HIP_TRY(hipGetLastError());
   for (uint32_t l = 0; l < w.levels; ++l) {
-    hipLaunchKernelGGL(k_order_level, dim3(P * now * w.level), dim3(kWideThreads), 0, os, problems,
-                       WideGrid{now, w.level}, l);
+    hipLaunchKernelGGL(k_order_level, dim3(wide_grid_blocks(pairs, w.level)), dim3(kWideThreads), 0, os, problems,
+                       WideGrid{now, w.level, pairs}, l);
   }
   ASP_HIP_TRY(hipGetLastError());
   return ASP_OK;
 }
 int launch_wide_stream(hipStream_t os, const OrderArgs *problems, uint32_t P, uint32_t now, const WidePartsMax &w) {
-  hipLaunchKernelGGL(k_order_stream, dim3(P * now * w.stream), dim3(kWideThreads), 0, os, problems,
-                     WideGrid{now, w.stream});
+  const uint32_t pairs = P * now;
+  hipLaunchKernelGGL(k_order_stream, dim3(wide_grid_blocks(pairs, w.stream)), dim3(kWideThreads), 0, os, problems,
+                     WideGrid{now, w.stream, pairs});
   ASP_HIP_TRY(hipGetLastError());
   return ASP_OK;
 }
@@ -1855,6 +1970,7 @@ struct ShuffledRun {
   size_t lds = 0, order_lds = 0;
   bool order_in_lds = false;
   bool wide_orders = false;  // the order build as grids over the chunk (k_order_*): large clusters
+  int counters_in_lds = 0;  // ... of which the peel is the per-sweep workgroup's: 1 bytes, 2 nibbles in LDS
   uint32_t wide_levels = 0;  // level launches per chunk of the wide path (wide_level_launches)
   double expected_levels = 0.0;  // levels a sweep is expected to have (setup())
   DeviceBuffer<uint32_t> d_peel_ctl[kLanes], d_level_start[kLanes];
@@ -1926,9 +2042,25 @@ struct ShuffledRun {
     // are resident beside the order workgroups) and the counters fit a byte
     order_in_lds = K < 65536 && p->rq_max_quads * 4u <= 255u && !std::getenv("ASP_SHUFFLED_ORDER_IN_HBM") &&
                    order_lds_bytes(level_cap, block_cap, order_threads / 64, K) <= p->max_lds * 9 / 16;
-    order_lds = order_lds_bytes(level_cap, block_cap, order_threads / 64, order_in_lds ? K : 0);
     wide_orders = !order_in_lds && !std::getenv("ASP_SHUFFLED_ORDER_FUSED");
-    wide_levels = wide_orders ? wide_level_launches(expected_levels, level_cap) : 0u;
+    // Beyond that: priorities, counts and the later-masks from grids over the chunk, and the PEEL in
+    // the per-sweep workgroup with its counters as bytes in LDS when those fit (K <= ~150 000) —
+    // the peel's decrements are random atomics, and in HBM the chip retires ~27 G of them a second
+    // whatever their locality (tools/atomics_probe.hip); else level launches (k_order_level).
+    counters_in_lds = 0;
+    if (wide_orders && !std::getenv("ASP_SHUFFLED_COUNTERS_IN_HBM")) {
+      const uint32_t ow = order_threads / 64;
+      const bool bytes_fit = p->rq_max_quads * 4u <= 255u && !std::getenv("ASP_SHUFFLED_COUNTER_NIBBLES") &&
+                             order_lds_bytes(level_cap, block_cap, ow, 0, (K + 3) / 4) <= p->max_lds;
+      if (bytes_fit) {
+        counters_in_lds = 1;
+      } else if (order_lds_bytes(level_cap, block_cap, ow, 0, (K + 7) / 8) <= p->max_lds) {
+        counters_in_lds = 2;  // nibbles; spins with 15 or more earlier neighbours count in HBM
+      }
+    }
+    order_lds = order_lds_bytes(level_cap, block_cap, order_threads / 64, order_in_lds ? K : 0,
+                                counters_in_lds == 1 ? (K + 3) / 4 : (counters_in_lds == 2 ? (K + 7) / 8 : 0));
+    wide_levels = wide_orders && !counters_in_lds ? wide_level_launches(expected_levels, level_cap) : 0u;
     if (order_lds > p->max_lds) {
       return asp::set_error(ASP_ERR_TOO_LARGE, "%u levels x %u blocks do not fit the order kernel's LDS",
                             level_cap, block_cap);
@@ -1983,6 +2115,7 @@ struct ShuffledRun {
     oa.num_quads = p->rq_quads;
     oa.max_quads = p->rq_max_quads;
     oa.lds_arrays = order_in_lds ? 1u : 0u;
+    oa.lds_counters = static_cast<uint32_t>(counters_in_lds);
     oa.finish_only = wide_orders ? 1u : 0u;
     oa.wide_levels = wide_levels;
     oa.col_shift = (layout == kWide || layout == kGlobal) ? 2u : 0u;  // (byte offsets of 32-bit spin words)
@@ -2323,15 +2456,17 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
       ASP_TRY(r->plan_sizes());
       chunk = std::min(chunk, r->chunk);
     }
-    size_t order_lds = 0;
+    size_t order_lds = 0, order_lds_wide = 0;  // of the two order launches (k_shuffled_orders_batch)
     for (ShuffledRun *r : runs) {
       ASP_TRY(r->plan_buffers(chunk));
-      order_lds = std::max(order_lds, r->order_lds);
+      size_t &of = r->wide_orders ? order_lds_wide : order_lds;
+      of = std::max(of, r->order_lds);
     }
     for (ShuffledRun *r : runs) ASP_HIP_TRY(hipStreamSynchronize(r->p->stream));  // schedules up, status zeroed
-    if (order_lds > 64 * 1024) {
+    if (std::max(order_lds, order_lds_wide) > 64 * 1024) {
       ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shuffled_orders_batch),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(order_lds)));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(std::max(order_lds, order_lds_wide))));
     }
     std::vector<std::unique_ptr<Class>> classes;
     for (uint32_t i = 0; i < P; ++i) {
@@ -2473,8 +2608,14 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
         const OrderArgs *chunk_problems = d_oargs.ptr + static_cast<size_t>(turn) * P;
         const OrderArgs *chunk_wide = Pw ? d_oargs_wide.ptr + static_cast<size_t>(turn) * Pw : nullptr;
         if (Pw) ASP_TRY(launch_wide_front(os, chunk_wide, Pw, now, wide));
-        hipLaunchKernelGGL(k_shuffled_orders_batch, dim3(P * now), dim3(order_threads), order_lds, os,
-                           chunk_problems, now);
+        if (Pw < P) {
+          hipLaunchKernelGGL(k_shuffled_orders_batch, dim3(P * now), dim3(order_threads), order_lds, os,
+                             chunk_problems, now, 0u);
+        }
+        if (Pw) {
+          hipLaunchKernelGGL(k_shuffled_orders_batch, dim3(Pw * now), dim3(order_threads), order_lds_wide, os,
+                             chunk_wide, now, 1u);
+        }
         ASP_HIP_TRY(hipGetLastError());
         if (Pw) ASP_TRY(launch_wide_stream(os, chunk_wide, Pw, now, wide));
         ASP_HIP_TRY(hipEventRecord(ordered[which], os));

@@ -1285,16 +1285,28 @@ def test_shuffled_lane_packing_over_many_chunks_and_in_a_batch():
         assert np.array_equal(bx, oxs) and be.tobytes() == oes.tobytes()
 
 
+_LEVEL_LAUNCHES = {"ASP_SHUFFLED_ORDER_IN_HBM": "1", "ASP_SHUFFLED_COUNTERS_IN_HBM": "1"}
+
+
 @pytest.mark.parametrize("n,degree,reps,sweeps,env", [
-    (3000, 12.0, 6, 40, {"ASP_SHUFFLED_ORDER_IN_HBM": "1"}),                     # the wide grids on a small cluster
+    (3000, 12.0, 6, 40, _LEVEL_LAUNCHES),                                        # the level launches on a small cluster
+    (3000, 12.0, 6, 40, {"ASP_SHUFFLED_ORDER_IN_HBM": "1"}),                     # counters in LDS, the rest in HBM
     (3000, 12.0, 6, 40, {"ASP_SHUFFLED_ORDER_IN_HBM": "1", "ASP_SHUFFLED_ORDER_FUSED": "1"}),  # one workgroup per sweep, arrays in HBM
-    (700, 9.0, 20, 300, {"ASP_SHUFFLED_ORDER_IN_HBM": "1", "ASP_SHUFFLED_BYTES": "400000"}),   # many chunks, lane packing
-    (70000, 6.0, 3, 24, {}),                                                     # beyond 16-bit indices: wide by itself
+    (700, 9.0, 20, 300, dict(_LEVEL_LAUNCHES, ASP_SHUFFLED_BYTES="400000")),     # many chunks, lane packing
+    (701, 9.0, 20, 300, {"ASP_SHUFFLED_ORDER_IN_HBM": "1", "ASP_SHUFFLED_BYTES": "400000"}),   # the same, counters in LDS
+    (70000, 6.0, 3, 24, {}),                                                     # beyond 16-bit indices: counters in LDS by itself
+    (70000, 6.0, 3, 24, {"ASP_SHUFFLED_COUNTERS_IN_HBM": "1"}),                  # ... and the level launches
+    (3000, 40.0, 4, 30, {"ASP_SHUFFLED_ORDER_IN_HBM": "1", "ASP_SHUFFLED_COUNTER_NIBBLES": "1"}),  # 4-bit counters, most spins on the HBM escape
+    (3001, 9.0, 4, 30, {"ASP_SHUFFLED_ORDER_IN_HBM": "1", "ASP_SHUFFLED_COUNTER_NIBBLES": "1"}),   # ... few of them
+    (170000, 5.0, 2, 12, {}),                                                    # beyond byte counters: nibbles by itself
+    (330000, 4.0, 2, 8, {}),                                                     # beyond those: level launches by itself
 ])
 def test_shuffled_order_build_paths(monkeypatch, n, degree, reps, sweeps, env):
-    """The visiting orders are built by one of three device paths — a workgroup per sweep with the
-    peel's arrays in LDS, the same with the arrays in HBM, or (large clusters) grids over all sweeps of
-    the chunk with one launch per level — and every path must give the oracle's chains."""
+    """The visiting orders are built by one of four device paths — a workgroup per sweep with the
+    peel's arrays in LDS, the same with the arrays in HBM, or (large clusters) priorities, counts and
+    stream as grids over all sweeps of the chunk and the peel either in the per-sweep workgroup with
+    its counters in LDS (bytes, or nibbles with an HBM escape for spins of 15 or more earlier
+    neighbours) or as one launch per level — and every path must give the oracle's chains."""
     from annealing_sign_problem_amd import annealer as sa
 
     for key, value in env.items():
@@ -1315,6 +1327,7 @@ def test_shuffled_wide_orders_hand_over_to_the_sweep_workgroup(monkeypatch, wide
     from annealing_sign_problem_amd import annealer as sa
 
     monkeypatch.setenv("ASP_SHUFFLED_ORDER_IN_HBM", "1")
+    monkeypatch.setenv("ASP_SHUFFLED_COUNTERS_IN_HBM", "1")
     monkeypatch.setenv("ASP_SHUFFLED_BYTES", "2000000")  # several chunks
     monkeypatch.setenv("ASP_SHUFFLED_WIDE_LEVELS", str(wide_levels))
     J, h, ham, info, betas = _shuffled_case(2500, 10.0, 60, seed=17)
@@ -1327,6 +1340,24 @@ def test_shuffled_wide_orders_hand_over_to_the_sweep_workgroup(monkeypatch, wide
     o2, e2, _, _ = oracle.sa_anneal_shuffled(other[0], other[1], 6, other[4], 4, 0, None, other[3].energy_scale_exp,
                                              num_threads=4)
     assert np.array_equal(results[1][0], o2) and results[1][1].tobytes() == e2.tobytes()
+
+
+def test_shuffled_batch_mixes_the_order_build_paths():
+    """One batch with a cluster of every order-build path — arrays in LDS, byte and nibble counters in LDS
+    (peel in the per-sweep workgroup), level launches — shares its launches; every problem is its own
+    call's chain."""
+    from annealing_sign_problem_amd import annealer as sa
+
+    cases = [_shuffled_case(400, 8.0, 10, seed=31), _shuffled_case(60000, 6.0, 10, seed=32),
+             _shuffled_case(165000, 5.0, 10, seed=33), _shuffled_case(30000, 7.0, 10, seed=34),
+             _shuffled_case(330000, 4.0, 10, seed=35)]
+    seeds, reps_of = (1, 2, 3, 4, 5), (4, 2, 2, 3, 1)
+    results = sa.anneal_batch_raw([c[2] for c in cases], list(seeds), [c[4] for c in cases], list(reps_of),
+                                  shuffled=True)
+    for (J, h, ham, info, betas), seed, reps, (bx, be) in zip(cases, seeds, reps_of, results):
+        oxs, oes, _, _ = oracle.sa_anneal_shuffled(J, h, seed, betas, reps, 0, None, info.energy_scale_exp,
+                                                   num_threads=4)
+        assert np.array_equal(bx, oxs) and be.tobytes() == oes.tobytes()
 
 
 def test_shuffled_fill_statistics():
