@@ -233,6 +233,35 @@ struct PeelArrays {
     }
     // (kPeelLdsCounters / kPeelLdsNibbles: loaded from k_order_counts' words, see the prologue)
   }
+  // The same in two steps, so that the atomics of many neighbours are in flight together: the word
+  // returned by the atomic (`peeked`: the neighbour's LDS word read beforehand, nibbles only), and
+  // what it says.
+  __device__ __forceinline__ uint32_t peek(uint32_t n) const {
+    if constexpr (MODE == kPeelLdsNibbles) return indeg[n >> 3];
+    return 0u;
+  }
+  __device__ __forceinline__ bool counts_in_hbm(uint32_t n, uint32_t peeked) const {
+    return MODE == kPeelLdsNibbles && ((peeked >> (4u * (n & 7u))) & 15u) == 15u;
+  }
+  __device__ __forceinline__ uint32_t decrement(uint32_t n, uint32_t peeked) const {
+    if constexpr (MODE == kPeelLdsNibbles) {
+      if (counts_in_hbm(n, peeked)) return atomicSub(exact + n, 1u);
+      return atomicSub(indeg + (n >> 3), 1u << (4u * (n & 7u)));
+    } else if constexpr (kCountersInLds) {
+      return atomicSub(indeg + (n >> 2), 1u << (8u * (n & 3u)));
+    } else {
+      return atomicSub(indeg + n, 1u);
+    }
+  }
+  __device__ __forceinline__ bool was_last(uint32_t n, uint32_t peeked, uint32_t returned) const {
+    if constexpr (MODE == kPeelLdsNibbles) {
+      return counts_in_hbm(n, peeked) ? returned == 1u : ((returned >> (4u * (n & 7u))) & 15u) == 1u;
+    } else if constexpr (kCountersInLds) {
+      return ((returned >> (8u * (n & 3u))) & 0xFFu) == 1u;
+    } else {
+      return returned == 1u;
+    }
+  }
   // one earlier neighbour of spin n has been visited: true when it was the last one
   __device__ __forceinline__ bool visited_one(uint32_t n) const {
     if constexpr (MODE == kPeelLdsNibbles) {
@@ -421,31 +450,90 @@ __device__ __forceinline__ void shuffled_orders_impl(const Args &a, const uint32
           }
         }
       };
-      for (uint32_t m0 = begin + gid; m0 < end; m0 += groups * U) {
-        uint32_t q0[U], q1[U];
+      uint32_t *order_w = static_cast<uint32_t *>(peel.order);
+      uint32_t *row_quads = a.prio + static_cast<uint64_t>(s) * K;  // (the priorities: of no use after the counts)
+      // (the trip count is the SAME for every lane of the workgroup: the appends below are wave-wide)
+      for (uint32_t base = begin; base < end; base += groups * U) {
+        const uint32_t m0 = base + gid;
+        // (every load below is UNCONDITIONAL — a lane without a row or a quad reads a valid address and
+        // discards the value —: loads under a branch are waited for one by one)
+        uint32_t row[U], q0[U], q1[U];
+        bool live[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const uint32_t m = m0 + static_cast<uint32_t>(u) * groups;
-          q0[u] = m < end ? order[m] : 0xFFFFFFFFu;
+          live[u] = m < end;
+          row[u] = order[live[u] ? m : begin];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const uint32_t i = q0[u];
-          q0[u] = i != 0xFFFFFFFFu ? a.rq_ptr[i] : 0u;
-          q1[u] = i != 0xFFFFFFFFu ? a.rq_ptr[i + 1] : 0u;
+          q0[u] = a.rq_ptr[row[u]];
+          q1[u] = a.rq_ptr[row[u] + 1u];
         }
-        uint4 c[U];
-        uint32_t mask[U];
+        // (the rows' lengths beside the order, for the sort of the levels: no gathers there)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (sub == 0 && live[u]) row_quads[m0 + static_cast<uint32_t>(u) * groups] = q1[u] - q0[u];
+        }
+        uint32_t cs[U][4], mask[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const uint32_t q = q0[u] + sub;
-          const bool have = q < q1[u];
-          c[u] = have ? a.rq_col[q] : make_uint4(0u, 0u, 0u, 0u);
-          mask[u] = have ? later[q] : 0u;
+          const bool have = live[u] && q < q1[u];
+          const uint32_t at = have ? q : 0u;
+          const uint4 c = a.rq_col[at];
+          mask[u] = later[at];
+          mask[u] = have ? mask[u] : 0u;
+          cs[u][0] = c.x, cs[u][1] = c.y, cs[u][2] = c.z, cs[u][3] = c.w;
+          if (!live[u]) q1[u] = 0u;  // (no remainder either)
+        }
+        // the decrements of the batch's 4 U entries per lane: issued together, read afterwards
+        uint32_t peeked[U][4], returned[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) peeked[u][j] = peel.peek(cs[u][j]);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) visit(c[u], mask[u]);
-        // (rows of more than G quads)
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            returned[u][j] = 0u;
+            if ((mask[u] >> j) & 1u) returned[u][j] = peel.decrement(cs[u][j], peeked[u][j]);
+          }
+        }
+        // the spins whose last earlier neighbour this was: ONE atomic on the order's tail per
+        // wavefront and batch (ballots give every lane its place), not one per spin
+        uint32_t total = 0;
+        uint64_t pushing[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool hit = ((mask[u] >> j) & 1u) && peel.was_last(cs[u][j], peeked[u][j], returned[u][j]);
+            pushing[u][j] = __ballot(hit);
+            total += static_cast<uint32_t>(__builtin_popcountll(pushing[u][j]));
+          }
+        }
+        if (total) {  // (uniform over the wavefront)
+          uint32_t first = 0;
+          if (lane == 0) first = atomicAdd(&ctl[0], total);
+          first = __builtin_amdgcn_readfirstlane(first);
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const uint64_t p = pushing[u][j];
+              if ((p >> lane) & 1ull) {
+                const uint32_t before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(p >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(p), 0u));
+                order_w[first + before] = cs[u][j];
+              }
+              first += static_cast<uint32_t>(__builtin_popcountll(p));
+            }
+          }
+        }
+        // (rows of more than G quads: a lane at a time)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           for (uint32_t q = q0[u] + sub + G; q < q1[u]; q += G) visit(a.rq_col[q], later[q]);
@@ -520,9 +608,14 @@ __device__ __forceinline__ void shuffled_orders_impl(const Args &a, const uint32
     hist[wave * 64u + lane] = 0;
     __syncthreads();
     for (uint32_t m = lane; m < n; m += 64u) {
-      const uint32_t i = peel.order_at(lo + m);
-      const uint32_t cls = min(a.rq_ptr[i + 1] - a.rq_ptr[i], kClassCap);
-      atomicAdd(&hist[wave * 64u + cls], 1u);
+      uint32_t quads;
+      if constexpr (MODE == kPeelLdsCounters || MODE == kPeelLdsNibbles) {
+        quads = a.prio[static_cast<uint64_t>(s) * K + lo + m];  // (written by the peel, position by position)
+      } else {
+        const uint32_t i = peel.order_at(lo + m);
+        quads = a.rq_ptr[i + 1] - a.rq_ptr[i];
+      }
+      atomicAdd(&hist[wave * 64u + min(quads, kClassCap)], 1u);
     }
     __syncthreads();
     {
@@ -538,8 +631,13 @@ __device__ __forceinline__ void shuffled_orders_impl(const Args &a, const uint32
     __syncthreads();
     for (uint32_t m = lane; m < n; m += 64u) {
       const uint32_t i = peel.order_at(lo + m);
-      const uint32_t cls = min(a.rq_ptr[i + 1] - a.rq_ptr[i], kClassCap);
-      sop[pos0 + atomicAdd(&cursor[wave * 64u + cls], 1u)] = i;
+      uint32_t quads;
+      if constexpr (MODE == kPeelLdsCounters || MODE == kPeelLdsNibbles) {
+        quads = a.prio[static_cast<uint64_t>(s) * K + lo + m];
+      } else {
+        quads = a.rq_ptr[i + 1] - a.rq_ptr[i];
+      }
+      sop[pos0 + atomicAdd(&cursor[wave * 64u + min(quads, kClassCap)], 1u)] = i;
     }
     for (uint32_t m = n + lane; m < ((n + S - 1u) & ~(S - 1u)); m += 64u) sop[pos0 + m] = kDummySpin;
     __syncthreads();
@@ -1939,6 +2037,9 @@ struct ShuffledRun {
     if (order_threads_cap) order_threads = std::min(order_threads, order_threads_cap);
     lanes_per_row = std::min(64u, std::min(order_threads, next_pow2(std::max(
         1u, static_cast<uint32_t>(std::ceil(mean_degree / 4.0))))));
+    if (const char *env = std::getenv("ASP_SHUFFLED_LANES_PER_ROW")) {  // measurements
+      lanes_per_row = std::min(64u, next_pow2(std::max(1u, static_cast<uint32_t>(std::atoi(env)))));
+    }
     if (const char *env = std::getenv("ASP_SHUFFLED_BYTES")) budget = std::strtoull(env, nullptr, 10);
 
     // (the run's own order streams and events: made by enqueue(), which the batched driver — with
@@ -2434,7 +2535,7 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
   // block size) — eleven streams on the production mix — kernels waiting for their chunk's orders
   // blocked the queues of kernels that could have run (profiles/r04_shuffled_batch_trace.txt).
   struct Class {
-    int layout, m;
+    int layout, m, lds_bucket;
     uint32_t waves = 0;  // of the launch: the most any member wants
     bool packed_lanes;
     std::vector<uint32_t> members;
@@ -2469,17 +2570,29 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
                                       static_cast<int>(std::max(order_lds, order_lds_wide))));
     }
     std::vector<std::unique_ptr<Class>> classes;
+    int lds_buckets = 2;  // (scanned on the kagome_36 pipeline: 8.1 / 7.4 / 9.3 s per round with 1 / 2 / 3)
+    if (const char *env = std::getenv("ASP_SHUFFLED_LDS_BUCKETS")) lds_buckets = std::atoi(env);
     for (uint32_t i = 0; i < P; ++i) {
       ShuffledRun *r = runs[i];
       Class *c = nullptr;
+      // (a launch has ONE LDS size, the largest of its members: a 2 000-spin model in the launch of a
+      // 200 000-spin one would hold a whole compute unit's LDS — three LDS sizes per kernel, so
+      // four, two or one workgroup per compute unit)
+      int lds_bucket = r->lds <= 40 * 1024 ? 0 : (r->lds <= 80 * 1024 ? 1 : 2);
+      if (lds_buckets == 2) lds_bucket = r->lds <= 64 * 1024 ? 0 : 1;
+      if (lds_buckets <= 1) lds_bucket = 0;
       for (auto &k : classes) {
-        if (k->layout == r->layout && k->m == r->m && k->packed_lanes == r->packed_lanes) c = k.get();
+        if (k->layout == r->layout && k->m == r->m && k->packed_lanes == r->packed_lanes &&
+            k->lds_bucket == lds_bucket) {
+          c = k.get();
+        }
       }
       if (!c) {
         classes.emplace_back(new Class());
         c = classes.back().get();
         c->layout = r->layout;
         c->m = r->m;
+        c->lds_bucket = lds_bucket;
         c->packed_lanes = r->packed_lanes;
         ASP_TRY(c->stream.acquire());
         for (auto &e : c->swept) ASP_TRY(events.make(&e));
@@ -2488,6 +2601,9 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
       c->lds = std::max(c->lds, r->lds);
       c->waves = std::max(c->waves, r->waves);
     }
+    // the launches of the large workgroups first: the small ones fill the compute units they leave
+    std::stable_sort(classes.begin(), classes.end(),
+                     [](const std::unique_ptr<Class> &x, const std::unique_ptr<Class> &y) { return x->lds > y->lds; });
     // (a kernel is keyed by (m, layout, packing), a class also by its wavefronts and block size:
     // classes may share a kernel, and its dynamic-LDS limit must cover the largest of them)
     std::vector<std::pair<ShuffledBatchKernel, size_t>> kernel_lds;
