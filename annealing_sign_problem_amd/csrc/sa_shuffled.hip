@@ -2813,6 +2813,11 @@ int sa_shuffled_batch(asp_sa_batch_item const *items, const uint32_t *which, uin
     const int forced = std::atoi(env);
     if (forced == 1 || forced == 2 || forced == 4) m = forced;
   }
+  int big_m = 8;  // chains per workgroup of the clusters beyond the word layout, in a batch that fills the chip
+  if (const char *env = std::getenv("ASP_SHUFFLED_BATCH_BIG_M")) {
+    const int forced = std::atoi(env);
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) big_m = forced;
+  }
   for (uint32_t k = 0; k < count; ++k) {
     const asp_sa_batch_item &it = items[which[k]];
     runs.emplace_back(new ShuffledRun());
@@ -2834,7 +2839,7 @@ int sa_shuffled_batch(asp_sa_batch_item const *items, const uint32_t *which, uin
       // coupling, written once and read by EVERY workgroup of the problem — is the traffic of such a
       // model: 350 bytes per spin and sweep over M chains; the real kagome_36 order-2 models (3.5e4 ..
       // 3e5 spins, 64 chains each) moved 87 bytes per flip at M = 4.
-      if (saturates && it.plan->host.num_spins * 4ull > it.plan->max_lds * 15 / 16) r.forced_m = 8;
+      if (saturates && it.plan->host.num_spins * 4ull > it.plan->max_lds * 15 / 16) r.forced_m = big_m;
     }
     r.batch_saturates = saturates;
     if (const char *env = std::getenv("ASP_SHUFFLED_ORDER_THREADS")) {  // (development: scanned 128 .. 1024, no effect)
