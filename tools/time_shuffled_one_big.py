@@ -11,6 +11,8 @@ ham = sa.Hamiltonian(J, h)
 info = ham.info()
 betas = sa.make_schedule(info.beta0_auto, info.beta1_auto, sweeps)
 lib = _lib.load()
+if len(sys.argv) > 5:
+    lib.asp_sa_set_shuffled_launch(ham.plan(), int(sys.argv[4]), int(sys.argv[5]))
 for _ in range(2):
     t0 = time.perf_counter()
     sa.anneal_raw(ham, 12345, betas, 64, shuffled=True)

@@ -1,3 +1,6 @@
+#!/bin/bash
+# rocprofv3 --kernel-trace of one annealing round of the kagome_36 pipeline (32 clusters); read the
+# database with tools/trace_report.py gpurun_out/pipe_trace/t_results.db.  GPU box.
 export TMPDIR=/tmp
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 D=/tmp/k36; mkdir -p $D

@@ -1,3 +1,6 @@
+"""Per-kernel totals and a stretch of the timeline from a rocprofv3 --kernel-trace database (rocpd .db).
+    python tools/trace_report.py <results.db> [position 0..1 = 0.75] [milliseconds = 30] [rows = 80]
+(Development aid.)"""
 import sqlite3, re, collections, sys
 db=sqlite3.connect(sys.argv[1])
 c=db.cursor()
