@@ -703,16 +703,25 @@ __device__ __forceinline__ void shuffled_orders_impl(const Args &a, const uint32
 #endif
 }
 
-template <typename Args>
+// (WIDE: the per-sweep workgroup of a cluster of the wide path — a kernel of its own: its batched
+// peel holds 81 registers per lane where the others need 54, and at 1024 threads per workgroup that
+// is the difference between one and two workgroups per compute unit for the small clusters)
+template <bool WIDE, typename Args>
 __device__ __forceinline__ void shuffled_orders_body(const Args &a, const uint32_t s) {
-  if (a.lds_arrays) {
-    shuffled_orders_impl<kPeelLds>(a, s);
-  } else if (a.lds_counters == 1u) {
-    shuffled_orders_impl<kPeelLdsCounters>(a, s);
-  } else if (a.lds_counters == 2u) {
-    shuffled_orders_impl<kPeelLdsNibbles>(a, s);
+  if constexpr (WIDE) {
+    if (a.lds_counters == 1u) {
+      shuffled_orders_impl<kPeelLdsCounters>(a, s);
+    } else if (a.lds_counters == 2u) {
+      shuffled_orders_impl<kPeelLdsNibbles>(a, s);
+    } else {
+      shuffled_orders_impl<kPeelHbm>(a, s);
+    }
   } else {
-    shuffled_orders_impl<kPeelHbm>(a, s);
+    if (a.lds_arrays) {
+      shuffled_orders_impl<kPeelLds>(a, s);
+    } else {
+      shuffled_orders_impl<kPeelHbm>(a, s);
+    }
   }
 }
 
@@ -917,20 +926,21 @@ __global__ __launch_bounds__(kWideThreads) void k_order_stream(const OrderArgs *
   wide_dispatch(problems, g, [&](const auto &a, uint32_t s, uint32_t part) { order_stream_body(a, s, part, g.parts); });
 }
 
+template <bool WIDE>
 __global__ __launch_bounds__(kOrderThreads) void k_shuffled_orders(OrderArgs a) {
-  shuffled_orders_body(a, blockIdx.x);
+  shuffled_orders_body<WIDE>(a, blockIdx.x);
 }
 
-// Many problems, `count` sweeps of each: workgroup -> (problem, sweep).  `wide_pass`: the launch is
-// for the problems of the wide path only (1) or for the others only (0) — two launches, each with
-// the LDS its own problems need (the finish workgroup of a large cluster holds K bytes of counters).
-__global__ __launch_bounds__(kOrderThreads) void k_shuffled_orders_batch(const OrderArgs *problems, uint32_t count,
-                                                                         uint32_t wide_pass) {
+// Many problems, `count` sweeps of each: workgroup -> (problem, sweep).  WIDE: the launch is for the
+// problems of the wide path only, else for the others only — two launches, each with the LDS its own
+// problems need (the finish workgroup of a large cluster holds its counters).
+template <bool WIDE>
+__global__ __launch_bounds__(kOrderThreads) void k_shuffled_orders_batch(const OrderArgs *problems, uint32_t count) {
   using ConstArgs = const OrderArgs __attribute__((address_space(4)));
   const uint32_t problem = blockIdx.x / count;
   ConstArgs *a = reinterpret_cast<ConstArgs *>(reinterpret_cast<uintptr_t>(problems + problem));
-  if ((a->finish_only != 0u) != (wide_pass != 0u)) return;
-  shuffled_orders_body(*a, blockIdx.x - problem * count);
+  if ((a->finish_only != 0u) != WIDE) return;
+  shuffled_orders_body<WIDE>(*a, blockIdx.x - problem * count);
 }
 
 // ---------------------------------------------------------------------------
@@ -2331,7 +2341,7 @@ struct ShuffledRun {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     }
     if (order_lds > 64 * 1024) {
-      ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shuffled_orders),
+      ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wide_orders ? k_shuffled_orders<true> : k_shuffled_orders<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(order_lds)));
     }
     ASP_TRY(plan_buffers(chunk));
@@ -2374,7 +2384,11 @@ struct ShuffledRun {
         // go of it; chunks alternate between the two order streams (a scratch area each)
         if (turn >= static_cast<uint32_t>(nsets)) ASP_HIP_TRY(hipStreamWaitEvent(os, swept[which], 0));
         if (wide_orders) ASP_TRY(launch_wide_front(os, d_oargs.ptr + turn, 1, now, wide));
-        hipLaunchKernelGGL(k_shuffled_orders, dim3(now), dim3(order_threads), order_lds, os, o_args);
+        if (wide_orders) {
+          hipLaunchKernelGGL(k_shuffled_orders<true>, dim3(now), dim3(order_threads), order_lds, os, o_args);
+        } else {
+          hipLaunchKernelGGL(k_shuffled_orders<false>, dim3(now), dim3(order_threads), order_lds, os, o_args);
+        }
         ASP_HIP_TRY(hipGetLastError());
         if (wide_orders) ASP_TRY(launch_wide_stream(os, d_oargs.ptr + turn, 1, now, wide));
         ASP_HIP_TRY(hipEventRecord(ordered[which], os));
@@ -2595,10 +2609,13 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
       of = std::max(of, r->order_lds);
     }
     for (ShuffledRun *r : runs) ASP_HIP_TRY(hipStreamSynchronize(r->p->stream));  // schedules up, status zeroed
-    if (std::max(order_lds, order_lds_wide) > 64 * 1024) {
-      ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shuffled_orders_batch),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      static_cast<int>(std::max(order_lds, order_lds_wide))));
+    if (order_lds > 64 * 1024) {
+      ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shuffled_orders_batch<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(order_lds)));
+    }
+    if (order_lds_wide > 64 * 1024) {
+      ASP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shuffled_orders_batch<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(order_lds_wide)));
     }
     std::vector<std::unique_ptr<Class>> classes;
     int lds_buckets = 2;  // (scanned on the kagome_36 pipeline: 8.1 / 7.4 / 9.3 s per round with 1 / 2 / 3)
@@ -2610,7 +2627,7 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
       // 200 000-spin one would hold a whole compute unit's LDS — three LDS sizes per kernel, so
       // four, two or one workgroup per compute unit)
       int lds_bucket = r->lds <= 40 * 1024 ? 0 : (r->lds <= 80 * 1024 ? 1 : 2);
-      if (lds_buckets == 2) lds_bucket = r->lds <= 64 * 1024 ? 0 : 1;
+      if (lds_buckets == 2) lds_bucket = r->lds <= 80 * 1024 ? 0 : 1;  // (one workgroup per compute unit, or more)
       if (lds_buckets <= 1) lds_bucket = 0;
       for (auto &k : classes) {
         if (k->layout == r->layout && k->m == r->m && k->packed_lanes == r->packed_lanes &&
@@ -2676,6 +2693,12 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
         }
       }
       if (!seen) kernel_lds.emplace_back(kernel, c->lds);
+    }
+    if (std::getenv("ASP_SHUFFLED_HOST_TIMING")) {
+      for (auto &c : classes) {
+        std::fprintf(stderr, "  shuffled batch: class M=%d layout=%d packed=%d: %zu problems, %u slots x %u wavefronts, %zu bytes of LDS\n",
+                     c->m, c->layout, int(c->packed_lanes), c->members.size(), c->num_slots, c->waves, c->lds);
+      }
     }
     for (auto &k : kernel_lds) {
       if (k.second > 64 * 1024) {
@@ -2756,12 +2779,12 @@ int run_shuffled_group(std::vector<ShuffledRun *> &runs, float *sweep_ms) {
         const OrderArgs *chunk_wide = Pw ? d_oargs_wide.ptr + static_cast<size_t>(turn) * Pw : nullptr;
         if (Pw) ASP_TRY(launch_wide_front(os, chunk_wide, Pw, now, wide));
         if (Pw < P) {
-          hipLaunchKernelGGL(k_shuffled_orders_batch, dim3(P * now), dim3(order_threads), order_lds, os,
-                             chunk_problems, now, 0u);
+          hipLaunchKernelGGL(k_shuffled_orders_batch<false>, dim3(P * now), dim3(order_threads), order_lds, os,
+                             chunk_problems, now);
         }
         if (Pw) {
-          hipLaunchKernelGGL(k_shuffled_orders_batch, dim3(Pw * now), dim3(order_threads), order_lds_wide, os,
-                             chunk_wide, now, 1u);
+          hipLaunchKernelGGL(k_shuffled_orders_batch<true>, dim3(Pw * now), dim3(order_threads), order_lds_wide, os,
+                             chunk_wide, now);
         }
         ASP_HIP_TRY(hipGetLastError());
         if (Pw) ASP_TRY(launch_wide_stream(os, chunk_wide, Pw, now, wide));
