@@ -103,6 +103,39 @@ def fingerprint() -> str:
     return _fingerprint([os.path.join(CSRC, s) for s in SOURCES])
 
 
+# What the profiler counters of a sweep case depend on: the kernel's source file and the plan
+# builder that lays out what it reads (with the headers they include).  profiles/sweep_counters.json
+# ties every case to the fingerprint of its set, so that a change to an unrelated kernel file (the
+# coupling build, say) does not void the counters of the sweep kernels, and a change to
+# sa_shuffled.hip voids the shuffled cases only.
+KERNEL_SOURCE_SETS = {
+    "colour": ["sa_sweep.hip", "sa_plan.cpp"],
+    "shuffled": ["sa_shuffled.hip", "sa_plan.cpp"],
+}
+SETS_STAMP_PATH = STAMP_PATH[:-len(".stamp")] + ".sets.stamp"
+
+
+def source_set_fingerprints() -> dict:
+    """{set name: fingerprint} of KERNEL_SOURCE_SETS for the sources as they are now."""
+    out = {}
+    for name, members in KERNEL_SOURCE_SETS.items():
+        sources = [os.path.join(CSRC, s) for s in members]
+        headers = sorted({h for s in sources for h in _included_headers(s)})
+        out[name] = _fingerprint(sources, headers)
+    return out
+
+
+def built_source_set_fingerprints() -> dict | None:
+    """The same, as recorded when the library on disk was built, or None."""
+    import json
+
+    try:
+        with open(SETS_STAMP_PATH) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
 def built_fingerprint() -> str | None:
     """Fingerprint recorded when the library on disk was built, or None."""
     try:
@@ -170,7 +203,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if not (os.path.exists(LIB_PATH) and os.path.exists(STAMP_PATH)):
             return False
         with open(STAMP_PATH) as f:
-            return f.read().strip() == fp
+            if f.read().strip() != fp:
+                return False
+        if built_source_set_fingerprints() is None and os.access(HERE, os.W_OK):
+            _write_sets_stamp()  # (a library built before the per-set stamps existed: same sources)
+        return True
 
     if not force and current():
         return LIB_PATH
@@ -205,7 +242,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
         os.replace(tmp, LIB_PATH)
         with open(STAMP_PATH, "w") as f:
             f.write(fp)
+        _write_sets_stamp()
     return LIB_PATH
+
+
+def _write_sets_stamp() -> None:
+    import json
+
+    tmp = "%s.%d.tmp" % (SETS_STAMP_PATH, os.getpid())
+    with open(tmp, "w") as f:
+        json.dump(source_set_fingerprints(), f)
+    os.replace(tmp, SETS_STAMP_PATH)
 
 
 if __name__ == "__main__":

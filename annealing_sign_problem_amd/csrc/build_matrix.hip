@@ -5,30 +5,39 @@
 // Data in HBM (all SoA except the 512-bit keys, which keep the reference's AoS
 // layout because that is what the ABI hands over):
 //   table   ls_bits512[K]   sorted, unique           table0  u64[K] = words[0]
-//   slots   u64[2^s]        open-addressing hash of table0: {fingerprint:32 | index+1:32}
+//   slots   u64[2^s]        open-addressing hash of table0: {fingerprint:32 | index+1:32}, load
+//                           factor <= 1/2, read a BUCKET of eight slots (64 bytes) per probe
 //   needles ls_bits512[N]   flat, row-major by row
 //   counts i64[K], psi f64[K], coeffs f64[N], other_psi f64[N], other_counts i64[K]
 //   offsets i64[K+1] (prefix sums of other_counts, formed on the host while the upload checks
-//   them), found i32[N] (table index or -1), row_hits u32[K],
-//   block_total u32[row blocks], tile_total u64[2][row blocks / 64] (hits of 64 row blocks)
+//   them), found i32[N] (table index or -1),
+//   group_hits u32[N / 64] (hits among 64 consecutive needles), chunk_total u32[N / 2048],
+//   super_total u64[2][N / 131072] (one parity per run)
 //   out: row u32[N], col u32[N], elements f64[N], field f64[K]
 //
-// One build = THREE launches on one stream, no host round trip except nnz (round 2: twelve —
-// two memsets, two three-kernel scans, four kernels):
-//   k_insert_keys   table -> table0 (words[0]), a flag "some table key has a non-zero word
-//                   1..7", and table0 -> slots (load factor <= 1/2, linear probing, atomicCAS)
-//   k_search_rows   32 lanes per row: each lane resolves one connection through the hash
-//                   (the reference bsearches, cbits/build_matrix.c:37-38; on a unique table
-//                   any exact lookup returns the same element), row hit count by ballot; the
-//                   block's total goes to block_total and, atomically, to its tile's total
-//   k_emit_rows     first the block's output position WITHOUT a scan kernel: the totals of the
-//                   tiles before its own (<= K / 512 numbers) plus the totals of the blocks
-//                   before it inside its tile (<= 63) — integer sums, so the order does not
-//                   matter; then 32 lanes per row: COO triples in input order at ballot-prefix
+// One build = THREE launches on one stream, no host round trip except nnz:
+//   k_insert_keys   table -> table0 (words[0]) and table0 -> slots (linear probing from the
+//                   first slot of the key's bucket, atomicCAS).  Whether some table key has a
+//                   non-zero word 1..7 the host notes while it uploads the keys.
+//   k_search_flat   the needles as ONE FLAT ARRAY, whatever row they belong to: a wavefront
+//                   resolves 64 consecutive needles per trip (4 KiB of contiguous memory, loaded
+//                   coalesced TWO TRIPS AHEAD of their use — the loads depend on nothing), each lane
+//                   one connection through the hash (the reference bsearches,
+//                   cbits/build_matrix.c:37-38; on a unique table any exact lookup returns the
+//                   same element).  Hits are counted per group of 64 needles (ballot), per chunk
+//                   (a workgroup) and, atomically, per super-chunk.  Round 3 searched row by row
+//                   (32 lanes per row: offsets -> needles -> slot -> verify, four dependent round
+//                   trips per wavefront and nothing else in flight): 110 us of a 170 us build.
+//   k_emit_rows     first the block's output position WITHOUT a scan kernel: hits before the
+//                   first needle of its first row = super-chunks before (<= N / 131072 numbers) +
+//                   chunks before inside the super-chunk (<= 63) + groups before inside the chunk
+//                   (<= 31) + hits among the <= 63 needles before it inside its group — integer
+//                   sums, so the order does not matter; then 32 lanes per row: the row's hits
+//                   (first pass over `found`), COO triples in input order at ballot-prefix
 //                   positions (coalesced), and the row's field as a LEFT-TO-RIGHT sum over its
 //                   misses (the reference's rounding, cbits/build_matrix.c:49); last, every block
-//                   zeroes its share of the hash slots and block 0 the flag and the OTHER parity's
-//                   tile totals: the next run finds them clean (the slots are zeroed at creation)
+//                   zeroes its share of the hash slots and block 0 the OTHER parity's super-chunk
+//                   totals: the next run finds them clean
 //
 // Arithmetic: __dmul_rn / __dadd_rn keep every product and the field add
 // separately rounded (no FMA contraction), matching the reference binary.
@@ -42,8 +51,24 @@ namespace {
 using asp::DeviceBuffer;
 
 constexpr int kThreads = 256;
-constexpr int kRowLanes = 32;                         // lanes cooperating on one row
+constexpr int kRowLanes = 32;                         // lanes cooperating on one row (k_emit_rows)
 constexpr int kRowsPerBlock = kThreads / kRowLanes;   // 8
+constexpr uint32_t kGroup = 64;                       // needles a wavefront resolves per trip
+constexpr uint32_t kSearchWaves = kThreads / 64;      // 4
+constexpr uint32_t kTrips = 8;                        // trips of a wavefront of k_search_flat
+constexpr uint32_t kGroupsPerChunk = kSearchWaves * kTrips;  // 32: a chunk = a workgroup = 2048 needles
+constexpr uint32_t kChunk = kGroupsPerChunk * kGroup;
+constexpr uint32_t kChunksPerSuper = 64;              // 131072 needles
+static_assert(kGroupsPerChunk <= 64 && kChunksPerSuper <= 64, "one wavefront sums a level");
+constexpr uint32_t kStagePlaces = kGroup * 5;         // 16-byte places of a wavefront's LDS staging area
+constexpr uint32_t kBucket = 8;                       // hash slots a probe reads: one 128-byte line
+
+// One hash slot: {fingerprint: the hash's high word | index + 1}, 0 = empty.  Eight bytes, so that
+// the whole hash (load factor <= 1/2: 2 MiB at K = 1e5) and the first words it is verified against
+// (table0, 0.8 MiB) stay in an XCD's 4 MiB of L2 beside the needles streaming through it: with
+// the key itself in a 16-byte slot (8 MiB at load factor 1/4) half of the probes missed the L2 and
+// the look-ups fetched as many bytes from HBM as the needles (FETCH_SIZE, round 4).
+using Slot = unsigned long long;
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
   x ^= x >> 30;
@@ -55,53 +80,75 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
 }
 
 __global__ __launch_bounds__(kThreads) void k_insert_keys(const ls_bits512 *__restrict__ table,
-                                                         uint64_t n,
-                                                         uint64_t *__restrict__ table0,
-                                                         uint32_t *__restrict__ tail_flag,
-                                                         unsigned long long *__restrict__ slots,
-                                                         uint64_t mask) {
+                                                         uint64_t n, uint64_t *__restrict__ table0,
+                                                         Slot *__restrict__ slots, uint64_t bucket_mask) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x;
   if (i >= n) return;
-  const ls_bits512 key = table[i];
-  table0[i] = key.words[0];
-  uint64_t tail = 0;
-#pragma unroll
-  for (int w = 1; w < 8; ++w) tail |= key.words[w];
-  if (tail != 0) atomicOr(tail_flag, 1u);
-  const uint64_t h = mix64(key.words[0]);
-  const unsigned long long entry = (h & 0xFFFFFFFF00000000ull) | (i + 1);
-  uint64_t at = h & mask;
-  while (atomicCAS(&slots[at], 0ull, entry) != 0ull) at = (at + 1) & mask;
+  const uint64_t word0 = table[i].words[0];
+  table0[i] = word0;
+  // linear probing over the slots, STARTING at the first slot of the key's bucket: a look-up reads
+  // whole buckets and stops at the first empty slot
+  const uint64_t slot_mask = bucket_mask * kBucket + (kBucket - 1);
+  const uint64_t h = mix64(word0);
+  const Slot entry = (h & 0xFFFFFFFF00000000ull) | (i + 1);
+  uint64_t at = (h & bucket_mask) * kBucket;
+  while (atomicCAS(&slots[at], 0ull, entry) != 0ull) at = (at + 1) & slot_mask;
 }
 
-// Index of the needle (its eight words in registers) in the table, or -1.
-__device__ __forceinline__ int32_t find_key(const unsigned long long *__restrict__ slots,
-                                            uint64_t mask, const uint64_t *__restrict__ table0,
-                                            const ls_bits512 *__restrict__ table,
-                                            bool table_has_tails, const uint64_t (&needle)[8]) {
-  const uint64_t n0 = needle[0];
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// The eight slots of bucket `b` — 64 bytes — in four 16-byte loads AS WRITTEN (left to itself
+// hipcc loads slot after slot, each behind the test of the one before: a dependent round trip per
+// slot; a volatile access becomes a system-scope load past the L2).  vmcnt counts in order, so
+// waiting for these loads is waiting for every older one too — the asm's wait costs what the
+// compiler's would; nothing of the asm is outstanding when the compiler's own waits run.
+__device__ __forceinline__ void load_bucket(const Slot *bucket, u32x4 (&s)[kBucket / 2]) {
+  static_assert(kBucket == 8, "four loads spelled out");
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off\n\t"
+      "global_load_dwordx4 %1, %4, off offset:16\n\t"
+      "global_load_dwordx4 %2, %4, off offset:32\n\t"
+      "global_load_dwordx4 %3, %4, off offset:48\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3])
+      : "v"(bucket)
+      : "memory");
+}
+
+// Index in the table of the needle with first word n0, or -1.  `verify(index)`: the needle IS
+// table[index] (its first word against table0, and — HAS_TAILS — the words 1..7,
+// cbits/build_matrix.c:11-18).  HAS_TAILS = false: no table key has a non-zero word 1..7, so a
+// needle with one (`tail_zero` false) is a miss without a probe.
+template <bool HAS_TAILS, typename Verify>
+__device__ __forceinline__ int32_t find_key(const Slot *__restrict__ slots, uint64_t bucket_mask, uint64_t n0,
+                                            bool tail_zero, Verify verify) {
+  if (!HAS_TAILS && !tail_zero) return -1;
   const uint64_t h = mix64(n0);
   const uint32_t fingerprint = static_cast<uint32_t>(h >> 32);
-  uint64_t needle_tail = 0;
+  for (uint64_t b = h & bucket_mask;; b = (b + 1) & bucket_mask) {
+    u32x4 s[kBucket / 2];
+    load_bucket(slots + b * kBucket, s);
+    uint32_t empty = 0, match = 0;
 #pragma unroll
-  for (int w = 1; w < 8; ++w) needle_tail |= needle[w];
-  for (uint64_t at = h & mask;; at = (at + 1) & mask) {
-    const unsigned long long slot = slots[at];
-    if (slot == 0) return -1;
-    if (static_cast<uint32_t>(slot >> 32) != fingerprint) continue;
-    const uint32_t idx = static_cast<uint32_t>(slot) - 1u;
-    if (table0[idx] != n0) continue;
-    // word 0 matches: the full 512-bit keys must agree (cbits/build_matrix.c:11-18)
-    bool same;
-    if (table_has_tails) {
-      uint64_t diff = 0;
-#pragma unroll
-      for (int w = 1; w < 8; ++w) diff |= table[idx].words[w] ^ needle[w];
-      same = diff == 0;
-    } else {
-      same = needle_tail == 0;
+    for (uint32_t j = 0; j < kBucket / 2; ++j) {  // slot 2 j = {x: index + 1, y: fingerprint}, 2 j + 1 = {z, w}
+      empty |= (s[j].x == 0u ? 1u : 0u) << (2 * j) | (s[j].z == 0u ? 1u : 0u) << (2 * j + 1);
+      match |= (s[j].y == fingerprint ? 1u : 0u) << (2 * j) | (s[j].w == fingerprint ? 1u : 0u) << (2 * j + 1);
     }
-    if (same) return static_cast<int32_t>(idx);
+    // the chain of this needle ends at the first empty slot: candidates are the matches before it
+    // (an occupied slot has index + 1 != 0 whatever its fingerprint)
+    match &= (empty & (0u - empty)) - 1u;
+    while (match) {  // in slot order, as a slot-by-slot probe would; one candidate in all but 2^-32 of the cases
+      const uint32_t j = static_cast<uint32_t>(__ffs(match) - 1);
+      uint32_t index1 = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < kBucket / 2; ++k) {
+        index1 = 2 * k == j ? s[k].x : index1;
+        index1 = 2 * k + 1 == j ? s[k].z : index1;
+      }
+      if (verify(index1 - 1u)) return static_cast<int32_t>(index1 - 1u);
+      match &= match - 1u;
+    }
+    if (empty) return -1;
   }
 }
 
@@ -111,83 +158,126 @@ __device__ __forceinline__ uint32_t half_ballot(bool predicate, uint32_t lane) {
   return static_cast<uint32_t>(all >> (lane & 32u));
 }
 
-__global__ __launch_bounds__(kThreads) void k_search_rows(
-    const unsigned long long *__restrict__ slots, uint64_t mask,
-    const uint64_t *__restrict__ table0, const ls_bits512 *__restrict__ table,
-    const uint32_t *__restrict__ tail_flag, uint64_t num_spins,
-    const ls_bits512 *__restrict__ needles, const int64_t *__restrict__ offsets,
-    int32_t *__restrict__ found, uint32_t *__restrict__ row_hits,
-    uint32_t *__restrict__ block_total, unsigned long long *__restrict__ tile_total) {
+// Workgroup c resolves the needles [c kChunk, (c + 1) kChunk): wavefront w the groups k 4 + w.
+template <bool HAS_TAILS>
+__device__ __forceinline__ void search_flat_body(
+    const Slot *__restrict__ slots, uint64_t bucket_mask, const uint64_t *__restrict__ table0,
+    const ls_bits512 *__restrict__ table, const ls_bits512 *__restrict__ needles, uint64_t num_needles,
+    int32_t *__restrict__ found, uint32_t *__restrict__ group_hits, uint32_t *__restrict__ chunk_total,
+    unsigned long long *__restrict__ super_total, uint4 *stage, uint32_t *hits_of_wave) {
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t sub = threadIdx.x & (kRowLanes - 1);
-  const uint64_t r = static_cast<uint64_t>(blockIdx.x) * kRowsPerBlock + threadIdx.x / kRowLanes;
-  const bool row_ok = r < num_spins;
-  const int64_t begin = row_ok ? offsets[r] : 0;
-  const int64_t end = row_ok ? offsets[r + 1] : 0;
-  const bool has_tails = *tail_flag != 0;
-  uint32_t hits = 0;
-  // The 32 needles a half-wavefront resolves per trip are 2 KiB of CONTIGUOUS memory (AoS
-  // keys of one row).  Each lane fetches four 16-byte chunks of that run (fully coalesced,
-  // 512 contiguous bytes per half and instruction) into LDS and then reads its own key
-  // back transposed, instead of eight loads per lane at a 64-byte stride.
-  __shared__ uint4 stage[kThreads * 4];
-  uint4 *mine = stage + (threadIdx.x / kRowLanes) * (kRowLanes * 4);
-  // both halves of the wavefront iterate until the longer row is done, so the ballot is
-  // always executed by all 64 lanes
-  const int64_t other_len = __shfl_xor(end - begin, 32, 64);
-  const int64_t trips = ((end - begin > other_len ? end - begin : other_len) + kRowLanes - 1) / kRowLanes;
-  for (int64_t it = 0; it < trips; ++it) {
-    const int64_t run = begin + it * kRowLanes;
-    const int64_t valid = end - run;  // needles of this trip that exist (may be <= 0)
-    const uint4 *src = reinterpret_cast<const uint4 *>(needles + run);
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint64_t chunk_first = static_cast<uint64_t>(blockIdx.x) * kChunk;
+  // The 64 needles of a trip are 4 KiB of CONTIGUOUS memory (AoS keys).  Each lane fetches four
+  // 16-byte pieces of that run (fully coalesced, 1 KiB per instruction), the wavefront passes them
+  // through LDS and every lane reads its own key back — instead of eight loads per lane at a
+  // 64-byte stride.  In LDS a key takes FIVE 16-byte places (80 bytes): at a stride of 64 bytes
+  // every second lane of a read-back hits the same four banks (a 32-way conflict: the read-backs of
+  // the 28 wavefronts of a compute unit alone were ~70 us of LDS time, round 4's first flat search),
+  // at 80 the eight lanes of a pass cover the banks once.
+  uint4 *mine = stage + wave * kStagePlaces;
+  const u32x4 *src = reinterpret_cast<const u32x4 *>(needles);
+  const uint64_t last_piece = num_needles * 4u - 1u;  // (num_needles > 0: the launch is skipped otherwise)
+  // loads of trip k: unconditional, on clamped addresses (a group past the end re-reads the last
+  // piece: under a branch hipcc would wait for every load where it is issued)
+  // Trip k of workgroup c is the chunk's group slice (k + c) mod kTrips: the workgroups of a launch
+  // run in step, and with every one of them at the SAME offset inside its 128 KiB chunk the requests
+  // in flight at any moment are 128 KiB apart — a few of the memory channels at a time.
+  const uint32_t rotate = blockIdx.x;
+  uint4 buf[4];
+  auto request = [&](uint32_t k) {
+    const uint32_t slice = (k + rotate) % kTrips;
+    const uint64_t piece0 = (chunk_first + static_cast<uint64_t>(slice * kSearchWaves + wave) * kGroup) * 4u + lane;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const uint32_t chunk = i * kRowLanes + sub;  // 4 chunks per key
-      if (static_cast<int64_t>(chunk >> 2) < valid) mine[chunk] = src[chunk];
+      const uint64_t piece = piece0 + static_cast<uint64_t>(i) * kGroup;
+      const u32x4 v = __builtin_nontemporal_load(src + (piece < last_piece ? piece : last_piece));
+      buf[i] = uint4{v.x, v.y, v.z, v.w};
+    }
+  };
+  uint32_t hits = 0;  // of this wavefront's groups (wave-uniform)
+  request(0);
+#pragma unroll 1
+  for (uint32_t k = 0; k < kTrips; ++k) {
+    const uint64_t group = static_cast<uint64_t>(blockIdx.x) * kGroupsPerChunk +
+                           ((k + rotate) % kTrips) * kSearchWaves + wave;
+    const uint64_t first = group * kGroup;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t piece = i * kGroup + lane;  // piece & 3 of key piece >> 2
+      mine[piece + (piece >> 2)] = buf[i];
     }
     __builtin_amdgcn_wave_barrier();  // same wavefront: LDS ops are in order, keep them so
-    const int64_t e = run + sub;
-    const bool active = e < end;
-    int32_t idx = -1;
-    if (active) {
-      uint64_t key[8];
+    uint64_t key[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint4 q = mine[sub * 4 + j];
-        key[2 * j] = (static_cast<uint64_t>(q.y) << 32) | q.x;
-        key[2 * j + 1] = (static_cast<uint64_t>(q.w) << 32) | q.z;
-      }
-      idx = find_key(slots, mask, table0, table, has_tails, key);
+    for (int j = 0; j < 4; ++j) {
+      const uint4 q = mine[lane * 5 + j];
+      key[2 * j] = (static_cast<uint64_t>(q.y) << 32) | q.x;
+      key[2 * j + 1] = (static_cast<uint64_t>(q.w) << 32) | q.z;
+    }
+    __builtin_amdgcn_wave_barrier();  // the next trip overwrites the staging area
+    // The registers are free: the next trip's needles are requested BEFORE this trip's probe and
+    // arrive with it — one round trip to HBM per trip carries both; the verifying load that
+    // follows hits the L2 (a bucket is a whole chain in all but ~1 % of the look-ups).
+    if (k + 1u < kTrips) request(k + 1u);
+    if (first >= num_needles) continue;  // (wave-uniform) nothing of this group exists
+    const uint64_t e = first + lane;
+    int32_t idx = -1;
+    if (e < num_needles) {
+      uint64_t needle_tail = 0;
+#pragma unroll
+      for (int w = 1; w < 8; ++w) needle_tail |= key[w];
+      idx = find_key<HAS_TAILS>(slots, bucket_mask, key[0], needle_tail == 0, [&](uint32_t at) {
+        if (table0[at] != key[0]) return false;
+        if (!HAS_TAILS) return true;
+        uint64_t diff = 0;
+#pragma unroll
+        for (int w = 1; w < 8; ++w) diff |= table[at].words[w] ^ key[w];
+        return diff == 0;
+      });
       found[e] = idx;
     }
-    hits += __popc(half_ballot(idx >= 0, lane));
-    __builtin_amdgcn_wave_barrier();  // the next trip overwrites the staging area
+    const uint32_t h = static_cast<uint32_t>(__popcll(__ballot(idx >= 0)));
+    if (lane == 0) group_hits[group] = h;
+    hits += h;
   }
-  if (row_ok && sub == 0) row_hits[r] = hits;
-  // hits of the block's rows: to the block's total and to the total of its tile of 64 blocks
-  __shared__ uint32_t hits_of_row[kRowsPerBlock];
-  if (sub == 0) hits_of_row[threadIdx.x / kRowLanes] = row_ok ? hits : 0u;
+  // hits of the chunk: to its own total and, atomically, to the total of its super-chunk
+  if (lane == 0) hits_of_wave[wave] = hits;
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t total = 0;
 #pragma unroll
-    for (int k = 0; k < kRowsPerBlock; ++k) total += hits_of_row[k];
-    block_total[blockIdx.x] = total;
-    if (total) atomicAdd(&tile_total[blockIdx.x >> 6], static_cast<unsigned long long>(total));
+    for (uint32_t k = 0; k < kSearchWaves; ++k) total += hits_of_wave[k];
+    chunk_total[blockIdx.x] = total;
+    if (total) atomicAdd(&super_total[blockIdx.x / kChunksPerSuper], static_cast<unsigned long long>(total));
   }
 }
 
+// HAS_TAILS (whether some table key has a non-zero word 1..7: the host sees the keys when it
+// uploads them) picks the instantiation, so that the common case — keys of at most 64 spins — does
+// not carry the registers of the eight-word comparison.
+template <bool HAS_TAILS>
+__global__ __launch_bounds__(kThreads) void k_search_flat(
+    const Slot *__restrict__ slots, uint64_t bucket_mask, const uint64_t *__restrict__ table0,
+    const ls_bits512 *__restrict__ table, const ls_bits512 *__restrict__ needles, uint64_t num_needles,
+    int32_t *__restrict__ found, uint32_t *__restrict__ group_hits, uint32_t *__restrict__ chunk_total,
+    unsigned long long *__restrict__ super_total) {
+  __shared__ uint4 stage[kSearchWaves * kStagePlaces];
+  __shared__ uint32_t hits_of_wave[kSearchWaves];
+  search_flat_body<HAS_TAILS>(slots, bucket_mask, table0, table, needles, num_needles, found, group_hits, chunk_total,
+                              super_total, stage, hits_of_wave);
+}
+
 struct EmitTotals {
-  const uint32_t *row_hits;                // [K]
-  const uint32_t *block_total;             // [row blocks]
-  const unsigned long long *tile_total;    // [tiles] of this run
+  const uint32_t *group_hits;              // [groups]
+  const uint32_t *chunk_total;             // [chunks]
+  const unsigned long long *super_total;   // [supers] of this run
   unsigned long long *nnz;                 // the build's number of couplings
   // left clean for the next run:
-  unsigned long long *slots;
+  Slot *slots;
   uint64_t slot_count;
-  uint32_t *tail_flag;
-  unsigned long long *next_tile_total;     // the other parity's tiles
-  uint32_t num_tiles;
+  unsigned long long *next_super_total;    // the other parity's totals
+  uint32_t num_supers;
 };
 
 __global__ __launch_bounds__(kThreads) void k_emit_rows(
@@ -203,19 +293,48 @@ __global__ __launch_bounds__(kThreads) void k_emit_rows(
   const uint32_t row_in_block = threadIdx.x / kRowLanes;
   const uint64_t r = static_cast<uint64_t>(blockIdx.x) * kRowsPerBlock + row_in_block;
   const bool row_ok = r < num_spins;
-  // ---- where this block's couplings start: tiles before its tile + blocks before it in the tile
+  const int64_t begin = row_ok ? offsets[r] : 0;
+  const int64_t end = row_ok ? offsets[r + 1] : 0;
+  const int64_t other_len = __shfl_xor(end - begin, 32, 64);
+  // both halves of the wavefront iterate until the longer row is done, so a ballot is
+  // always executed by all 64 lanes
+  const int64_t trips = ((end - begin > other_len ? end - begin : other_len) + kRowLanes - 1) / kRowLanes;
+  // ---- where this block's couplings start: the hits before the first needle of its first row
   __shared__ unsigned long long block_base;
   __shared__ uint32_t hits_of_row[kRowsPerBlock];
   if (threadIdx.x == 0) block_base = 0ull;
-  if (sub == 0) hits_of_row[row_in_block] = row_ok ? totals.row_hits[r] : 0u;
   __syncthreads();
   {
-    const uint32_t tile = blockIdx.x >> 6, first_of_tile = blockIdx.x & ~63u;
+    const uint64_t o = static_cast<uint64_t>(offsets[static_cast<uint64_t>(blockIdx.x) * kRowsPerBlock]);
+    const uint64_t g0 = o / kGroup, c0 = g0 / kGroupsPerChunk, s0 = c0 / kChunksPerSuper;
+    const uint32_t wave = threadIdx.x >> 6;
     unsigned long long mine = 0;
-    for (uint32_t t = threadIdx.x; t < tile; t += kThreads) mine += totals.tile_total[t];
-    if (threadIdx.x < blockIdx.x - first_of_tile) mine += totals.block_total[first_of_tile + threadIdx.x];
+    if (wave == 0) {
+      for (uint64_t t = lane; t < s0; t += 64) mine += totals.super_total[t];
+    } else if (wave == 1) {
+      const uint64_t c = s0 * kChunksPerSuper + lane;
+      if (c < c0) mine = totals.chunk_total[c];
+    } else if (wave == 2) {
+      const uint64_t g = c0 * kGroupsPerChunk + lane;
+      if (g < g0) mine = totals.group_hits[g];
+    } else {
+      const uint64_t e = g0 * kGroup + lane;
+      if (e < o) mine = found[e] >= 0 ? 1u : 0u;
+    }
     for (int step = 1; step < 64; step <<= 1) mine += __shfl_xor(mine, step, 64);
     if (lane == 0 && mine) atomicAdd(&block_base, mine);
+  }
+  // ---- the hits of the block's rows (the first trip's lookups stay in a register)
+  int32_t pos0 = -1;
+  {
+    uint32_t hits = 0;
+    for (int64_t it = 0; it < trips; ++it) {
+      const int64_t e = begin + it * kRowLanes + sub;
+      const int32_t pos = e < end ? found[e] : -1;
+      if (it == 0) pos0 = pos;
+      hits += __popc(half_ballot(pos >= 0, lane));
+    }
+    if (sub == 0) hits_of_row[row_in_block] = hits;
   }
   __syncthreads();
   int64_t w = static_cast<int64_t>(block_base);
@@ -225,17 +344,13 @@ __global__ __launch_bounds__(kThreads) void k_emit_rows(
     for (int k = 0; k < kRowsPerBlock; ++k) all += hits_of_row[k];
     *totals.nnz = all;
   }
-  const int64_t begin = row_ok ? offsets[r] : 0;
-  const int64_t end = row_ok ? offsets[r + 1] : 0;
   const double c = row_ok ? static_cast<double>(counts[r]) : 0.0;  // exact i64 -> f64 as in C
   const double a = row_ok ? fabs(psi[r]) : 0.0;
   double f = 0.0;
-  const int64_t other_len = __shfl_xor(end - begin, 32, 64);
-  const int64_t trips = ((end - begin > other_len ? end - begin : other_len) + kRowLanes - 1) / kRowLanes;
   for (int64_t it = 0; it < trips; ++it) {
     const int64_t e = begin + it * kRowLanes + sub;
     const bool active = e < end;
-    const int32_t pos = active ? found[e] : -1;
+    const int32_t pos = it == 0 ? pos0 : (active ? found[e] : -1);
     // ((counts * coeff) * |psi|) * x, each product rounded: build_matrix.c:41-42,49
     const double head = active ? __dmul_rn(__dmul_rn(c, coeffs[e]), a) : 0.0;
     const double x = active ? other_psi[e] : 0.0;
@@ -264,15 +379,14 @@ __global__ __launch_bounds__(kThreads) void k_emit_rows(
     }
   }
   if (row_ok && sub == 0) out_field[r] = f;
-  // ---- leave the tables clean for the next run (nobody reads the slots or the flag any more) ----
+  // ---- leave the tables clean for the next run (nobody reads the slots any more) ----
   {
     const uint64_t share = (totals.slot_count + gridDim.x - 1) / gridDim.x;
     const uint64_t first = static_cast<uint64_t>(blockIdx.x) * share;
     const uint64_t last = first + share < totals.slot_count ? first + share : totals.slot_count;
     for (uint64_t k = first + threadIdx.x; k < last; k += kThreads) totals.slots[k] = 0ull;
     if (blockIdx.x == 0) {
-      if (threadIdx.x == 0) *totals.tail_flag = 0u;
-      for (uint32_t t = threadIdx.x; t < totals.num_tiles; t += kThreads) totals.next_tile_total[t] = 0ull;
+      for (uint32_t t = threadIdx.x; t < totals.num_supers; t += kThreads) totals.next_super_total[t] = 0ull;
     }
   }
 }
@@ -304,17 +418,17 @@ struct asp_build {
   bool uploaded = false;
   DeviceBuffer<ls_bits512> table, needles;
   DeviceBuffer<uint64_t> table0;
-  DeviceBuffer<unsigned long long> slots;
-  DeviceBuffer<uint32_t> tail_flag;
+  DeviceBuffer<Slot> slots;
+  bool has_tails = false;  // some table key has a non-zero word 1..7 (seen by asp_build_upload)
   uint64_t slot_mask = 0;
   DeviceBuffer<int64_t> counts, offsets;
   DeviceBuffer<double> psi, coeffs, other_psi, elements, field;
   DeviceBuffer<int32_t> found;
-  DeviceBuffer<uint32_t> row_hits, block_total, out_row, out_col;
-  DeviceBuffer<unsigned long long> tile_total, nnz;  // tile_total: [2][num_tiles], one parity per run
-  uint32_t num_tiles = 0;
+  DeviceBuffer<uint32_t> group_hits, chunk_total, out_row, out_col;
+  DeviceBuffer<unsigned long long> super_total, nnz;  // super_total: [2][num_supers], one parity per run
+  uint32_t num_chunks = 0, num_supers = 0;
   uint32_t parity = 0;
-  bool clean = false;  // slots, flag and this parity's tile totals are zero (k_emit_rows leaves them so)
+  bool clean = false;  // slots and this parity's super totals are zero (k_emit_rows leaves them so)
 };
 
 extern "C" {
@@ -340,17 +454,18 @@ asp_build *asp_build_create(uint64_t num_spins, uint64_t num_other) {
   uint64_t slot_count = 64;
   while (slot_count < 2 * K) slot_count <<= 1;  // load factor <= 1/2
   b->slot_mask = slot_count - 1;
-  const uint64_t row_blocks = row_blocks_for(K);
-  b->num_tiles = static_cast<uint32_t>((row_blocks + 63) / 64);
+  const uint64_t num_groups = (N + kGroup - 1) / kGroup;
+  b->num_chunks = static_cast<uint32_t>((N + kChunk - 1) / kChunk);  // (N < 2^40)
+  b->num_supers = (b->num_chunks + kChunksPerSuper - 1) / kChunksPerSuper;
   ok = ok && b->table.alloc(K) == ASP_OK && b->needles.alloc(N) == ASP_OK &&
        b->table0.alloc(K) == ASP_OK && b->slots.alloc(b->slot_mask + 1) == ASP_OK &&
-       b->tail_flag.alloc(1) == ASP_OK && b->counts.alloc(K) == ASP_OK &&
+       b->counts.alloc(K) == ASP_OK &&
        b->offsets.alloc(K + 1) == ASP_OK &&
        b->psi.alloc(K) == ASP_OK && b->coeffs.alloc(N) == ASP_OK &&
        b->other_psi.alloc(N) == ASP_OK && b->elements.alloc(N) == ASP_OK &&
        b->field.alloc(K) == ASP_OK && b->found.alloc(N) == ASP_OK &&
-       b->row_hits.alloc(K) == ASP_OK && b->block_total.alloc(row_blocks) == ASP_OK &&
-       b->tile_total.alloc(2ull * b->num_tiles) == ASP_OK && b->nnz.alloc(1) == ASP_OK &&
+       b->group_hits.alloc(num_groups) == ASP_OK && b->chunk_total.alloc(b->num_chunks) == ASP_OK &&
+       b->super_total.alloc(2ull * b->num_supers) == ASP_OK && b->nnz.alloc(1) == ASP_OK &&
        b->out_row.alloc(N) == ASP_OK && b->out_col.alloc(N) == ASP_OK;
   if (!ok) {
     asp_build_destroy(b);
@@ -395,6 +510,14 @@ int asp_build_upload(asp_build *b, ls_bits512 const *spins, int64_t const *count
     return asp::set_error(ASP_ERR_INVALID, "sum(other_counts) = %llu but num_other = %llu",
                           (unsigned long long)total, (unsigned long long)N);
   }
+  // does any table key reach beyond its first word?  (the search kernel's instantiation)
+  bool tails = false;
+  for (uint64_t r = 0; r < K && !tails; ++r) {
+    uint64_t rest = 0;
+    for (int w = 1; w < 8; ++w) rest |= spins[r].words[w];
+    tails = rest != 0;
+  }
+  b->has_tails = tails;
   // offsets of the rows in the flat arrays: the prefix sums of the counts just walked
   std::vector<int64_t> offsets(K + 1);
   offsets[0] = 0;
@@ -419,23 +542,26 @@ int asp_build_run(asp_build *b, uint64_t *nnz) {
   hipStream_t s = b->stream;
   if (!b->clean) {
     // first run of the handle, or the one before it failed half-way: k_emit_rows leaves these zero
-    ASP_HIP_TRY(hipMemsetAsync(b->slots.ptr, 0, (b->slot_mask + 1) * sizeof(unsigned long long), s));
-    ASP_HIP_TRY(hipMemsetAsync(b->tail_flag.ptr, 0, sizeof(uint32_t), s));
-    ASP_HIP_TRY(hipMemsetAsync(b->tile_total.ptr, 0, 2ull * b->num_tiles * sizeof(unsigned long long), s));
+    ASP_HIP_TRY(hipMemsetAsync(b->slots.ptr, 0, (b->slot_mask + 1) * sizeof(Slot), s));
+    if (b->num_supers) {
+      ASP_HIP_TRY(hipMemsetAsync(b->super_total.ptr, 0, 2ull * b->num_supers * sizeof(unsigned long long), s));
+    }
   }
   b->clean = false;
   ASP_HIP_TRY(hipEventRecord(b->ev_start, s));
   if (K > 0) {
-    unsigned long long *tiles = b->tile_total.ptr + static_cast<size_t>(b->parity) * b->num_tiles;
-    unsigned long long *other_tiles = b->tile_total.ptr + static_cast<size_t>(b->parity ^ 1u) * b->num_tiles;
+    unsigned long long *supers = b->super_total.ptr + static_cast<size_t>(b->parity) * b->num_supers;
+    unsigned long long *other_supers = b->super_total.ptr + static_cast<size_t>(b->parity ^ 1u) * b->num_supers;
     hipLaunchKernelGGL(k_insert_keys, dim3(blocks_for(K)), dim3(kThreads), 0, s, b->table.ptr, K,
-                       b->table0.ptr, b->tail_flag.ptr, b->slots.ptr, b->slot_mask);
-    hipLaunchKernelGGL(k_search_rows, dim3(row_blocks_for(K)), dim3(kThreads), 0, s, b->slots.ptr,
-                       b->slot_mask, b->table0.ptr, b->table.ptr, b->tail_flag.ptr, K,
-                       b->needles.ptr, b->offsets.ptr, b->found.ptr, b->row_hits.ptr,
-                       b->block_total.ptr, tiles);
-    EmitTotals totals{b->row_hits.ptr, b->block_total.ptr, tiles, b->nnz.ptr, b->slots.ptr,
-                      b->slot_mask + 1, b->tail_flag.ptr, other_tiles, b->num_tiles};
+                       b->table0.ptr, b->slots.ptr, b->slot_mask / kBucket);
+    if (b->num_chunks) {  // (a build without a single connection searches nothing)
+      hipLaunchKernelGGL(b->has_tails ? k_search_flat<true> : k_search_flat<false>, dim3(b->num_chunks),
+                         dim3(kThreads), 0, s, b->slots.ptr, b->slot_mask / kBucket, b->table0.ptr, b->table.ptr,
+                         b->needles.ptr, b->num_other, b->found.ptr, b->group_hits.ptr, b->chunk_total.ptr,
+                         supers);
+    }
+    EmitTotals totals{b->group_hits.ptr, b->chunk_total.ptr, supers, b->nnz.ptr, b->slots.ptr,
+                      b->slot_mask + 1, other_supers, b->num_supers};
     hipLaunchKernelGGL(k_emit_rows, dim3(row_blocks_for(K)), dim3(kThreads), 0, s, b->offsets.ptr,
                        totals, b->found.ptr, b->counts.ptr, b->psi.ptr, b->coeffs.ptr,
                        b->other_psi.ptr, K, b->out_row.ptr, b->out_col.ptr, b->elements.ptr,
@@ -447,7 +573,7 @@ int asp_build_run(asp_build *b, uint64_t *nnz) {
   if (K > 0) ASP_HIP_TRY(hipMemcpyAsync(&total, b->nnz.ptr, sizeof total, hipMemcpyDeviceToHost, s));
   ASP_HIP_TRY(hipStreamSynchronize(s));
   ASP_HIP_TRY(hipEventElapsedTime(&b->last_ms, b->ev_start, b->ev_stop));
-  // this run's tile totals were read by its last kernel; the other parity's are zero again
+  // this run's super-chunk totals were read by its last kernel; the other parity's are zero again
   b->parity ^= 1u;
   b->clean = K > 0;
   b->last_nnz = static_cast<uint64_t>(total);

@@ -21,9 +21,10 @@ The JSON line also carries
                 2.4 GHz; beside it the measured HBM fraction, the useful-f64-FMA
                 fraction, the algorithmic bytes/s (B_flip = 12*dbar + 16) and
                 the rate with every proposal evaluated (field cache / inert skipping
-                off).  The PMC summary carries the fingerprint of the library build it was
-                measured on: when that is not the running library, `frac` is null and
-                `frac_null_reason` says so;
+                off).  Every case of the PMC summary carries the fingerprint of the sources
+                its kernel is built from (kernel file, plan builder, headers, flags) as
+                measured: a case whose sources have changed since is dropped — its `frac`
+                is null and `frac_null_reason` / `stale_counter_cases` say so;
   shuffled_order  the same clusters, chains and sweeps with the reference annealer's
                 visiting order (a fresh random permutation every sweep,
                 asp_sa_anneal_shuffled), and the reference's default call (64 chains x
@@ -85,29 +86,48 @@ def _load_profile(name):
         return None
 
 
-def profiled_counters(built_fingerprint):
+def case_source_set(case):
+    """The kernel-source set (build.KERNEL_SOURCE_SETS) a profiled case depends on."""
+    return "shuffled" if "shuffled" in case else "colour"
+
+
+def profiled_counters(built_sets):
     """``(counters, traffic, reason)``: the committed rocprofv3 summaries
-    (profiles/sweep_counters.json, profiles/traffic.json; tools/gpu_profile_r3.sh) — but only
-    when they were taken from THIS library build.  Both files carry the fingerprint of the
-    sources and flags of the libasp_hip.so they were measured on (build.py); when it differs
-    from the one of the library that is running, the counters say nothing about this binary,
-    ``counters`` and ``traffic`` are None and ``reason`` says why, and every ``frac`` of the bench
-    line is null instead of a number carried over from another kernel."""
+    (profiles/sweep_counters.json, profiles/traffic.json; tools/gpu_profile_r4.sh) — but only the
+    cases that were taken from THIS code.  Every case carries the fingerprint of the sources its
+    kernel is built from (build.KERNEL_SOURCE_SETS: the kernel's file, the plan builder, their
+    headers and the compiler flags) as it was when the case was measured; ``built_sets`` are the
+    fingerprints recorded when the running library was built.  A case whose fingerprint differs
+    says nothing about this binary and is dropped — its ``frac`` in the bench line is null instead
+    of a number carried over from another kernel — and ``reason`` names what was dropped."""
     counters, traffic = _load_profile("sweep_counters.json"), _load_profile("traffic.json")
     if counters is None:
         return None, None, "profiles/sweep_counters.json missing or unreadable"
-    have = counters.get("library_fingerprint")
-    if not have:
-        return None, None, "profiles/sweep_counters.json carries no library fingerprint"
-    if not built_fingerprint:
+    if not built_sets:
         return None, None, "the running library has no build stamp to compare the counters with"
-    if have != built_fingerprint:
-        return None, None, ("stale counters: profiles/sweep_counters.json was measured on library build "
-                            "%s..., the running library is build %s... (re-run tools/gpu_profile_r3.sh)"
-                            % (have[:12], built_fingerprint[:12]))
-    if traffic is not None and traffic.get("library_fingerprint") != built_fingerprint:
-        traffic = None
-    return counters, traffic, None
+
+    def current(doc):
+        kept, dropped = {}, []
+        for case, entry in doc.get("cases", {}).items():
+            name = entry.get("kernel_source_set") or case_source_set(case)
+            have = entry.get("source_set_fingerprint")
+            if have and have == built_sets.get(name):
+                kept[case] = entry
+            else:
+                dropped.append(case)
+        return kept, dropped
+
+    kept, dropped = current(counters)
+    reason = None
+    if dropped:
+        reason = ("stale counters dropped (their kernel's sources changed since they were measured; re-run "
+                  "tools/gpu_profile_r4.sh for them): " + ", ".join(sorted(dropped)))
+    if not kept:
+        return None, None, reason
+    counters = dict(counters, cases=kept)
+    if traffic is not None:
+        traffic = dict(traffic, cases=current(traffic)[0])
+    return counters, traffic, reason
 
 
 def issue_fraction(case, counters, flips_per_s):
@@ -784,7 +804,7 @@ def main():
         kernel_flips = flips_per_step * args.steps / kernel_s
         from annealing_sign_problem_amd import build as asp_build
 
-        counters, traffic, stale = profiled_counters(asp_build.built_fingerprint())
+        counters, traffic, stale = profiled_counters(asp_build.built_source_set_fingerprints())
         # every proposal evaluated: field cache and inert-block skipping off (results identical).
         # Left out under --no-build, the form the rocprofv3 passes use, so that their per-launch
         # averages cover the timed workload only.
@@ -845,7 +865,10 @@ def main():
             "unit": "G SIMD issue cycles/s",
             "frac": issue / peak_issue if issue is not None else None,
             "frac_null_reason": stale if issue is None else None,
-            "counters_library_fingerprint": counters.get("library_fingerprint") if counters else None,
+            "stale_counter_cases": stale if issue is not None else None,
+            "counters_source_fingerprints": ({case: entry.get("source_set_fingerprint")
+                                             for case, entry in counters["cases"].items()} if counters else None),
+            "running_source_fingerprints": asp_build.built_source_set_fingerprints(),
             "running_library_fingerprint": asp_build.built_fingerprint(),
             "traffic": hbm_per_launch,
             "per_cluster_size": per_size,

@@ -64,7 +64,10 @@ def test_build_matrix_raw_cffi_style_call():
 
 @pytest.mark.parametrize("seed,n,mean,multi,miss", [
     (1, 1, 3.0, False, 0.5), (2, 65, 0.5, False, 0.0), (3, 3000, 30.0, False, 0.5),
-    (4, 500, 12.0, True, 0.3), (5, 4097, 2.0, False, 0.9)])
+    (4, 500, 12.0, True, 0.3), (5, 4097, 2.0, False, 0.9),
+    # the flat search counts hits per 64 / 2048 / 131072 connections: several super-chunks, multi-word
+    # keys; and rows far longer than the 32 lanes that emit them
+    (6, 12000, 30.0, True, 0.4), (7, 300, 1000.0, False, 0.5)])
 def test_build_matrix_matches_oracle_random(seed, n, mean, multi, miss):
     from annealing_sign_problem_amd import _build_matrix
 
@@ -82,9 +85,9 @@ def test_build_matrix_matches_oracle_random(seed, n, mean, multi, miss):
 
 def test_build_handle_is_reusable_run_after_run():
     """The device-resident form (asp_build_create / upload / run / download: what bench.py times):
-    one build is three launches and leaves its hash slots, flag and tile totals clean for the next
+    one build is three launches and leaves its hash slots, flag and super-chunk totals clean for the next
     one — three runs on one upload, then other data of the same shape through the same handle,
-    are each the oracle's result (sizes that span several tiles of row blocks)."""
+    are each the oracle's result (sizes that span several chunks of the flat search)."""
     import ctypes
 
     from annealing_sign_problem_amd import _build_matrix, _lib

@@ -428,30 +428,61 @@ def test_hamiltonian_arrays_are_frozen_against_stale_plans():
     assert ham.exchange.tocoo().nnz == ham.exchange.nnz and ham.exchange[:5][:, :5].shape == (5, 5)
 
 
-def test_bench_roofline_refuses_counters_of_another_library_build(tmp_path, monkeypatch):
+def test_bench_roofline_refuses_counters_of_other_kernel_sources(tmp_path, monkeypatch):
     """bench.py multiplied the live rate by constants from a committed JSON, so a
-    changed kernel with a forgotten PMC pass still printed the old fraction.  The JSON now names
-    the library build it was measured on; any other running build gets no fraction but a reason."""
+    changed kernel with a forgotten PMC pass still printed the old fraction.  Every case of the JSON
+    now names the sources its kernel was built from when it was measured (kernel file, plan builder,
+    headers, flags: build.KERNEL_SOURCE_SETS); a case measured on other sources gets no fraction
+    but a reason, while the cases of an untouched kernel file stay."""
     import json
 
     import bench
 
     profiles = tmp_path / "profiles"
     profiles.mkdir()
-    counters = {"library_fingerprint": "a" * 64, "cycles_per_valu_inst": 4.35,
-                "cases": {"colour_10000": {"valu_insts_per_flip": 1.5}}}
+    counters = {"cycles_per_valu_inst": 4.35,
+                "cases": {"colour_10000": {"valu_insts_per_flip": 1.5, "kernel_source_set": "colour",
+                                           "source_set_fingerprint": "a" * 64},
+                          "shuffled_10000": {"valu_insts_per_flip": 4.0, "kernel_source_set": "shuffled",
+                                             "source_set_fingerprint": "b" * 64}}}
     (profiles / "sweep_counters.json").write_text(json.dumps(counters))
-    (profiles / "traffic.json").write_text(json.dumps({"library_fingerprint": "b" * 64, "cases": {}}))
+    (profiles / "traffic.json").write_text(json.dumps({"cases": {
+        "colour_10000": {"hbm_bytes_per_flip": 4.5, "source_set_fingerprint": "0" * 64}}}))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    got, traffic, reason = bench.profiled_counters("a" * 64)
+    got, traffic, reason = bench.profiled_counters({"colour": "a" * 64, "shuffled": "b" * 64})
     assert got == counters and reason is None
-    assert traffic is None  # measured on yet another build: dropped on its own
+    assert traffic == {"cases": {}}  # measured on yet other sources: dropped on its own
     frac = bench.issue_fraction("colour_10000", got, 200e9)
     assert abs(frac - 1.5 * 4.35 * 200 / (1024 * 2.4)) < 1e-12
     assert bench.issue_fraction("colour_30000", got, 200e9) is None  # a case that was not profiled
-    stale, traffic, reason = bench.profiled_counters("c" * 64)
-    assert stale is None and traffic is None and "stale" in reason and "aaaaaaaaaaaa" in reason
+    # sa_shuffled.hip changed: the shuffled case goes, the colour case stays
+    got, _, reason = bench.profiled_counters({"colour": "a" * 64, "shuffled": "c" * 64})
+    assert sorted(got["cases"]) == ["colour_10000"] and "stale" in reason and "shuffled_10000" in reason
+    assert bench.issue_fraction("shuffled_10000", got, 200e9) is None
+    stale, traffic, reason = bench.profiled_counters({"colour": "c" * 64, "shuffled": "c" * 64})
+    assert stale is None and traffic is None and "stale" in reason and "colour_10000" in reason
     assert bench.issue_fraction("colour_10000", stale, 200e9) is None
     assert bench.profiled_counters(None)[2] is not None  # no build stamp: no fraction either
-    (profiles / "sweep_counters.json").write_text(json.dumps({"cases": {}}))  # a summary without fingerprint
-    assert bench.profiled_counters("a" * 64)[0] is None
+    (profiles / "sweep_counters.json").write_text(json.dumps({"cases": {"colour_10000": {}}}))  # no fingerprint
+    assert bench.profiled_counters({"colour": "a" * 64, "shuffled": "b" * 64})[0] is None
+
+
+def test_build_records_the_fingerprints_of_the_kernel_source_sets():
+    """The stamp beside the library names what its sweep kernels were built from; it follows the
+    sources (a change to another kernel file leaves both sets alone)."""
+    from annealing_sign_problem_amd import build
+
+    now = build.source_set_fingerprints()
+    assert sorted(now) == ["colour", "shuffled"] and now["colour"] != now["shuffled"]
+    built = build.built_source_set_fingerprints()
+    if build.built_fingerprint() == build.fingerprint():  # (the library on disk is of these sources)
+        assert built == now
+    # the committed counters: every case names its set, and a fingerprint if it has one is 64 hex digits
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                           "sweep_counters.json")) as f:
+        for case, entry in json.load(f)["cases"].items():
+            assert entry["kernel_source_set"] == ("shuffled" if "shuffled" in case else "colour")
+            assert entry["source_set_fingerprint"] is None or len(entry["source_set_fingerprint"]) == 64

@@ -37,8 +37,12 @@ def main():
     a = p.parse_args()
     lib = _lib.load()
     kind, _, arg = a.case.partition("_")
-    record = {"case": a.case, "library_fingerprint": build.built_fingerprint(), "chains": a.chains,
-              "sweeps": a.sweeps, "runs": a.runs}
+    # (what the case's kernel is built from: bench.py keeps a case while that is unchanged)
+    source_set = "shuffled" if "shuffled" in a.case else "colour"
+    record = {"case": a.case, "library_fingerprint": build.built_fingerprint(),
+              "kernel_source_set": source_set,
+              "source_set_fingerprint": (build.built_source_set_fingerprints() or {}).get(source_set),
+              "chains": a.chains, "sweeps": a.sweeps, "runs": a.runs}
     flips, sweep_ms = 0, []
     if kind in ("colour", "shuffled", "shuffled64"):
         k = int(arg)

@@ -7,9 +7,11 @@ for the counter sets `sq` (instruction counts, busy cycles, GRBM_GUI_ACTIVE), `l
 (SQ_THREAD_CYCLES_VALU over SQ_ACTIVE_INST_VALU: lanes with exec = 1 per VALU instruction), `fetch`
 (FETCH_SIZE) and `l2` (WRITE_SIZE, TCC hits / misses), and calib/ for tools/fetch_calibrate.hip.
 
-Both files carry the fingerprint of the library the counters were taken from
-(annealing_sign_problem_amd/build.py); bench.py refuses to compute a fraction from counters of
-another binary.
+Every case carries the fingerprint of the sources its kernel is built from
+(annealing_sign_problem_amd/build.py: KERNEL_SOURCE_SETS) as it was when the case was profiled;
+bench.py refuses to compute a fraction from counters of other code.  Cases that are NOT under
+<prof_dir> are carried over from the committed files as they are (with the fingerprints they were
+measured on): a change to sa_shuffled.hip needs the shuffled cases re-profiled, not all twelve.
 """
 import collections
 import csv
@@ -64,7 +66,10 @@ for path in sorted(glob.glob(os.path.join(prof, "cases", "*.json"))):
     case = rec["case"]
     fingerprints.add(rec.get("library_fingerprint"))
     flips = float(rec["flips"])
-    entry = {"kernel": rec["kernel"], "flips_profiled": flips}
+    entry = {"kernel": rec["kernel"], "flips_profiled": flips,
+             "kernel_source_set": rec.get("kernel_source_set"),
+             "source_set_fingerprint": rec.get("source_set_fingerprint"),
+             "library_fingerprint": rec.get("library_fingerprint"), "tag": tag}
     for key in ("K", "dbar", "chains", "sweeps", "problems"):
         if key in rec:
             entry[key] = rec[key]
@@ -116,10 +121,17 @@ for path in sorted(glob.glob(os.path.join(prof, "cases", "*.json"))):
 if len(fingerprints) != 1 or None in fingerprints:
     raise SystemExit("the cases were not all profiled on one library build: %r" % fingerprints)
 fingerprint = fingerprints.pop()
+# cases not re-profiled this time: carried over from the committed summary, fingerprints and all
+try:
+    previous = json.load(open(os.path.join(out_dir, "%s_roofline_summary.json" % tag)))["cases"]
+except (OSError, ValueError, KeyError):
+    previous = {}
+for case, entry in previous.items():
+    cases.setdefault(case, entry)
 probe = "profiles/r02_issue_rate_probe.txt"
 common = {
     "tag": tag,
-    "library_fingerprint": fingerprint,
+    "library_fingerprint": fingerprint,  # of the newest cases; every case names its own
     "cycles_per_valu_inst": 4.35,
     "cycles_per_valu_inst_source": probe + ": 4.2-4.4 SIMD cycles per wave64 instruction for every class "
                                    "the kernels' hot phases issue at 3-4 waves per SIMD (f64 FMA/add, VOP3 "
