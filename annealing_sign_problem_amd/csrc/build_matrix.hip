@@ -50,6 +50,13 @@ namespace {
 
 using asp::DeviceBuffer;
 
+// Timing-only ablations of k_search_flat (results are WRONG when set; never set in the product
+// build): 1 no probe, 2 probe without the verifying load, 3 every trip re-reads the chunk's first
+// 4 KiB (no HBM stream)
+#ifndef ASP_BUILD_ABL
+#define ASP_BUILD_ABL 0
+#endif
+
 constexpr int kThreads = 256;
 constexpr int kRowLanes = 32;                         // lanes cooperating on one row (k_emit_rows)
 constexpr int kRowsPerBlock = kThreads / kRowLanes;   // 8
@@ -79,6 +86,9 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
   return x;
 }
 
+// Blocked hashing: a key lives in its home bucket (eight slots, 64 bytes) unless that is full,
+// then in the next bucket that is not.  A look-up therefore reads whole buckets: a match is
+// wherever it is in the bucket, and a bucket with an empty slot ends the chain.
 __global__ __launch_bounds__(kThreads) void k_insert_keys(const ls_bits512 *__restrict__ table,
                                                          uint64_t n, uint64_t *__restrict__ table0,
                                                          Slot *__restrict__ slots, uint64_t bucket_mask) {
@@ -86,22 +96,25 @@ __global__ __launch_bounds__(kThreads) void k_insert_keys(const ls_bits512 *__re
   if (i >= n) return;
   const uint64_t word0 = table[i].words[0];
   table0[i] = word0;
-  // linear probing over the slots, STARTING at the first slot of the key's bucket: a look-up reads
-  // whole buckets and stops at the first empty slot
-  const uint64_t slot_mask = bucket_mask * kBucket + (kBucket - 1);
   const uint64_t h = mix64(word0);
   const Slot entry = (h & 0xFFFFFFFF00000000ull) | (i + 1);
-  uint64_t at = (h & bucket_mask) * kBucket;
-  while (atomicCAS(&slots[at], 0ull, entry) != 0ull) at = (at + 1) & slot_mask;
+  // (the keys of a bucket start at different slots of it: fewer of them fight over one slot)
+  const uint32_t first = static_cast<uint32_t>(h >> 29) & (kBucket - 1);
+  for (uint64_t b = h & bucket_mask;; b = (b + 1) & bucket_mask) {
+    for (uint32_t t = 0; t < kBucket; ++t) {
+      if (atomicCAS(&slots[b * kBucket + ((first + t) & (kBucket - 1))], 0ull, entry) == 0ull) return;
+    }
+  }
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// The eight slots of bucket `b` — 64 bytes — in four 16-byte loads AS WRITTEN (left to itself
-// hipcc loads slot after slot, each behind the test of the one before: a dependent round trip per
-// slot; a volatile access becomes a system-scope load past the L2).  vmcnt counts in order, so
-// waiting for these loads is waiting for every older one too — the asm's wait costs what the
-// compiler's would; nothing of the asm is outstanding when the compiler's own waits run.
+// Loads AS WRITTEN (left to itself hipcc loads slot after slot, each behind the test of the one
+// before: a dependent round trip per slot; a volatile access becomes a system-scope load past the
+// L2).  vmcnt counts in order, so waiting for these loads is waiting for every older one too — the
+// asm's wait costs what the compiler's would; nothing of the asm is outstanding when the
+// compiler's own waits run.
+// The eight slots of bucket `b` — 64 bytes — in four 16-byte loads:
 __device__ __forceinline__ void load_bucket(const Slot *bucket, u32x4 (&s)[kBucket / 2]) {
   static_assert(kBucket == 8, "four loads spelled out");
   asm volatile(
@@ -115,15 +128,12 @@ __device__ __forceinline__ void load_bucket(const Slot *bucket, u32x4 (&s)[kBuck
       : "memory");
 }
 
-// Index in the table of the needle with first word n0, or -1.  `verify(index)`: the needle IS
-// table[index] (its first word against table0, and — HAS_TAILS — the words 1..7,
-// cbits/build_matrix.c:11-18).  HAS_TAILS = false: no table key has a non-zero word 1..7, so a
-// needle with one (`tail_zero` false) is a miss without a probe.
-template <bool HAS_TAILS, typename Verify>
-__device__ __forceinline__ int32_t find_key(const Slot *__restrict__ slots, uint64_t bucket_mask, uint64_t n0,
-                                            bool tail_zero, Verify verify) {
-  if (!HAS_TAILS && !tail_zero) return -1;
-  const uint64_t h = mix64(n0);
+// Index in the table of the needle with hash h, or -1 (`verify(index)`: the needle IS
+// table[index]): a lane reads the needle's home bucket whole — the chain ends there in all but
+// ~1 % of the look-ups — and moves on only from a full bucket.
+template <typename Verify>
+__device__ __forceinline__ int32_t find_key(const Slot *__restrict__ slots, uint64_t bucket_mask, uint64_t h,
+                                            Verify verify) {
   const uint32_t fingerprint = static_cast<uint32_t>(h >> 32);
   for (uint64_t b = h & bucket_mask;; b = (b + 1) & bucket_mask) {
     u32x4 s[kBucket / 2];
@@ -134,10 +144,8 @@ __device__ __forceinline__ int32_t find_key(const Slot *__restrict__ slots, uint
       empty |= (s[j].x == 0u ? 1u : 0u) << (2 * j) | (s[j].z == 0u ? 1u : 0u) << (2 * j + 1);
       match |= (s[j].y == fingerprint ? 1u : 0u) << (2 * j) | (s[j].w == fingerprint ? 1u : 0u) << (2 * j + 1);
     }
-    // the chain of this needle ends at the first empty slot: candidates are the matches before it
-    // (an occupied slot has index + 1 != 0 whatever its fingerprint)
-    match &= (empty & (0u - empty)) - 1u;
-    while (match) {  // in slot order, as a slot-by-slot probe would; one candidate in all but 2^-32 of the cases
+    match &= ~empty;  // (an empty slot is all zeros, and zero is a fingerprint like any other)
+    while (match) {  // one candidate in all but 2^-32 of the cases (keys that share their first word aside)
       const uint32_t j = static_cast<uint32_t>(__ffs(match) - 1);
       uint32_t index1 = 0;
 #pragma unroll
@@ -171,22 +179,16 @@ __device__ __forceinline__ void search_flat_body(
   // The 64 needles of a trip are 4 KiB of CONTIGUOUS memory (AoS keys).  Each lane fetches four
   // 16-byte pieces of that run (fully coalesced, 1 KiB per instruction), the wavefront passes them
   // through LDS and every lane reads its own key back — instead of eight loads per lane at a
-  // 64-byte stride.  In LDS a key takes FIVE 16-byte places (80 bytes): at a stride of 64 bytes
-  // every second lane of a read-back hits the same four banks (a 32-way conflict: the read-backs of
-  // the 28 wavefronts of a compute unit alone were ~70 us of LDS time, round 4's first flat search),
-  // at 80 the eight lanes of a pass cover the banks once.
+  // 64-byte stride.  (In LDS a key takes FIVE 16-byte places, 80 bytes: the eight lanes of a pass of
+  // the read-back then cover the banks once; at 64 every second lane shares four banks.)
   uint4 *mine = stage + wave * kStagePlaces;
   const u32x4 *src = reinterpret_cast<const u32x4 *>(needles);
   const uint64_t last_piece = num_needles * 4u - 1u;  // (num_needles > 0: the launch is skipped otherwise)
   // loads of trip k: unconditional, on clamped addresses (a group past the end re-reads the last
   // piece: under a branch hipcc would wait for every load where it is issued)
-  // Trip k of workgroup c is the chunk's group slice (k + c) mod kTrips: the workgroups of a launch
-  // run in step, and with every one of them at the SAME offset inside its 128 KiB chunk the requests
-  // in flight at any moment are 128 KiB apart — a few of the memory channels at a time.
-  const uint32_t rotate = blockIdx.x;
   uint4 buf[4];
   auto request = [&](uint32_t k) {
-    const uint32_t slice = (k + rotate) % kTrips;
+    const uint32_t slice = ASP_BUILD_ABL == 3 ? 0u : k;
     const uint64_t piece0 = (chunk_first + static_cast<uint64_t>(slice * kSearchWaves + wave) * kGroup) * 4u + lane;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -199,8 +201,7 @@ __device__ __forceinline__ void search_flat_body(
   request(0);
 #pragma unroll 1
   for (uint32_t k = 0; k < kTrips; ++k) {
-    const uint64_t group = static_cast<uint64_t>(blockIdx.x) * kGroupsPerChunk +
-                           ((k + rotate) % kTrips) * kSearchWaves + wave;
+    const uint64_t group = static_cast<uint64_t>(blockIdx.x) * kGroupsPerChunk + k * kSearchWaves + wave;
     const uint64_t first = group * kGroup;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -218,28 +219,35 @@ __device__ __forceinline__ void search_flat_body(
     __builtin_amdgcn_wave_barrier();  // the next trip overwrites the staging area
     // The registers are free: the next trip's needles are requested BEFORE this trip's probe and
     // arrive with it — one round trip to HBM per trip carries both; the verifying load that
-    // follows hits the L2 (a bucket is a whole chain in all but ~1 % of the look-ups).
+    // follows hits the L2.
     if (k + 1u < kTrips) request(k + 1u);
     if (first >= num_needles) continue;  // (wave-uniform) nothing of this group exists
     const uint64_t e = first + lane;
+    uint64_t needle_tail = 0;
+#pragma unroll
+    for (int w = 1; w < 8; ++w) needle_tail |= key[w];
+    // HAS_TAILS = false: no table key has a non-zero word 1..7, so a needle with one is a miss
+    // without a probe
+    const bool wanted = e < num_needles && (HAS_TAILS || needle_tail == 0);
+    const uint64_t h = mix64(key[0]);
+    auto verify = [&](uint32_t at) {
+      if (ASP_BUILD_ABL == 2) return true;
+      if (table0[at] != key[0]) return false;  // (an L2 hit: 8 K bytes in all)
+      if (!HAS_TAILS) return true;
+      // word 0 matches: the full 512-bit keys must agree (cbits/build_matrix.c:11-18)
+      uint64_t diff = 0;
+#pragma unroll
+      for (int w = 1; w < 8; ++w) diff |= table[at].words[w] ^ key[w];
+      return diff == 0;
+    };
+    // (tried: four lanes per bucket, 16 bytes each, the hash by shuffle and the verdict through LDS —
+    // a quarter of the lines per load instruction, and slower: 100 against 71 us)
     int32_t idx = -1;
-    if (e < num_needles) {
-      uint64_t needle_tail = 0;
-#pragma unroll
-      for (int w = 1; w < 8; ++w) needle_tail |= key[w];
-      idx = find_key<HAS_TAILS>(slots, bucket_mask, key[0], needle_tail == 0, [&](uint32_t at) {
-        if (table0[at] != key[0]) return false;
-        if (!HAS_TAILS) return true;
-        uint64_t diff = 0;
-#pragma unroll
-        for (int w = 1; w < 8; ++w) diff |= table[at].words[w] ^ key[w];
-        return diff == 0;
-      });
-      found[e] = idx;
-    }
-    const uint32_t h = static_cast<uint32_t>(__popcll(__ballot(idx >= 0)));
-    if (lane == 0) group_hits[group] = h;
-    hits += h;
+    if (ASP_BUILD_ABL != 1 && wanted) idx = find_key(slots, bucket_mask, h, verify);
+    if (e < num_needles) found[e] = idx;
+    const uint32_t hcount = static_cast<uint32_t>(__popcll(__ballot(idx >= 0)));
+    if (lane == 0) group_hits[group] = hcount;
+    hits += hcount;
   }
   // hits of the chunk: to its own total and, atomically, to the total of its super-chunk
   if (lane == 0) hits_of_wave[wave] = hits;
