@@ -301,27 +301,38 @@ __global__ __launch_bounds__(kThreads) void k_emit_rows(
   const uint32_t row_in_block = threadIdx.x / kRowLanes;
   const uint64_t r = static_cast<uint64_t>(blockIdx.x) * kRowsPerBlock + row_in_block;
   const bool row_ok = r < num_spins;
+  // Everything a row needs is requested in TWO rounds of loads, then one barrier: (1) the row's
+  // bounds, its count and amplitude, and the first needle of the block; (2) what the bounds point
+  // at — the first 32 connections of the row (look-up result, coefficient, amplitude: kept in
+  // registers for the emission below) and this wavefront's share of the hit totals before the
+  // block.  (Until round 4's last build the block position, the rows' hits and the emission were
+  // three phases with a barrier and a round trip each: 45 us at K = 1e5.)
   const int64_t begin = row_ok ? offsets[r] : 0;
   const int64_t end = row_ok ? offsets[r + 1] : 0;
+  const uint64_t o = static_cast<uint64_t>(offsets[static_cast<uint64_t>(blockIdx.x) * kRowsPerBlock]);
+  const double c = row_ok ? static_cast<double>(counts[r]) : 0.0;  // exact i64 -> f64 as in C
+  const double a = row_ok ? fabs(psi[r]) : 0.0;
   const int64_t other_len = __shfl_xor(end - begin, 32, 64);
   // both halves of the wavefront iterate until the longer row is done, so a ballot is
   // always executed by all 64 lanes
   const int64_t trips = ((end - begin > other_len ? end - begin : other_len) + kRowLanes - 1) / kRowLanes;
-  // ---- where this block's couplings start: the hits before the first needle of its first row
-  __shared__ unsigned long long block_base;
+  __shared__ unsigned long long base_part[kThreads / 64];
   __shared__ uint32_t hits_of_row[kRowsPerBlock];
-  if (threadIdx.x == 0) block_base = 0ull;
-  __syncthreads();
+  const int64_t e0 = begin + sub;
+  const bool active0 = e0 < end;
+  const int32_t pos0 = active0 ? found[e0] : -1;
+  const double coeff0 = active0 ? coeffs[e0] : 0.0;
+  const double x0 = active0 ? other_psi[e0] : 0.0;
   {
-    const uint64_t o = static_cast<uint64_t>(offsets[static_cast<uint64_t>(blockIdx.x) * kRowsPerBlock]);
+    // ---- where this block's couplings start: the hits before the first needle of its first row
     const uint64_t g0 = o / kGroup, c0 = g0 / kGroupsPerChunk, s0 = c0 / kChunksPerSuper;
     const uint32_t wave = threadIdx.x >> 6;
     unsigned long long mine = 0;
     if (wave == 0) {
       for (uint64_t t = lane; t < s0; t += 64) mine += totals.super_total[t];
     } else if (wave == 1) {
-      const uint64_t c = s0 * kChunksPerSuper + lane;
-      if (c < c0) mine = totals.chunk_total[c];
+      const uint64_t ch = s0 * kChunksPerSuper + lane;
+      if (ch < c0) mine = totals.chunk_total[ch];
     } else if (wave == 2) {
       const uint64_t g = c0 * kGroupsPerChunk + lane;
       if (g < g0) mine = totals.group_hits[g];
@@ -330,21 +341,22 @@ __global__ __launch_bounds__(kThreads) void k_emit_rows(
       if (e < o) mine = found[e] >= 0 ? 1u : 0u;
     }
     for (int step = 1; step < 64; step <<= 1) mine += __shfl_xor(mine, step, 64);
-    if (lane == 0 && mine) atomicAdd(&block_base, mine);
+    if (lane == 0) base_part[wave] = mine;
   }
-  // ---- the hits of the block's rows (the first trip's lookups stay in a register)
-  int32_t pos0 = -1;
   {
+    // ---- the hits of the block's rows
     uint32_t hits = 0;
     for (int64_t it = 0; it < trips; ++it) {
       const int64_t e = begin + it * kRowLanes + sub;
-      const int32_t pos = e < end ? found[e] : -1;
-      if (it == 0) pos0 = pos;
+      const int32_t pos = it == 0 ? pos0 : (e < end ? found[e] : -1);
       hits += __popc(half_ballot(pos >= 0, lane));
     }
     if (sub == 0) hits_of_row[row_in_block] = hits;
   }
   __syncthreads();
+  unsigned long long block_base = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kThreads / 64; ++k) block_base += base_part[k];
   int64_t w = static_cast<int64_t>(block_base);
   for (uint32_t k = 0; k < row_in_block; ++k) w += hits_of_row[k];
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
@@ -352,16 +364,15 @@ __global__ __launch_bounds__(kThreads) void k_emit_rows(
     for (int k = 0; k < kRowsPerBlock; ++k) all += hits_of_row[k];
     *totals.nnz = all;
   }
-  const double c = row_ok ? static_cast<double>(counts[r]) : 0.0;  // exact i64 -> f64 as in C
-  const double a = row_ok ? fabs(psi[r]) : 0.0;
   double f = 0.0;
   for (int64_t it = 0; it < trips; ++it) {
     const int64_t e = begin + it * kRowLanes + sub;
     const bool active = e < end;
     const int32_t pos = it == 0 ? pos0 : (active ? found[e] : -1);
     // ((counts * coeff) * |psi|) * x, each product rounded: build_matrix.c:41-42,49
-    const double head = active ? __dmul_rn(__dmul_rn(c, coeffs[e]), a) : 0.0;
-    const double x = active ? other_psi[e] : 0.0;
+    const double coeff = it == 0 ? coeff0 : (active ? coeffs[e] : 0.0);
+    const double head = active ? __dmul_rn(__dmul_rn(c, coeff), a) : 0.0;
+    const double x = it == 0 ? x0 : (active ? other_psi[e] : 0.0);
     const bool hit = active && pos >= 0;
     const uint32_t hit_mask = half_ballot(hit, lane);
     if (hit) {
