@@ -68,7 +68,12 @@ constexpr uint32_t kChunk = kGroupsPerChunk * kGroup;
 constexpr uint32_t kChunksPerSuper = 64;              // 131072 needles
 static_assert(kGroupsPerChunk <= 64 && kChunksPerSuper <= 64, "one wavefront sums a level");
 constexpr uint32_t kStagePlaces = kGroup * 5;         // 16-byte places of a wavefront's LDS staging area
-constexpr uint32_t kBucket = 8;                       // hash slots a probe reads: one 128-byte line
+// (slots of a bucket, 8 or 4.  Measured at K = 1e5: four — half the bytes per probe, ~8 % of the
+// look-ups in a second bucket — search 66.8 against 70.4 us, insert 15.1 against 12.5: no gain)
+#ifndef ASP_BUILD_BUCKET
+#define ASP_BUILD_BUCKET 8
+#endif
+constexpr uint32_t kBucket = ASP_BUILD_BUCKET;        // hash slots a probe reads
 
 // One hash slot: {fingerprint: the hash's high word | index + 1}, 0 = empty.  Eight bytes, so that
 // the whole hash (load factor <= 1/2: 2 MiB at K = 1e5) and the first words it is verified against
@@ -114,18 +119,32 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // L2).  vmcnt counts in order, so waiting for these loads is waiting for every older one too — the
 // asm's wait costs what the compiler's would; nothing of the asm is outstanding when the
 // compiler's own waits run.
-// The eight slots of bucket `b` — 64 bytes — in four 16-byte loads:
+// The slots of one bucket, two to a 16-byte load:
 __device__ __forceinline__ void load_bucket(const Slot *bucket, u32x4 (&s)[kBucket / 2]) {
-  static_assert(kBucket == 8, "four loads spelled out");
-  asm volatile(
-      "global_load_dwordx4 %0, %4, off\n\t"
-      "global_load_dwordx4 %1, %4, off offset:16\n\t"
-      "global_load_dwordx4 %2, %4, off offset:32\n\t"
-      "global_load_dwordx4 %3, %4, off offset:48\n\t"
-      "s_waitcnt vmcnt(0)"
-      : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3])
-      : "v"(bucket)
-      : "memory");
+  static_assert(kBucket == 8 || kBucket == 4, "the loads are spelled out");
+#if ASP_BUILD_BUCKET == 8
+  {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off\n\t"
+        "global_load_dwordx4 %1, %4, off offset:16\n\t"
+        "global_load_dwordx4 %2, %4, off offset:32\n\t"
+        "global_load_dwordx4 %3, %4, off offset:48\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3])
+        : "v"(bucket)
+        : "memory");
+  }
+#else
+  {
+    asm volatile(
+        "global_load_dwordx4 %0, %2, off\n\t"
+        "global_load_dwordx4 %1, %2, off offset:16\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(s[0]), "=&v"(s[1])
+        : "v"(bucket)
+        : "memory");
+  }
+#endif
 }
 
 // Index in the table of the needle with hash h, or -1 (`verify(index)`: the needle IS
