@@ -52,7 +52,8 @@ using asp::DeviceBuffer;
 
 // Timing-only ablations of k_search_flat (results are WRONG when set; never set in the product
 // build): 1 no probe, 2 probe without the verifying load, 3 every trip re-reads the chunk's first
-// 4 KiB (no HBM stream)
+// 4 KiB (no HBM stream), 4 no pass through LDS (a lane takes the first piece it loaded for its
+// key), 5 one 16-byte load per probe instead of the bucket's four, 6 no result stores
 #ifndef ASP_BUILD_ABL
 #define ASP_BUILD_ABL 0
 #endif
@@ -62,14 +63,26 @@ constexpr int kRowLanes = 32;                         // lanes cooperating on on
 constexpr int kRowsPerBlock = kThreads / kRowLanes;   // 8
 constexpr uint32_t kGroup = 64;                       // needles a wavefront resolves per trip
 constexpr uint32_t kSearchWaves = kThreads / 64;      // 4
-constexpr uint32_t kTrips = 8;                        // trips of a wavefront of k_search_flat
+#ifndef ASP_BUILD_SLOTS_PER_KEY
+#define ASP_BUILD_SLOTS_PER_KEY 2
+#endif
+constexpr uint64_t kSlotsPerKey = ASP_BUILD_SLOTS_PER_KEY;  // the hash's load factor is at most its inverse
+#ifndef ASP_BUILD_TRIPS
+#define ASP_BUILD_TRIPS 8
+#endif
+constexpr uint32_t kTrips = ASP_BUILD_TRIPS;                        // trips of a wavefront of k_search_flat
 constexpr uint32_t kGroupsPerChunk = kSearchWaves * kTrips;  // 32: a chunk = a workgroup = 2048 needles
 constexpr uint32_t kChunk = kGroupsPerChunk * kGroup;
 constexpr uint32_t kChunksPerSuper = 64;              // 131072 needles
 static_assert(kGroupsPerChunk <= 64 && kChunksPerSuper <= 64, "one wavefront sums a level");
 constexpr uint32_t kStagePlaces = kGroup * 5;         // 16-byte places of a wavefront's LDS staging area
-// (slots of a bucket, 8 or 4.  Measured at K = 1e5: four — half the bytes per probe, ~8 % of the
-// look-ups in a second bucket — search 66.8 against 70.4 us, insert 15.1 against 12.5: no gain)
+// (slots of a bucket: 8, 4 or 2.  Measured at K = 1e5, search / insert in us: eight 70.4 / 12.5,
+// four — half the bytes per probe, ~8 % of the look-ups in a second bucket — 66.8 / 15.1, two
+// 67.8 / 13.6, two at a load factor <= 1/4 66.5 / 9.4: 126-128 us per build whichever.  The
+// timing-only ablations above say where the search's 70 us are: 22 without any probe (the keys
+// alone, largely from the 256 MB last-level cache on repeated runs), 56 with one 16-byte load per
+// probe and the chain cut there, 59 without the verifying load, 68 without the stores, 42 with
+// the keys re-read from L2 — the dependent look-up, not the bytes.)
 #ifndef ASP_BUILD_BUCKET
 #define ASP_BUILD_BUCKET 8
 #endif
@@ -121,8 +134,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // compiler's own waits run.
 // The slots of one bucket, two to a 16-byte load:
 __device__ __forceinline__ void load_bucket(const Slot *bucket, u32x4 (&s)[kBucket / 2]) {
-  static_assert(kBucket == 8 || kBucket == 4, "the loads are spelled out");
-#if ASP_BUILD_BUCKET == 8
+  static_assert(kBucket == 8 || kBucket == 4 || kBucket == 2, "the loads are spelled out");
+#if ASP_BUILD_ABL == 5
+  {
+    asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(s[0]) : "v"(bucket) : "memory");
+    for (uint32_t j = 1; j < kBucket / 2; ++j) s[j] = u32x4{0u, 0u, 0u, 0u};
+  }
+#elif ASP_BUILD_BUCKET == 8
   {
     asm volatile(
         "global_load_dwordx4 %0, %4, off\n\t"
@@ -133,6 +151,10 @@ __device__ __forceinline__ void load_bucket(const Slot *bucket, u32x4 (&s)[kBuck
         : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3])
         : "v"(bucket)
         : "memory");
+  }
+#elif ASP_BUILD_BUCKET == 2
+  {
+    asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(s[0]) : "v"(bucket) : "memory");
   }
 #else
   {
@@ -225,13 +247,13 @@ __device__ __forceinline__ void search_flat_body(
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const uint32_t piece = i * kGroup + lane;  // piece & 3 of key piece >> 2
-      mine[piece + (piece >> 2)] = buf[i];
+      if (ASP_BUILD_ABL != 4) mine[piece + (piece >> 2)] = buf[i];
     }
     __builtin_amdgcn_wave_barrier();  // same wavefront: LDS ops are in order, keep them so
     uint64_t key[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const uint4 q = mine[lane * 5 + j];
+      const uint4 q = ASP_BUILD_ABL == 4 ? buf[0] : mine[lane * 5 + j];
       key[2 * j] = (static_cast<uint64_t>(q.y) << 32) | q.x;
       key[2 * j + 1] = (static_cast<uint64_t>(q.w) << 32) | q.z;
     }
@@ -263,9 +285,9 @@ __device__ __forceinline__ void search_flat_body(
     // a quarter of the lines per load instruction, and slower: 100 against 71 us)
     int32_t idx = -1;
     if (ASP_BUILD_ABL != 1 && wanted) idx = find_key(slots, bucket_mask, h, verify);
-    if (e < num_needles) found[e] = idx;
+    if (e < num_needles && (ASP_BUILD_ABL != 6 || idx == 12345)) found[e] = idx;
     const uint32_t hcount = static_cast<uint32_t>(__popcll(__ballot(idx >= 0)));
-    if (lane == 0) group_hits[group] = hcount;
+    if (lane == 0 && (ASP_BUILD_ABL != 6 || hcount == 99)) group_hits[group] = hcount;
     hits += hcount;
   }
   // hits of the chunk: to its own total and, atomically, to the total of its super-chunk
@@ -490,7 +512,7 @@ asp_build *asp_build_create(uint64_t num_spins, uint64_t num_other) {
             hipEventCreate(&b->ev_start) == hipSuccess && hipEventCreate(&b->ev_stop) == hipSuccess;
   if (!ok) asp::set_error(ASP_ERR_HIP, "could not create HIP stream/events");
   uint64_t slot_count = 64;
-  while (slot_count < 2 * K) slot_count <<= 1;  // load factor <= 1/2
+  while (slot_count < kSlotsPerKey * K) slot_count <<= 1;  // load factor <= 1 / kSlotsPerKey
   b->slot_mask = slot_count - 1;
   const uint64_t num_groups = (N + kGroup - 1) / kGroup;
   b->num_chunks = static_cast<uint32_t>((N + kChunk - 1) / kChunk);  // (N < 2^40)

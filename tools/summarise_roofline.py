@@ -132,6 +132,10 @@ probe = "profiles/r02_issue_rate_probe.txt"
 common = {
     "tag": tag,
     "library_fingerprint": fingerprint,  # of the newest cases; every case names its own
+    "carried_over_cases": "cases whose library_fingerprint is 47eedac1... were profiled before the per-set "
+                          "fingerprints existed: the colour set (sa_sweep.hip, sa_plan.cpp, their headers, the "
+                          "flags) is byte-identical at the measured commit 3d5814c and since (git diff empty), so "
+                          "they carry the fingerprint any build of those sources stamps",
     "cycles_per_valu_inst": 4.35,
     "cycles_per_valu_inst_source": probe + ": 4.2-4.4 SIMD cycles per wave64 instruction for every class "
                                    "the kernels' hot phases issue at 3-4 waves per SIMD (f64 FMA/add, VOP3 "
@@ -153,7 +157,9 @@ traffic_out = {
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum in separate passes "
               "(MI355X_MICROARCH.md, HBM/rocprofv3 section); FETCH_SIZE (KB) divided by the fraction of the "
               "true bytes it reports for 16-byte-per-lane streams on this chip (tools/fetch_calibrate.hip)",
-    "cases": {k: {kk: vv for kk, vv in v.items() if kk.startswith("hbm_") or kk in ("l2_hit_rate", "kernel", "K")}
+    "cases": {k: {kk: vv for kk, vv in v.items()
+                  if kk.startswith("hbm_") or kk in ("l2_hit_rate", "kernel", "K", "kernel_source_set",
+                                                     "source_set_fingerprint", "library_fingerprint", "tag")}
               for k, v in cases.items()},
 }
 with open(os.path.join(out_dir, "traffic.json"), "w") as o:
