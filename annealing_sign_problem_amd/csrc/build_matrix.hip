@@ -5,8 +5,9 @@
 // Data in HBM (all SoA except the 512-bit keys, which keep the reference's AoS
 // layout because that is what the ABI hands over):
 //   table   ls_bits512[K]   sorted, unique           table0  u64[K] = words[0]
-//   slots   u64[2^s]        open-addressing hash of table0: {fingerprint:32 | index+1:32}, load
-//                           factor <= 1/2, read a BUCKET of eight slots (64 bytes) per probe
+//   slots   u64[2^s]        blocked hash of table0: {fingerprint:32 | index+1:32}, load factor
+//                           <= 1/2; a key is in its home BUCKET of eight slots (64 bytes, one
+//                           probe) unless that is full, then in the next bucket that is not
 //   needles ls_bits512[N]   flat, row-major by row
 //   counts i64[K], psi f64[K], coeffs f64[N], other_psi f64[N], other_counts i64[K]
 //   offsets i64[K+1] (prefix sums of other_counts, formed on the host while the upload checks
@@ -16,13 +17,16 @@
 //   out: row u32[N], col u32[N], elements f64[N], field f64[K]
 //
 // One build = THREE launches on one stream, no host round trip except nnz:
-//   k_insert_keys   table -> table0 (words[0]) and table0 -> slots (linear probing from the
-//                   first slot of the key's bucket, atomicCAS).  Whether some table key has a
-//                   non-zero word 1..7 the host notes while it uploads the keys.
+//   k_insert_keys   table -> table0 (words[0]) and table0 -> slots (atomicCAS on the slots of the
+//                   bucket, from a slot the hash picks).  Whether some table key has a non-zero
+//                   word 1..7 the host notes while it uploads the keys.
 //   k_search_flat   the needles as ONE FLAT ARRAY, whatever row they belong to: a wavefront
 //                   resolves 64 consecutive needles per trip (4 KiB of contiguous memory, loaded
-//                   coalesced TWO TRIPS AHEAD of their use — the loads depend on nothing), each lane
-//                   one connection through the hash (the reference bsearches,
+//                   coalesced and requested BEFORE the previous trip's probe — the loads depend on
+//                   nothing, one round trip carries both), each lane one connection through
+//                   the hash: its bucket in four loads issued together, fingerprint candidates
+//                   verified against table0 and, for keys beyond 64 spins, against the other
+//                   seven words (the reference bsearches,
 //                   cbits/build_matrix.c:37-38; on a unique table any exact lookup returns the
 //                   same element).  Hits are counted per group of 64 needles (ballot), per chunk
 //                   (a workgroup) and, atomically, per super-chunk.  Round 3 searched row by row
@@ -32,8 +36,9 @@
 //                   first needle of its first row = super-chunks before (<= N / 131072 numbers) +
 //                   chunks before inside the super-chunk (<= 63) + groups before inside the chunk
 //                   (<= 31) + hits among the <= 63 needles before it inside its group — integer
-//                   sums, so the order does not matter; then 32 lanes per row: the row's hits
-//                   (first pass over `found`), COO triples in input order at ballot-prefix
+//                   sums, so the order does not matter; 32 lanes per row: the row's hits, its
+//                   first 32 connections and those totals are loaded in front of ONE barrier;
+//                   then COO triples in input order at ballot-prefix
 //                   positions (coalesced), and the row's field as a LEFT-TO-RIGHT sum over its
 //                   misses (the reference's rounding, cbits/build_matrix.c:49); last, every block
 //                   zeroes its share of the hash slots and block 0 the OTHER parity's super-chunk
@@ -70,7 +75,7 @@ constexpr uint64_t kSlotsPerKey = ASP_BUILD_SLOTS_PER_KEY;  // the hash's load f
 #ifndef ASP_BUILD_TRIPS
 #define ASP_BUILD_TRIPS 8
 #endif
-constexpr uint32_t kTrips = ASP_BUILD_TRIPS;                        // trips of a wavefront of k_search_flat
+constexpr uint32_t kTrips = ASP_BUILD_TRIPS;          // trips of a wavefront of k_search_flat (4 / 8 / 16: the same)
 constexpr uint32_t kGroupsPerChunk = kSearchWaves * kTrips;  // 32: a chunk = a workgroup = 2048 needles
 constexpr uint32_t kChunk = kGroupsPerChunk * kGroup;
 constexpr uint32_t kChunksPerSuper = 64;              // 131072 needles
